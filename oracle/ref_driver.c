@@ -1,0 +1,112 @@
+/* oracle/ref_driver.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A thin driver (our code) around the REAL reference decoder, compiled by
+ * oracle/Makefile together with the reference's own sources into
+ * oracle/_ref/libdvda_ref.so.  It feeds a raw MLP byte stream to the
+ * reference's mlp.h entry points exactly as the reference's track reader does
+ * (reference src/dvd-audio.c:1127-1140, 1181-1184, 1212-1215): one
+ * br_open_buffer() reader per "packet", dvda_mlpdecoder_decode_packet(), close.
+ *
+ * Nothing here is part of the product; the product never links this file.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mlp.h"   /* reference src/mlp.h:29-42 (pulled in via -I$(REF)/src) */
+
+/* Decodes `len` bytes of MLP data in chunks of `chunk` bytes (0 = one chunk),
+ * mimicking PES-payload sized feeding.  Output: planar int32, channel c at
+ * out[c * cap .. c * cap + frames), RIFF-WAVE channel order (that is what the
+ * reference appends into `samples`, src/mlp.c:527-533).
+ * Returns the number of PCM frames decoded, or -1 if `cap` was too small. */
+long
+ref_mlp_decode(const uint8_t *data, size_t len, size_t chunk,
+               unsigned g0_bps, unsigned g1_bps,
+               unsigned g0_rate, unsigned g1_rate,
+               unsigned channel_assignment,
+               unsigned nch, int32_t *out, size_t cap)
+{
+    struct stream_parameters p;
+    MLPDecoder *dec;
+    aa_int *samples = aa_int_new();
+    unsigned c;
+    size_t off = 0;
+    long total = 0;
+
+    p.group_0_bps = g0_bps;
+    p.group_1_bps = g1_bps;
+    p.group_0_rate = g0_rate;
+    p.group_1_rate = g1_rate;
+    p.channel_assignment = channel_assignment;
+
+    for (c = 0; c < nch; c++)
+        (void)samples->append(samples);
+
+    dec = dvda_open_mlpdecoder(&p);
+    if (chunk == 0)
+        chunk = len ? len : 1;
+
+    while (off < len) {
+        size_t n = (len - off < chunk) ? (len - off) : chunk;
+        BitstreamReader *r = br_open_buffer(data + off, (unsigned)n,
+                                            BS_BIG_ENDIAN);
+        total += dvda_mlpdecoder_decode_packet(dec, r, samples);
+        r->close(r);
+        off += n;
+    }
+
+    for (c = 0; c < nch; c++) {
+        const a_int *ch = samples->_[c];
+        if (ch->len > cap) {
+            total = -1;
+            break;
+        }
+        if (ch->len)
+            memcpy(out + (size_t)c * cap, ch->_, sizeof(int32_t) * ch->len);
+    }
+
+    dvda_close_mlpdecoder(dec);
+    samples->del(samples);
+    return total;
+}
+
+/* per-channel decoded length is not necessarily `frames` for malformed
+ * channel layouts; expose it for tests that care. */
+long
+ref_mlp_decode_lens(const uint8_t *data, size_t len, size_t chunk,
+                    unsigned g0_bps, unsigned g1_bps,
+                    unsigned g0_rate, unsigned g1_rate,
+                    unsigned channel_assignment,
+                    unsigned nch, unsigned *lens)
+{
+    struct stream_parameters p;
+    MLPDecoder *dec;
+    aa_int *samples = aa_int_new();
+    unsigned c;
+    size_t off = 0;
+    long total = 0;
+
+    p.group_0_bps = g0_bps;
+    p.group_1_bps = g1_bps;
+    p.group_0_rate = g0_rate;
+    p.group_1_rate = g1_rate;
+    p.channel_assignment = channel_assignment;
+    for (c = 0; c < nch; c++)
+        (void)samples->append(samples);
+    dec = dvda_open_mlpdecoder(&p);
+    if (chunk == 0)
+        chunk = len ? len : 1;
+    while (off < len) {
+        size_t n = (len - off < chunk) ? (len - off) : chunk;
+        BitstreamReader *r = br_open_buffer(data + off, (unsigned)n,
+                                            BS_BIG_ENDIAN);
+        total += dvda_mlpdecoder_decode_packet(dec, r, samples);
+        r->close(r);
+        off += n;
+    }
+    for (c = 0; c < nch; c++)
+        lens[c] = samples->_[c]->len;
+    dvda_close_mlpdecoder(dec);
+    samples->del(samples);
+    return total;
+}
