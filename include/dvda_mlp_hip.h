@@ -1,0 +1,131 @@
+/* dvda_mlp_hip.h -- C ABI of the MI355X-native MLP decode path.
+ *
+ * This is the drop-in boundary for the ONE hot path of tuffy/libdvd-audio:
+ * MLP (Meridian Lossless Packing) access-unit decode.  Everything a binding
+ * needs is plain C: pointers, sizes and opaque handles -- no C++/HIP/torch
+ * types.  Pointers named d_* are DEVICE pointers (HBM); `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).
+ *
+ * Two tiers:
+ *
+ *  (A) Batch tier -- the fast path.  Many independent MLP byte streams (titles,
+ *      tracks, or single access units) resident in HBM are framed, parsed,
+ *      filtered, rematrixed and written as planar int32 PCM in RIFF-WAVE
+ *      channel order by hand-written gfx950 kernels.  It replaces, for a whole
+ *      batch at once, what the reference does one PES payload at a time in
+ *        dvda_mlpdecoder_decode_packet()   reference src/mlp.h:39-42, src/mlp.c:344-354
+ *        mlpdecoder_decode/read_mlp_frame  reference src/mlp.c:360-405   (framing)
+ *        decode_mlp_frame                  reference src/mlp.c:407-612   (sync, substreams,
+ *                                                                          rematrix, shift, order)
+ *        decode_substream .. filter_channel reference src/mlp.c:714-1306 (parse + FIR/IIR)
+ *        rematrix_channels                 reference src/mlp.c:1308-1358
+ *        checkdata_callback                reference src/mlp.c:1360-1399 (parity / CRC-8)
+ *
+ *  (B) Streaming tier -- the mlp.h mirror (declared further below):
+ *      dvda_hip_open_mlpdecoder / dvda_hip_mlpdecoder_decode_packet /
+ *      dvda_hip_close_mlpdecoder keep the exact call shape and return-value
+ *      meaning of reference src/mlp.h:29-42 with the reference's BitstreamReader
+ *      and aa_int containers replaced by (pointer, length) pairs; INTEGRATION.md
+ *      shows the 40-line src/mlp.c replacement that binds them.
+ *
+ * All functions return 0 on success or a negative DVDA_HIP_E* code; they never
+ * fall back to a CPU implementation.
+ */
+#ifndef DVDA_MLP_HIP_H
+#define DVDA_MLP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVDA_HIP_OK          0
+#define DVDA_HIP_ENODEV     -1   /* no usable HIP device / HIP runtime error */
+#define DVDA_HIP_ENOMEM     -2
+#define DVDA_HIP_EINVAL     -3
+#define DVDA_HIP_ECAPACITY  -4   /* more streams / segments / bytes than the context was created for */
+#define DVDA_HIP_ESTATE     -5   /* call order violated (decode before index, ...) */
+
+/* per-stream / per-segment status bits (0 = decoded exactly as the reference
+ * decodes a well-formed stream).  The low 10 bits mirror oracle/mlp_oracle.h. */
+#define DVDA_ST_NO_SYNC      (1u << 0)   /* stream does not begin with a major sync             */
+#define DVDA_ST_SYNC_CHANGE  (1u << 1)   /* later major sync differs (reference drops the frame) */
+#define DVDA_ST_PARITY       (1u << 2)
+#define DVDA_ST_CRC          (1u << 3)
+#define DVDA_ST_EOF          (1u << 4)   /* parse ran past a substream / frame end               */
+#define DVDA_ST_RESTART      (1u << 5)   /* bad restart header                                   */
+#define DVDA_ST_PARAMS       (1u << 6)   /* bad decoding parameters                              */
+#define DVDA_ST_HUFFMAN      (1u << 7)   /* invalid residual code                                */
+#define DVDA_ST_FILTER       (1u << 8)   /* FIR+IIR order > 8 or shift mismatch                  */
+#define DVDA_ST_ENVELOPE     (1u << 9)   /* stream outside the reference's defined behaviour     */
+/* conditions the batch tier reports instead of guessing: */
+#define DVDA_ST_IRREGULAR    (1u << 16)  /* frame chain does not land on the next major sync     */
+#define DVDA_ST_TIMING       (1u << 17)  /* an access unit's PCM-frame count differs from the
+                                            stream's standard 40/80/160: needs the two-pass mode */
+#define DVDA_ST_MIDFRAME     (1u << 18)  /* matrix-class parameters changed after a frame's
+                                            first block: frame re-decoded in frame-buffered mode */
+#define DVDA_ST_CHAINED      (1u << 19)  /* segment's first block uses FIR/IIR history of the
+                                            previous segment (informational once chained)        */
+#define DVDA_ST_OVERFLOW     (1u << 20)  /* output capacity (out_stride) too small               */
+#define DVDA_ST_TRUNCATED    (1u << 21)  /* stream ends inside a frame (tail not consumed)       */
+
+typedef struct dvda_mlp_hip_ctx dvda_mlp_hip_ctx;
+
+typedef struct dvda_mlp_stream_info {
+    uint64_t mlp_frames;      /* complete access units found                                  */
+    uint64_t pcm_frames;      /* PCM frames decoded per channel                               */
+    uint64_t bytes_consumed;  /* bytes covered by complete access units                       */
+    uint32_t status;          /* DVDA_ST_* bits                                               */
+    uint32_t channels;        /* channel count of the stream's channel assignment            */
+    uint32_t substreams;      /* 1 or 2 (from the first major sync)                           */
+    uint32_t assignment;      /* 5-bit channel assignment                                     */
+    uint32_t group0_bps, group1_bps, group0_rate, group1_rate;  /* major sync codes          */
+    uint32_t segments;        /* restart-delimited segments (units of parallel decode)        */
+    uint32_t reserved;
+} dvda_mlp_stream_info;
+
+/* ------------------------------------------------------------------ tier A */
+
+/* Creates a decode context on HIP device `device` able to hold an index for up
+ * to max_streams streams / max_segments restart segments.  Device workspace is
+ * allocated here, never inside the decode calls (graph-capture friendly). */
+int dvda_mlp_hip_create(dvda_mlp_hip_ctx **ctx, int device, uint32_t max_streams,
+                        uint32_t max_segments);
+void dvda_mlp_hip_destroy(dvda_mlp_hip_ctx *ctx);
+
+/* Frame index (reference src/mlp.c:384-405 + the major-sync test of :614-654):
+ * finds every major-sync access unit, walks the 12-bit size chain between
+ * them, and derives each segment's first output row.  d_bytes must be readable
+ * for total_bytes + 64 bytes; stream i occupies
+ * [d_stream_off[i], d_stream_off[i] + d_stream_len[i]) and starts 16-byte aligned. */
+int dvda_mlp_hip_index(dvda_mlp_hip_ctx *ctx, const uint8_t *d_bytes, uint64_t total_bytes,
+                       const uint64_t *d_stream_off, const uint64_t *d_stream_len,
+                       uint32_t n_streams, void *stream);
+
+/* Decodes every indexed segment.  Stream i's PCM is written planar at
+ * d_pcm[d_out_off[i] + channel * d_out_stride[i] + pcm_frame], channel in
+ * RIFF-WAVE order (reference src/mlp.c:416-438, 527-533). */
+int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d_out_off,
+                        const uint64_t *d_out_stride, void *stream);
+
+/* Blocks until the work enqueued on `stream` is done and copies the per-stream
+ * results to host memory. */
+int dvda_mlp_hip_stream_info(dvda_mlp_hip_ctx *ctx, dvda_mlp_stream_info *infos, uint32_t n,
+                             void *stream);
+
+/* Number of segments found by the last index call (blocks on `stream`). */
+int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *ctx, uint32_t *n_segments, void *stream);
+
+/* Average duration in milliseconds of the decode kernel launches recorded since
+ * the last call (HIP events on the launch stream); *launches receives the count.
+ * Blocks until those launches have finished. */
+int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *launches);
+
+const char *dvda_mlp_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

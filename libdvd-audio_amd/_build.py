@@ -1,0 +1,57 @@
+"""In-tree build of the native pieces (hipcc / gcc, no network, no JIT cache).
+
+    libdvda_mlp_hip.so   HIP kernels + C ABI (include/dvda_mlp_hip.h), gfx950
+    libmlp_synth.so      synthetic MLP stream generator (tooling for tests/bench)
+
+The oracle (oracle/Makefile) is built by __graft_entry__.build(), not here: it is
+test infrastructure and the product never loads it.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(HERE, "libdvda_mlp_hip.so")
+SYNTH_SO = os.path.join(HERE, "synth", "libmlp_synth.so")
+
+HIP_SRCS = [os.path.join(HERE, "csrc", f) for f in
+            ("mlp_hip.hip", "mlp_decode.h", "mlp_index.h", "mlp_tables.h")]
+HIP_SRCS.append(os.path.join(os.path.dirname(HERE), "include", "dvda_mlp_hip.h"))
+SYNTH_SRCS = [os.path.join(HERE, "synth", f) for f in ("mlp_synth.c", "mlp_synth.h")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X decode path cannot be built")
+
+
+def build_hip(force=False, verbose=False):
+    if not force and not _stale(HIP_SO, HIP_SRCS):
+        return HIP_SO
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", HIP_SO, HIP_SRCS[0]]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, check=True)
+    return HIP_SO
+
+
+def build_synth(force=False):
+    if not force and not _stale(SYNTH_SO, SYNTH_SRCS):
+        return SYNTH_SO
+    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-o", SYNTH_SO, SYNTH_SRCS[0],
+                    "-lpthread"], check=True)
+    return SYNTH_SO
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_synth(force)

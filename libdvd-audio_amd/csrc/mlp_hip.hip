@@ -1,0 +1,350 @@
+// mlp_hip.hip -- C-ABI entry points of the batch tier (include/dvda_mlp_hip.h)
+// and the launch sequence of the gfx950 kernels.
+//
+//   index : k_sync_mask -> k_exscan_u32 -> k_sync_scatter -> k_chase ->
+//           k_exscan_u32 -> k_link                 (framing, src/mlp.c:384-405)
+//   decode: k_decode<NS> -> k_finalize             (src/mlp.c:407-1358)
+//
+// No allocation, no host synchronisation inside index/decode: the workspace is
+// sized at create time and segment counts stay on the device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/dvda_mlp_hip.h"
+#include "mlp_decode.h"
+#include "mlp_index.h"
+
+using namespace mlp;
+
+#define HIP_TRY(x)                                                                         \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "dvda_mlp_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                   \
+            return DVDA_HIP_ENODEV;                                                        \
+        }                                                                                  \
+    } while (0)
+
+struct dvda_mlp_hip_ctx {
+    int device;
+    uint32_t max_streams, max_segments;
+    // index workspace
+    uint8_t *d_masks;
+    uint64_t masks_cap;        // chunks
+    uint32_t *d_tile_count;    // [tiles + 1]
+    uint32_t *d_tile_base;     // [tiles + 1]; last = number of candidates
+    uint64_t tiles_cap;
+    uint64_t *d_cand_off;      // [max_segments]
+    SegRec *d_seg;             // [max_segments]
+    uint32_t *d_seg_frames;    // [max_segments + 1]
+    uint32_t *d_seg_fbase;     // [max_segments + 1]
+    uint32_t *d_seg_status;    // [max_segments]
+    uint32_t *d_seg_rows;      // [max_segments]
+    StreamRec *d_streams;      // [max_streams]
+    uint32_t *d_n_cand;        // single counter (points at d_tile_base[tiles])
+    int32_t *d_iir;
+    uint32_t iir_lanes;
+    // call state
+    const uint8_t *d_bytes;
+    uint64_t total_bytes;
+    const uint64_t *d_stream_off;
+    const uint64_t *d_stream_len;
+    uint32_t n_streams;
+    uint64_t tiles;
+    bool indexed;
+    uint32_t lanes_per_seg;
+    // timing of the decode kernel
+    std::vector<hipEvent_t> ev;   // pairs (start, stop)
+    size_t ev_used;
+};
+
+static void free_ws(dvda_mlp_hip_ctx *c)
+{
+    (void)hipFree(c->d_masks);
+    (void)hipFree(c->d_tile_count);
+    (void)hipFree(c->d_tile_base);
+    (void)hipFree(c->d_cand_off);
+    (void)hipFree(c->d_seg);
+    (void)hipFree(c->d_seg_frames);
+    (void)hipFree(c->d_seg_fbase);
+    (void)hipFree(c->d_seg_status);
+    (void)hipFree(c->d_seg_rows);
+    (void)hipFree(c->d_streams);
+    (void)hipFree(c->d_iir);
+    for (hipEvent_t e : c->ev)
+        (void)hipEventDestroy(e);
+}
+
+extern "C" const char *dvda_mlp_hip_version(void) { return "dvda-mlp-hip 0.1 (gfx950)"; }
+
+extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t max_streams,
+                                   uint32_t max_segments)
+{
+    if (!out || max_streams == 0 || max_segments == 0)
+        return DVDA_HIP_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "dvda_mlp_hip: no usable HIP device (count=%d, requested=%d)\n", ndev, device);
+        return DVDA_HIP_ENODEV;
+    }
+    HIP_TRY(hipSetDevice(device));
+    dvda_mlp_hip_ctx *c = new (std::nothrow) dvda_mlp_hip_ctx();
+    if (!c)
+        return DVDA_HIP_ENOMEM;
+    c->device = device;
+    c->max_streams = max_streams;
+    c->max_segments = max_segments;
+    c->masks_cap = 0;
+    c->tiles_cap = 0;
+    c->indexed = false;
+    c->ev_used = 0;
+    const size_t ns = (size_t)max_segments;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (e == hipSuccess)
+            e = hipMalloc(p, bytes ? bytes : 16);
+    };
+    alloc((void **)&c->d_cand_off, ns * sizeof(uint64_t));
+    alloc((void **)&c->d_seg, ns * sizeof(SegRec));
+    alloc((void **)&c->d_seg_frames, (ns + 1) * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_fbase, (ns + 1) * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_status, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_rows, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_streams, (size_t)max_streams * sizeof(StreamRec));
+    // two lanes per segment at most, rounded up to whole workgroups
+    c->iir_lanes = (uint32_t)(((2 * ns + DEC_THREADS - 1) / DEC_THREADS) * DEC_THREADS);
+    alloc((void **)&c->d_iir, (size_t)c->iir_lanes * MAXCH * 16 * sizeof(int32_t));
+    if (e != hipSuccess) {
+        fprintf(stderr, "dvda_mlp_hip: workspace allocation failed: %s\n", hipGetErrorString(e));
+        free_ws(c);
+        delete c;
+        return DVDA_HIP_ENOMEM;
+    }
+    *out = c;
+    return DVDA_HIP_OK;
+}
+
+extern "C" void dvda_mlp_hip_destroy(dvda_mlp_hip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    free_ws(c);
+    delete c;
+}
+
+// byte-proportional workspace grows on demand OUTSIDE the timed path: the first
+// index call for a larger batch (re)allocates, later calls of the same size reuse
+static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
+{
+    const uint64_t chunks = (total_bytes + 15) / 16 + 4;
+    const uint64_t tiles = (chunks + IDX_TILE_CHUNKS - 1) / IDX_TILE_CHUNKS;
+    if (chunks > c->masks_cap) {
+        (void)hipFree(c->d_masks);
+        c->d_masks = nullptr;
+        c->masks_cap = 0;
+        if (hipMalloc((void **)&c->d_masks, chunks) != hipSuccess)
+            return DVDA_HIP_ENOMEM;
+        c->masks_cap = chunks;
+    }
+    if (tiles > c->tiles_cap) {
+        (void)hipFree(c->d_tile_count);
+        (void)hipFree(c->d_tile_base);
+        c->d_tile_count = c->d_tile_base = nullptr;
+        c->tiles_cap = 0;
+        if (hipMalloc((void **)&c->d_tile_count, (tiles + 1) * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&c->d_tile_base, (tiles + 1) * sizeof(uint32_t)) != hipSuccess)
+            return DVDA_HIP_ENOMEM;
+        c->tiles_cap = tiles;
+    }
+    return DVDA_HIP_OK;
+}
+
+__global__ void k_init_streams(StreamRec *s, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        StreamRec r;
+        r.first_seg = 0xFFFFFFFFu;
+        r.n_seg = 0;
+        r.sync = 0;
+        r.status = 0;
+        r.frames = 0;
+        r.consumed = 0;
+        r.rows = 0;
+        s[i] = r;
+    }
+}
+
+extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, uint64_t total_bytes,
+                                  const uint64_t *d_stream_off, const uint64_t *d_stream_len,
+                                  uint32_t n_streams, void *stream_)
+{
+    if (!c || !d_bytes || !d_stream_off || !d_stream_len || n_streams == 0 || total_bytes == 0)
+        return DVDA_HIP_EINVAL;
+    if (n_streams > c->max_streams)
+        return DVDA_HIP_ECAPACITY;
+    if (((uintptr_t)d_bytes & 15) != 0)
+        return DVDA_HIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_byte_ws(c, total_bytes);
+    if (rc)
+        return rc;
+    c->d_bytes = d_bytes;
+    c->total_bytes = total_bytes;
+    c->d_stream_off = d_stream_off;
+    c->d_stream_len = d_stream_len;
+    c->n_streams = n_streams;
+    const uint64_t chunks = (total_bytes + 15) / 16;
+    const uint64_t tiles = (chunks + IDX_TILE_CHUNKS - 1) / IDX_TILE_CHUNKS;
+    c->tiles = tiles;
+    c->d_n_cand = c->d_tile_base + tiles;
+    const uint32_t ms = c->max_segments;
+
+    hipLaunchKernelGGL(k_init_streams, dim3((n_streams + 255) / 256), dim3(256), 0, st, c->d_streams,
+                       n_streams);
+    HIP_TRY(hipMemsetAsync(c->d_seg_status, 0, (size_t)ms * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(c->d_seg_rows, 0, (size_t)ms * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_sync_mask, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, d_bytes,
+                       total_bytes, c->d_masks, c->d_tile_count);
+    hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, c->d_tile_count, c->d_tile_base,
+                       (uint32_t)tiles, (const uint32_t *)nullptr, (uint32_t)tiles);
+    hipLaunchKernelGGL(k_sync_scatter, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, c->d_masks,
+                       total_bytes, c->d_tile_base, c->d_cand_off, ms);
+    hipLaunchKernelGGL(k_chase, dim3((ms + 255) / 256), dim3(256), 0, st, d_bytes, d_stream_off,
+                       d_stream_len, n_streams, c->d_cand_off, c->d_n_cand, ms, c->d_seg,
+                       c->d_seg_frames, c->d_streams);
+    hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, c->d_seg_frames, c->d_seg_fbase, 0u,
+                       (const uint32_t *)c->d_n_cand, ms);
+    hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
+                       c->d_n_cand, ms, c->d_seg, c->d_streams);
+    HIP_TRY(hipGetLastError());
+    c->indexed = true;
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off,
+                                   const uint64_t *d_out_stride, void *stream_)
+{
+    if (!c || !d_pcm || !d_out_off || !d_out_stride)
+        return DVDA_HIP_EINVAL;
+    if (!c->indexed)
+        return DVDA_HIP_ESTATE;
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    DecodeArgs a;
+    a.bytes = c->d_bytes;
+    a.total_bytes = c->total_bytes;
+    a.seg = c->d_seg;
+    a.seg_fbase = c->d_seg_fbase;
+    a.n_seg_ptr = c->d_n_cand;
+    a.max_seg = c->max_segments;
+    a.lanes_per_seg = 2;   // substream count is a per-stream property known only on the device
+    a.streams = c->d_streams;
+    a.stream_off = c->d_stream_off;
+    a.pcm = d_pcm;
+    a.out_off = d_out_off;
+    a.out_stride = d_out_stride;
+    a.seg_status = c->d_seg_status;
+    a.seg_rows = c->d_seg_rows;
+    a.iir_ws = c->d_iir;
+    a.total_lanes = c->iir_lanes;
+    a.lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
+    const uint64_t lanes = (uint64_t)c->max_segments * a.lanes_per_seg;
+    const unsigned blocks = (unsigned)((lanes + DEC_THREADS - 1) / DEC_THREADS);
+
+    if (c->ev_used + 2 > c->ev.size()) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+    HIP_TRY(hipEventRecord(c->ev[c->ev_used], st));
+    hipLaunchKernelGGL(k_decode<6>, dim3(blocks), dim3(DEC_THREADS), 0, st, a);
+    HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], st));
+    c->ev_used += 2;
+    hipLaunchKernelGGL(k_finalize, dim3((c->n_streams + 255) / 256), dim3(256), 0, st, c->d_seg,
+                       c->d_seg_fbase, c->d_seg_status, c->d_seg_rows, c->d_streams, c->n_streams);
+    HIP_TRY(hipGetLastError());
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *c, uint32_t lanes)
+{
+    if (!c || (lanes != 1 && lanes != 2))
+        return DVDA_HIP_EINVAL;
+    c->lanes_per_seg = lanes;
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_stream_info(dvda_mlp_hip_ctx *c, dvda_mlp_stream_info *infos, uint32_t n,
+                                        void *stream_)
+{
+    if (!c || !infos)
+        return DVDA_HIP_EINVAL;
+    if (!c->indexed)
+        return DVDA_HIP_ESTATE;
+    if (n > c->n_streams)
+        n = c->n_streams;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    std::vector<StreamRec> h(n);
+    HIP_TRY(hipMemcpy(h.data(), c->d_streams, (size_t)n * sizeof(StreamRec), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        dvda_mlp_stream_info &o = infos[i];
+        memset(&o, 0, sizeof(o));
+        o.mlp_frames = h[i].frames;
+        o.pcm_frames = h[i].rows;
+        o.bytes_consumed = h[i].consumed;
+        o.status = h[i].status;
+        o.assignment = (h[i].sync >> 16) & 0x1F;
+        o.channels = channel_count(o.assignment);
+        o.substreams = (h[i].sync >> 24) & 0xF;
+        o.group0_bps = h[i].sync & 0xF;
+        o.group1_bps = (h[i].sync >> 4) & 0xF;
+        o.group0_rate = (h[i].sync >> 8) & 0xF;
+        o.group1_rate = (h[i].sync >> 12) & 0xF;
+        o.segments = h[i].n_seg;
+    }
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *c, uint32_t *n_segments, void *stream_)
+{
+    if (!c || !n_segments)
+        return DVDA_HIP_EINVAL;
+    if (!c->indexed)
+        return DVDA_HIP_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    HIP_TRY(hipMemcpy(n_segments, c->d_n_cand, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return *n_segments > c->max_segments ? DVDA_HIP_ECAPACITY : DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *c, double *avg_ms, uint32_t *launches)
+{
+    if (!c || !avg_ms)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    double total = 0;
+    uint32_t n = 0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        total += ms;
+        n++;
+    }
+    c->ev_used = 0;
+    *avg_ms = n ? total / n : 0.0;
+    if (launches)
+        *launches = n;
+    return DVDA_HIP_OK;
+}

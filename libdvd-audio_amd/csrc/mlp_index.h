@@ -1,0 +1,318 @@
+// mlp_index.h -- frame-index kernels (framing of reference src/mlp.c:384-405 and
+// the major-sync test of src/mlp.c:614-654), done data-parallel on the GPU.
+//
+// The reference finds frames by a serial pointer chase over the 12-bit size
+// field.  Here every major-sync access unit is found by a coalesced pattern
+// scan over all even byte offsets, then one lane per candidate walks the size
+// chain only up to the next major sync (a handful of dependent loads), which
+// also validates the candidate: a false positive does not land on the next
+// candidate and is reported (DVDA_ST_IRREGULAR) instead of being trusted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mlp_tables.h"
+
+namespace mlp {
+
+// one restart-delimited segment = [major-sync frame, next major-sync frame)
+struct SegRec {
+    uint64_t off;       // absolute byte offset of the segment's first frame
+    uint64_t end;       // absolute byte offset one past its last complete frame
+    uint32_t stream;    // owning stream
+    uint32_t nframes;   // complete access units in the segment
+    uint32_t flags;     // DVDA_ST_* bits found while indexing
+    uint32_t sync;      // packed major sync: g0bps | g1bps<<4 | g0rate<<8 | g1rate<<12 | assignment<<16 | substreams<<24
+};
+
+struct StreamRec {
+    uint32_t first_seg;   // index of the stream's first segment (0xFFFFFFFF = none)
+    uint32_t n_seg;
+    uint32_t sync;        // packed major sync of the first segment
+    uint32_t status;
+    uint64_t frames;      // complete access units
+    uint64_t consumed;    // bytes covered by complete access units
+    uint64_t rows;        // PCM frames written per channel (filled by decode)
+};
+
+constexpr int IDX_THREADS = 256;
+constexpr int IDX_CHUNKS_PER_THREAD = 16;                       // 16-byte chunks
+constexpr int IDX_TILE_CHUNKS = IDX_THREADS * IDX_CHUNKS_PER_THREAD;  // 64 KiB tile per block
+
+__device__ __forceinline__ uint32_t ld_u8(const uint8_t *p, uint64_t i) { return p[i]; }
+
+// Is there a valid major-sync access unit at absolute even offset p?
+// (sync words 0xF8726F, stream type 0xBB, substream count 1|2, frame long enough
+// to hold the 28-byte sync: reference src/mlp.c:621-639)
+__device__ __forceinline__ bool sync_frame_at(const uint8_t *b, uint64_t p, uint64_t limit)
+{
+    if (p + 32 > limit)
+        return false;
+    const uint32_t size = 2u * (((ld_u8(b, p) & 0x0Fu) << 8) | ld_u8(b, p + 1));
+    if (size < 32)
+        return false;
+    if (ld_u8(b, p + 4) != 0xF8 || ld_u8(b, p + 5) != 0x72 || ld_u8(b, p + 6) != 0x6F ||
+        ld_u8(b, p + 7) != 0xBB)
+        return false;
+    const uint32_t count = ld_u8(b, p + 20) >> 4;
+    return count == 1 || count == 2;
+}
+
+// Pass 1: one mask byte per 16-byte chunk (bit j = candidate at chunk*16 + 2j),
+// plus the number of candidates per 64 KiB tile.
+__global__ __launch_bounds__(IDX_THREADS) void k_sync_mask(const uint8_t *__restrict__ bytes,
+                                                           uint64_t total_bytes,
+                                                           uint8_t *__restrict__ masks,
+                                                           uint32_t *__restrict__ tile_count)
+{
+    __shared__ uint32_t s_cnt[IDX_THREADS / 64];
+    const uint64_t n_chunks = (total_bytes + 15) >> 4;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * IDX_TILE_CHUNKS;
+    uint32_t cnt = 0;
+    for (int k = 0; k < IDX_CHUNKS_PER_THREAD; k++) {
+        const uint64_t chunk = tile0 + (uint64_t)k * IDX_THREADS + threadIdx.x;
+        if (chunk >= n_chunks)
+            break;
+        // 48-byte window: the pattern of the last offset (chunk*16+14) ends at +22
+        const uint4 *q = reinterpret_cast<const uint4 *>(bytes) + chunk;
+        const uint4 a = q[0], c = q[1];
+        uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            // halfwords j+2, j+3 of the window hold bytes p+4..p+7
+            const int h = j + 2;
+            const uint32_t lo = (h & 1) ? (w[h >> 1] >> 16) : (w[h >> 1] & 0xFFFFu);
+            const uint32_t hi = ((h + 1) & 1) ? (w[(h + 1) >> 1] >> 16) : (w[(h + 1) >> 1] & 0xFFFFu);
+            if (lo == 0x72F8u && hi == 0xBB6Fu) {
+                if (sync_frame_at(bytes, chunk * 16 + 2 * j, total_bytes))
+                    m |= 1u << j;
+            }
+        }
+        masks[chunk] = (uint8_t)m;
+        cnt += __popc(m);
+    }
+    // block reduce
+    for (int o = 32; o > 0; o >>= 1)
+        cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0)
+        s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int i = 0; i < IDX_THREADS / 64; i++)
+            t += s_cnt[i];
+        tile_count[blockIdx.x] = t;
+    }
+}
+
+// Single-workgroup exclusive scan of n uint32 values; out[n] receives the total.
+// n is read from *n_ptr when n_ptr != nullptr (device-side counts).
+__global__ __launch_bounds__(1024) void k_exscan_u32(const uint32_t *__restrict__ in,
+                                                     uint32_t *__restrict__ out, uint32_t n_host,
+                                                     const uint32_t *__restrict__ n_ptr,
+                                                     uint32_t n_cap)
+{
+    __shared__ uint32_t s_part[1024];
+    uint32_t n = n_ptr ? *n_ptr : n_host;
+    if (n > n_cap)
+        n = n_cap;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per;
+    const uint32_t hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++)
+        sum += in[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    // Hillis-Steele over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 1023)
+        out[n] = s_part[1023];
+}
+
+// Pass 2: ordered compaction of the candidates of each tile.
+__global__ __launch_bounds__(IDX_THREADS) void k_sync_scatter(const uint8_t *__restrict__ masks,
+                                                              uint64_t total_bytes,
+                                                              const uint32_t *__restrict__ tile_base,
+                                                              uint64_t *__restrict__ cand_off,
+                                                              uint32_t max_cand)
+{
+    __shared__ uint32_t s_scan[IDX_THREADS];
+    const uint64_t n_chunks = (total_bytes + 15) >> 4;
+    const uint64_t first = (uint64_t)blockIdx.x * IDX_TILE_CHUNKS +
+                           (uint64_t)threadIdx.x * IDX_CHUNKS_PER_THREAD;
+    uint8_t m[IDX_CHUNKS_PER_THREAD];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < IDX_CHUNKS_PER_THREAD; k++) {
+        m[k] = (first + k < n_chunks) ? masks[first + k] : 0;
+        cnt += __popc((uint32_t)m[k]);
+    }
+    s_scan[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < IDX_THREADS; o <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)o ? s_scan[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t at = tile_base[blockIdx.x] + s_scan[threadIdx.x] - cnt;
+    if (cnt == 0)
+        return;
+#pragma unroll
+    for (int k = 0; k < IDX_CHUNKS_PER_THREAD; k++) {
+        uint32_t mk = m[k];
+        while (mk) {
+            const int j = __ffs(mk) - 1;
+            mk &= mk - 1;
+            if (at < max_cand)
+                cand_off[at] = (first + k) * 16 + 2 * j;
+            at++;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t find_stream(const uint64_t *__restrict__ stream_off,
+                                                uint32_t n_streams, uint64_t p)
+{
+    // last stream whose start is <= p
+    uint32_t lo = 0, hi = n_streams;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (stream_off[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// Pass 3: one lane per candidate walks the size chain to the next major sync.
+__global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes,
+                                               const uint64_t *__restrict__ stream_off,
+                                               const uint64_t *__restrict__ stream_len,
+                                               uint32_t n_streams,
+                                               const uint64_t *__restrict__ cand_off,
+                                               const uint32_t *__restrict__ n_cand_ptr,
+                                               uint32_t max_cand, SegRec *__restrict__ seg,
+                                               uint32_t *__restrict__ seg_frames,
+                                               StreamRec *__restrict__ streams)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = *n_cand_ptr;
+    if (n_cand > max_cand)
+        n_cand = max_cand;
+    if (i >= n_cand)
+        return;
+    const uint64_t off = cand_off[i];
+    const uint32_t s = find_stream(stream_off, n_streams, off);
+    const uint64_t s_begin = stream_off[s];
+    const uint64_t s_end = s_begin + stream_len[s];
+    SegRec r;
+    r.off = off;
+    r.stream = s;
+    r.flags = 0;
+    r.nframes = 0;
+    r.sync = 0;
+    uint64_t p = off;
+    if (off >= s_end || ((off - s_begin) & 1) || !sync_frame_at(bytes, off, s_end)) {
+        // candidate in inter-stream padding, at an odd stream offset, or cut by
+        // the stream end: not a segment of this stream
+        r.flags = 1u << 16; // DVDA_ST_IRREGULAR
+        r.end = off;
+    } else {
+        r.sync = (ld_u8(bytes, off + 8) >> 4) | ((ld_u8(bytes, off + 8) & 0xFu) << 4) |
+                 ((ld_u8(bytes, off + 9) >> 4) << 8) | ((ld_u8(bytes, off + 9) & 0xFu) << 12) |
+                 ((ld_u8(bytes, off + 11) & 0x1Fu) << 16) | ((ld_u8(bytes, off + 20) >> 4) << 24);
+        uint32_t n = 0;
+        for (;;) {
+            if (p + 4 > s_end) {
+                if (p != s_end)
+                    r.flags |= 1u << 21; // DVDA_ST_TRUNCATED
+                break;
+            }
+            const uint32_t size = 2u * (((ld_u8(bytes, p) & 0x0Fu) << 8) | ld_u8(bytes, p + 1));
+            if (size < 4) {
+                r.flags |= 1u << 4; // DVDA_ST_EOF: the reference stalls on such a header
+                break;
+            }
+            if (p + size > s_end) {
+                r.flags |= 1u << 21;
+                break;
+            }
+            p += size;
+            n++;
+            if (sync_frame_at(bytes, p, s_end))
+                break;
+        }
+        r.nframes = n;
+        r.end = p;
+    }
+    seg[i] = r;
+    seg_frames[i] = r.nframes;
+    // the first candidate of a stream registers itself
+    bool first = (i == 0);
+    if (!first) {
+        const uint64_t prev = cand_off[i - 1];
+        first = prev < s_begin;
+    }
+    if (first) {
+        streams[s].first_seg = i;
+        streams[s].sync = r.sync;
+    }
+}
+
+// Pass 4 (after the exclusive scan of seg_frames): per-stream totals and the
+// landing check.  One lane per segment.
+__global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ stream_off,
+                                              const uint64_t *__restrict__ stream_len,
+                                              const uint32_t *__restrict__ n_cand_ptr,
+                                              uint32_t max_cand, SegRec *__restrict__ seg,
+                                              StreamRec *__restrict__ streams)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = *n_cand_ptr;
+    if (n_cand > max_cand)
+        n_cand = max_cand;
+    if (i >= n_cand)
+        return;
+    SegRec r = seg[i];
+    const uint32_t s = r.stream;
+    const uint64_t s_begin = stream_off[s];
+    const uint64_t s_end = s_begin + stream_len[s];
+    const bool last = (i + 1 == n_cand) || (seg[i + 1].stream != s);
+    uint32_t st = r.flags;
+    if (streams[s].first_seg == i && r.off != s_begin)
+        st |= 1u << 0; // DVDA_ST_NO_SYNC: data before the first major sync
+    if (!last && seg[i + 1].off != r.end)
+        st |= 1u << 16; // chain does not land on the next candidate
+    if (r.sync != streams[s].sync) {
+        // reference compares the five stream parameters (src/mlp.c:450-455) and
+        // keeps the first substream count
+        st |= 1u << 1;
+    }
+    if (st != r.flags) {
+        r.flags = st;
+        seg[i].flags = st;
+    }
+    if (st)
+        atomicOr(&streams[s].status, st);
+    if (last) {
+        streams[s].n_seg = i + 1 - streams[s].first_seg;
+        streams[s].consumed = r.end - s_begin;
+        (void)s_end;
+    }
+}
+
+} // namespace mlp

@@ -1,0 +1,179 @@
+"""ctypes binding of the C ABI in include/dvda_mlp_hip.h (batch tier).
+
+torch is used for what it is good at here -- device memory and streams; every
+compute step is the HIP library.  There is no CPU fallback: a missing library,
+a missing GPU or a HIP error raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _build
+
+ST = dict(NO_SYNC=1 << 0, SYNC_CHANGE=1 << 1, PARITY=1 << 2, CRC=1 << 3, EOF=1 << 4, RESTART=1 << 5,
+          PARAMS=1 << 6, HUFFMAN=1 << 7, FILTER=1 << 8, ENVELOPE=1 << 9, IRREGULAR=1 << 16,
+          TIMING=1 << 17, MIDFRAME=1 << 18, CHAINED=1 << 19, OVERFLOW=1 << 20, TRUNCATED=1 << 21)
+# bits that do not invalidate the decoded PCM
+ST_BENIGN = ST["TRUNCATED"]
+
+
+class StreamInfo(ctypes.Structure):
+    _fields_ = [("mlp_frames", ctypes.c_uint64), ("pcm_frames", ctypes.c_uint64),
+                ("bytes_consumed", ctypes.c_uint64), ("status", ctypes.c_uint32),
+                ("channels", ctypes.c_uint32), ("substreams", ctypes.c_uint32),
+                ("assignment", ctypes.c_uint32), ("group0_bps", ctypes.c_uint32),
+                ("group1_bps", ctypes.c_uint32), ("group0_rate", ctypes.c_uint32),
+                ("group1_rate", ctypes.c_uint32), ("segments", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
+           "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
+           "dvda_mlp_hip_version")
+
+
+def lib():
+    """Loads (building if stale) libdvda_mlp_hip.so; raises if it cannot."""
+    global _lib
+    if _lib is None:
+        so = _build.build_hip()
+        L = ctypes.CDLL(so)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.dvda_mlp_hip_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32, u32]
+        L.dvda_mlp_hip_destroy.argtypes = [vp]
+        L.dvda_mlp_hip_destroy.restype = None
+        L.dvda_mlp_hip_index.argtypes = [vp, vp, u64, vp, vp, u32, vp]
+        L.dvda_mlp_hip_decode.argtypes = [vp, vp, vp, vp, vp]
+        L.dvda_mlp_hip_stream_info.argtypes = [vp, ctypes.POINTER(StreamInfo), u32, vp]
+        L.dvda_mlp_hip_segment_count.argtypes = [vp, ctypes.POINTER(u32), vp]
+        L.dvda_mlp_hip_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
+        L.dvda_mlp_hip_set_lanes_per_segment.argtypes = [vp, u32]
+        L.dvda_mlp_hip_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        names = {-1: "ENODEV", -2: "ENOMEM", -3: "EINVAL", -4: "ECAPACITY", -5: "ESTATE"}
+        raise HipError("%s failed: %s (%d)" % (what, names.get(rc, "?"), rc))
+
+
+class Context:
+    """One decode context = one GPU's index workspace (dvda_mlp_hip_create)."""
+
+    def __init__(self, device=0, max_streams=1, max_segments=1024, lanes_per_segment=2):
+        self._h = ctypes.c_void_p()
+        _check(lib().dvda_mlp_hip_create(ctypes.byref(self._h), device, max_streams, max_segments),
+               "dvda_mlp_hip_create")
+        _check(lib().dvda_mlp_hip_set_lanes_per_segment(self._h, lanes_per_segment), "set_lanes")
+        self.device = device
+        self.n_streams = 0
+
+    def close(self):
+        if self._h:
+            lib().dvda_mlp_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def index(self, d_bytes_ptr, total_bytes, d_off_ptr, d_len_ptr, n_streams, stream=0):
+        self.n_streams = n_streams
+        _check(lib().dvda_mlp_hip_index(self._h, d_bytes_ptr, total_bytes, d_off_ptr, d_len_ptr,
+                                        n_streams, stream), "dvda_mlp_hip_index")
+
+    def decode(self, d_pcm_ptr, d_out_off_ptr, d_out_stride_ptr, stream=0):
+        _check(lib().dvda_mlp_hip_decode(self._h, d_pcm_ptr, d_out_off_ptr, d_out_stride_ptr, stream),
+               "dvda_mlp_hip_decode")
+
+    def stream_info(self, n=None, stream=0):
+        n = self.n_streams if n is None else n
+        arr = (StreamInfo * n)()
+        _check(lib().dvda_mlp_hip_stream_info(self._h, arr, n, stream), "dvda_mlp_hip_stream_info")
+        return arr
+
+    def segment_count(self, stream=0):
+        v = ctypes.c_uint32()
+        _check(lib().dvda_mlp_hip_segment_count(self._h, ctypes.byref(v), stream), "segment_count")
+        return int(v.value)
+
+    def kernel_time(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_uint32()
+        _check(lib().dvda_mlp_hip_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)), "kernel_time")
+        return float(ms.value), int(n.value)
+
+
+ROWS_PER_AU = {0: 40, 8: 40, 1: 80, 9: 80, 2: 160, 10: 160}
+
+
+def pack_streams(streams):
+    """list of uint8 arrays -> (flat uint8 array with 64 spare bytes, offsets, lengths); 16-byte aligned"""
+    offs, lens, pos = [], [], 0
+    for s in streams:
+        offs.append(pos)
+        lens.append(len(s))
+        pos += (len(s) + 15) & ~15
+    flat = np.zeros(pos + 64, np.uint8)
+    for s, o in zip(streams, offs):
+        flat[o:o + len(s)] = s
+    return flat, np.asarray(offs, np.uint64), np.asarray(lens, np.uint64)
+
+
+def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2):
+    """Decodes a list of complete MLP byte streams on the GPU.
+
+    Returns (pcm, infos): pcm[i] is an int32 array [channels, pcm_frames] in RIFF-WAVE
+    channel order -- what the reference appends to `samples` (src/mlp.c:527-533) --
+    and infos[i] the dvda_mlp_stream_info of stream i.  Raises HipError if the HIP
+    path is unavailable; never falls back to a CPU decoder.
+    """
+    import torch
+    if not torch.cuda.is_available():
+        raise HipError("no GPU visible to torch: the MLP decode path is HIP-only")
+    dev = torch.device("cuda", device)
+    flat, offs, lens = pack_streams(streams)
+    total = int(len(flat) - 64)
+    if max_segments is None:
+        max_segments = max(64, total // 64)
+    ctx = Context(device, len(streams), max_segments, lanes_per_segment)
+    try:
+        d_bytes = torch.from_numpy(flat).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), len(streams), st)
+        infos = ctx.stream_info(stream=st)
+        rows, nch = [], []
+        for inf in infos:
+            r = int(inf.mlp_frames) * ROWS_PER_AU.get(int(inf.group0_rate), 0)
+            rows.append(r)
+            nch.append(int(inf.channels))
+        out_off, pos = [], 0
+        for r, c in zip(rows, nch):
+            out_off.append(pos)
+            pos += r * c
+        d_pcm = torch.zeros(max(pos, 1), dtype=torch.int32, device=dev)
+        d_out_off = torch.tensor(out_off, dtype=torch.int64, device=dev)
+        d_stride = torch.tensor(rows, dtype=torch.int64, device=dev)
+        ctx.decode(d_pcm.data_ptr(), d_out_off.data_ptr(), d_stride.data_ptr(), st)
+        infos = ctx.stream_info(stream=st)
+        host = d_pcm.cpu().numpy()
+        pcm = []
+        for i, inf in enumerate(infos):
+            r, c = rows[i], nch[i]
+            a = host[out_off[i]:out_off[i] + r * c].reshape(c, r) if r * c else np.zeros((c, 0), np.int32)
+            pcm.append(a[:, :int(inf.pcm_frames)].copy())
+        return pcm, list(infos)
+    finally:
+        ctx.close()
