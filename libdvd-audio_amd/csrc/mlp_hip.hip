@@ -223,7 +223,7 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, c->d_seg_frames, c->d_seg_fbase, 0u,
                        (const uint32_t *)c->d_n_cand, ms);
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
-                       c->d_n_cand, ms, c->d_seg, c->d_streams);
+                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams);
     HIP_TRY(hipGetLastError());
     c->indexed = true;
     return DVDA_HIP_OK;

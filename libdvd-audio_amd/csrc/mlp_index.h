@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
                                               const uint64_t *__restrict__ stream_len,
                                               const uint32_t *__restrict__ n_cand_ptr,
                                               uint32_t max_cand, SegRec *__restrict__ seg,
+                                              const uint32_t *__restrict__ seg_fbase,
                                               StreamRec *__restrict__ streams)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
     if (last) {
         streams[s].n_seg = i + 1 - streams[s].first_seg;
         streams[s].consumed = r.end - s_begin;
+        streams[s].frames = seg_fbase[i + 1] - seg_fbase[streams[s].first_seg];
         (void)s_end;
     }
 }

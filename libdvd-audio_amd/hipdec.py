@@ -42,6 +42,13 @@ def lib():
     """Loads (building if stale) libdvda_mlp_hip.so; raises if it cannot."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; import it FIRST so this library
+        # binds to the same HIP runtime (two runtimes in one process do not share
+        # devices or pointers)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         so = _build.build_hip()
         L = ctypes.CDLL(so)
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
