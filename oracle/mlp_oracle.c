@@ -924,3 +924,30 @@ long mlp_oracle_decode(const uint8_t *data, size_t len, size_t chunk, unsigned n
     mlp_oracle_close(d);
     return total;
 }
+
+/* ------------------------------------------------------------ test hooks */
+/* reads n fields (width > 0: unsigned, width < 0: signed of -width bits) */
+int mlp_oracle_test_read(const uint8_t *data, size_t len, const int *widths, int n, long *out)
+{
+    bits_t b;
+    int i;
+    bits_init(&b, data, len);
+    for (i = 0; i < n; i++)
+        out[i] = widths[i] >= 0 ? (long)rd(&b, (unsigned)widths[i]) : (long)rd_signed(&b, (unsigned)-widths[i]);
+    return b.eof;
+}
+
+int mlp_oracle_test_crc8(unsigned i)
+{
+    build_tables();
+    return CRC8[i & 0xFF];
+}
+
+/* (value & 0xFF) | length << 8 for a 9-bit peek of code book 1..3 */
+int mlp_oracle_test_huff(unsigned book, unsigned peek9)
+{
+    build_tables();
+    if (book < 1 || book > 3)
+        return -1;
+    return ((int)HUFF[book][peek9 & 511].value & 0xFF) | (HUFF[book][peek9 & 511].len << 8);
+}

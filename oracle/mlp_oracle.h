@@ -56,6 +56,11 @@ long mlp_oracle_decode(const uint8_t *data, size_t len, size_t chunk,
                        unsigned nch, int32_t *out, size_t cap,
                        unsigned *status);
 
+/* test hooks (bit-reader contract, tables) */
+int mlp_oracle_test_read(const uint8_t *data, size_t len, const int *widths, int n, long *out);
+int mlp_oracle_test_crc8(unsigned i);
+int mlp_oracle_test_huff(unsigned book, unsigned peek9);
+
 #ifdef __cplusplus
 }
 #endif

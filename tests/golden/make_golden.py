@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz in the DEV CONTAINER (needs /root/reference compiled into
+oracle/_ref by `make -C oracle ref`).
+
+Each fixture = the bytes of one small synthetic MLP stream + the planar int32 PCM that the
+REAL reference decoder (tuffy/libdvd-audio src/mlp.c through its mlp.h entry points, fed in
+2013-byte chunks like PES payloads) produced for it.  Fixtures are data only: inputs and
+expected outputs.  The generator parameters are recorded so a fixture can be re-derived.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import libdvd_audio_amd as pkg  # noqa: E402
+from tests import oracle_lib  # noqa: E402
+
+syn = pkg.synth
+SF = syn.SF
+
+# name, assignment, rate_code, substreams, n_aus, profile, features, seed, restart_interval
+FIXTURES = [
+    ("recipe_6ch_96k", 12, 1, 1, 24, 0, 0, 1, 8),
+    ("recipe_6ch_96k_2ss", 12, 1, 2, 24, 0, 0, 2, 8),
+    ("recipe_2ch_96k", 1, 1, 1, 40, 0, 0, 3, 8),
+    ("recipe_6ch_192k", 12, 2, 1, 12, 0, 0, 4, 4),
+    ("recipe_mono_48k", 0, 0, 1, 40, 0, 0, 5, 8),
+    ("recipe_5ch_0x12_44k", 0x12, 8, 1, 24, 0, 0, 6, 8),
+    ("recipe_6ch_0x14_2ss", 0x14, 1, 2, 16, 0, 0, 7, 8),
+    ("fuzz_fast_6ch", 12, 1, 1, 24, 1, syn.SF_FAST, 11, 5),
+    ("fuzz_fast_6ch_2ss", 12, 1, 2, 24, 1, syn.SF_FAST, 12, 3),
+    ("fuzz_iir_state", 12, 1, 1, 16, 1, SF["IIR"] | SF["FIRRAND"] | SF["PARAMBLOCKS"], 13, 4),
+    ("fuzz_all_6ch", 12, 1, 1, 24, 1, syn.SF_ALL, 14, 6),
+    ("fuzz_all_2ch_2ss", 1, 2, 2, 16, 1, syn.SF_ALL, 15, 4),
+    ("fuzz_chained", 12, 1, 1, 24, 1, SF["CHAINED"] | SF["FIRRAND"], 16, 4),
+    ("fuzz_midframe", 12, 1, 1, 16, 1, SF["MIDMATRIX"] | SF["PARAMBLOCKS"] | SF["MATRIXRAND"] |
+     SF["QSS"] | SF["OUTSHIFT"] | SF["VARBLOCK"], 17, 4),
+    ("fuzz_varrows", 6, 0, 1, 24, 1, SF["VARROWS"] | SF["VARBLOCK"], 18, 8),
+]
+
+
+def main():
+    assert oracle_lib.Reference.available(), "build oracle/_ref first: make -C oracle ref"
+    ref = oracle_lib.Reference()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, asg, rate, S, naus, prof, feat, seed, ri in FIXTURES:
+        cfg = syn.make_cfg(assignment=asg, rate_code=rate, n_substreams=S, n_aus=naus, profile=prof,
+                           features=feat, restart_interval=ri)
+        data, frames = syn.stream(cfg, seed)
+        pcm, r = ref.decode(data, asg, rate, cfg.bps_code, frames, chunk=2013)
+        assert r == frames, (name, r, frames)
+        np.savez_compressed(os.path.join(here, name + ".npz"), mlp=data, pcm=pcm,
+                            meta=np.array([asg, rate, S, naus, prof, feat, seed, ri, cfg.bps_code],
+                                          np.int64))
+        print("%-24s %6d bytes -> %s PCM" % (name, len(data), pcm.shape))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""CPU tests of the oracle: pinned against the committed golden vectors (produced by the
+real reference, tests/golden/make_golden.py), the reference's own bit-reader known answers,
+and -- where oracle/_ref exists -- the compiled reference on fresh fuzz streams."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def test_golden_present():
+    assert len(GOLDEN) >= 12
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+@pytest.mark.parametrize("chunk", [0, 2013, 97])
+def test_oracle_matches_golden(oracle, path, chunk):
+    z = np.load(path)
+    want = z["pcm"]
+    got, frames, status = oracle.decode(z["mlp"], want.shape[0], want.shape[1], chunk=chunk)
+    assert status == 0
+    assert frames == want.shape[1]
+    assert np.array_equal(got, want)
+
+
+def test_bitreader_known_answers(oracle):
+    # reference src/bitstream.c:4864-4868 and 4940-4944 on the bytes B1 ED 3B C1
+    data = (ctypes.c_uint8 * 4)(0xB1, 0xED, 0x3B, 0xC1)
+    lib = oracle.lib
+    lib.mlp_oracle_test_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int),
+                                         ctypes.c_int, ctypes.POINTER(ctypes.c_long)]
+    for widths, want in (([2, 3, 5, 3, 19], [2, 6, 7, 5, 0x53BC1]),
+                         ([-2, -3, -5, -3, -19], [-2, -2, 7, -3, -181311]),
+                         ([0, 8, 0, 24], [0, 0xB1, 0, 0xED3BC1])):
+        w = (ctypes.c_int * len(widths))(*widths)
+        out = (ctypes.c_long * len(widths))()
+        eof = lib.mlp_oracle_test_read(data, 4, w, len(widths), out)
+        assert eof == 0
+        assert list(out) == want
+    # reading past the end raises the EOF condition (reference: br_abort -> longjmp)
+    w = (ctypes.c_int * 2)(32, 1)
+    out = (ctypes.c_long * 2)()
+    assert lib.mlp_oracle_test_read(data, 4, w, 2, out) == 1
+
+
+def test_crc8_table(oracle):
+    # rows of the reference table, src/mlp.c:1364-1366 and :1395
+    first = [0x00, 0x63, 0xC6, 0xA5, 0xEF, 0x8C, 0x29, 0x4A, 0xBD, 0xDE, 0x7B, 0x18, 0x52, 0x31, 0x94, 0xF7,
+             0x19, 0x7A, 0xDF, 0xBC, 0xF6, 0x95, 0x30, 0x53]
+    last = [0x3A, 0x59, 0xFC, 0x9F, 0xD5, 0xB6, 0x13, 0x70]
+    got = [oracle.lib.mlp_oracle_test_crc8(i) for i in range(256)]
+    assert got[:24] == first
+    assert got[248:] == last
+
+
+# value -> code string, from reference src/mlp_codebook{1,2,3}.json
+BOOKS = {
+    1: {0: "000000001", 1: "00000001", 2: "0000001", 3: "000001", 4: "00001", 5: "0001", 6: "001",
+        7: "100", 8: "101", 9: "110", 10: "111", 11: "011", 12: "0101", 13: "01001", 14: "010001",
+        15: "0100001", 16: "01000001", 17: "010000001"},
+    2: {0: "000000001", 1: "00000001", 2: "0000001", 3: "000001", 4: "00001", 5: "0001", 6: "001",
+        7: "10", 8: "11", 9: "011", 10: "0101", 11: "01001", 12: "010001", 13: "0100001",
+        14: "01000001", 15: "010000001"},
+    3: {0: "000000001", 1: "00000001", 2: "0000001", 3: "000001", 4: "00001", 5: "0001", 6: "001",
+        7: "1", 8: "011", 9: "0101", 10: "01001", 11: "010001", 12: "0100001", 13: "01000001",
+        14: "010000001"},
+}
+
+
+@pytest.mark.parametrize("book", [1, 2, 3])
+def test_codebook_lut(oracle, book):
+    lut = {}
+    for value, code in BOOKS[book].items():
+        lo = int(code, 2) << (9 - len(code))
+        for i in range(1 << (9 - len(code))):
+            lut[lo + i] = (value, len(code))
+    for peek in range(512):
+        e = oracle.lib.mlp_oracle_test_huff(book, peek)
+        if peek in lut:
+            assert (e & 0xFF, e >> 8) == lut[peek]
+        else:
+            assert e & 0xFF == 0xFF          # the two invalid all-zero-tail codes
+            assert peek in (0, 0x80)
+
+
+@pytest.mark.skipif(not oracle_lib.Reference.available(), reason="compiled reference not present")
+def test_oracle_vs_compiled_reference(oracle, pkg):
+    syn = pkg.synth
+    ref = oracle_lib.Reference()
+    n = 0
+    for asg, S in ((12, 1), (12, 2), (1, 1), (0x14, 2), (0, 1)):
+        for rate in (0, 1, 2):
+            for feat in (0, syn.SF_ALL, syn.SF_FAST):
+                for seed in range(2):
+                    cfg = syn.make_cfg(assignment=asg, rate_code=rate, n_substreams=S, n_aus=16,
+                                       profile=1 if feat else 0, features=feat,
+                                       restart_interval=[8, 3][seed])
+                    data, frames = syn.stream(cfg, 1000 + n)
+                    want, r = ref.decode(data, asg, rate, cfg.bps_code, frames)
+                    got, r2, st = oracle.decode(data, syn.channels(asg), frames, chunk=[0, 777][seed])
+                    assert st == 0 and r == r2 == frames
+                    assert np.array_equal(got, want)
+                    n += 1
+    assert n == 90
+
+
+def test_oracle_flags_corruption(oracle, pkg):
+    """Where the reference would assert()/abort, the oracle records an error bit."""
+    syn = pkg.synth
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=8)
+    data, frames = syn.stream(cfg, 5)
+    bad = data.copy()
+    bad[len(bad) // 2] ^= 0x10          # payload bit flip -> parity / CRC mismatch
+    _, _, st = oracle.decode(bad, 6, frames)
+    assert st & (4 | 8)
+    # a truncated stream simply leaves the tail queued: fewer frames, no error
+    _, r, st = oracle.decode(data[:len(data) - 11], 6, frames)
+    assert st == 0 and r == frames - 80
+    # empty input
+    _, r, st = oracle.decode(data[:0], 6, 16)
+    assert r == 0 and st == 0
