@@ -1,16 +1,26 @@
 // mlp_decode.h -- the fused MLP segment-decode kernel for gfx950.
 //
 // One lane owns one (restart segment, substream) and runs the whole path of
-// reference src/mlp.c:407-1358 for it in registers: bitstream parse (restart
-// header, decoding parameters, Huffman/LSB residual rows), FIR/IIR
-// reconstruction, noise + rematrix, output shift and RIFF channel mapping.
-// A wavefront therefore advances 64 independent bit-serial parses in lockstep;
-// rows are the lockstep unit (every lane emits one PCM frame per iteration, a
-// lane that reaches a block/frame boundary parses its header first), so lanes
-// whose streams use different block structures do not serialise each other's
-// row loops.  Nothing between the compressed bytes and the PCM store touches
-// HBM: residuals, filter state and matrix inputs live in VGPRs, parameters and
-// tables in LDS.
+// reference src/mlp.c:407-1358 for it: bitstream parse (restart header, decoding
+// parameters, Huffman/LSB residual rows), parity/CRC-8, FIR/IIR reconstruction,
+// noise + rematrix, output shift and RIFF channel mapping.  A wavefront advances
+// 64 independent bit-serial parses in lockstep; the lockstep unit is the PCM
+// frame (row): every loop iteration a lane first parses a block/frame header if
+// it needs one, then every active lane decodes one row.  Lanes whose streams
+// use different block structures therefore do not serialise each other's row
+// loops; only header parses diverge.
+//
+// Memory behaviour (what the v1 profile asked for, profiles/r01_v1_pmc_summary.txt):
+//   * compressed bytes reach a lane through a private 256-byte LDS ring filled by
+//     whole 64-byte chunks, prefetched one row ahead of use, so every input line
+//     is fetched from HBM once and no global load sits on the serial parse chain;
+//     the CRC-8/parity check rides on the ring consumption (each dword passes once)
+//   * residuals, FIR history/coefficients, codebook parameters and the first two
+//     matrices live in VGPRs; nothing between the ring and the PCM store touches
+//     memory (cold state only: IIR taps, matrices 3..6 in a workspace)
+//   * PCM leaves as 16-byte stores (4 frames x 1 channel per lane)
+//   * Huffman codes are decoded arithmetically (the three books share one
+//     structure, mlp_tables.h) -- no table, no LDS latency on the parse chain
 //
 // Reference quirks reproduced: FIR history is never cleared;
 // IIR history is cleared by every restart header; restart checksums are
@@ -29,11 +39,14 @@
 
 namespace mlp {
 
-constexpr int DEC_THREADS = 256;
+constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
-constexpr int MATCOEF = MAXCH + 2;
+constexpr int RING_PLANES = 16;                 // 16 planes x 16 B = 256 B per lane
+constexpr int RING_DWORDS = RING_PLANES * 4;    // 64 dwords
+constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
+constexpr int OUT_ROWS = 4;                     // PCM frames per 16-byte store
 
 // status bits (mirror include/dvda_mlp_hip.h)
 constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_RESTART = 1u << 5,
@@ -49,49 +62,194 @@ struct DecodeArgs {
     const uint32_t *seg_fbase;     // exclusive scan of frames per segment (global)
     const uint32_t *n_seg_ptr;
     uint32_t max_seg;
-    uint32_t lanes_per_seg;        // 1 or 2 (max substreams in the batch)
     StreamRec *streams;
-    const uint64_t *stream_off;
     int32_t *pcm;
     const uint64_t *out_off;
     const uint64_t *out_stride;
     uint32_t *seg_status;          // per segment, OR of both substream lanes
     uint32_t *seg_rows;            // per segment PCM frames written
-    int32_t *iir_ws;               // cold IIR storage: [(slot*16 + k) * total_lanes + lane]
+    int32_t *iir_ws;               // cold: [(slot*16 + j) * total_lanes + lane], j<8 coeff, 8+j history
+    uint32_t *mat_ws;              // cold: [(m*5 + j) * total_lanes + lane], packed int16 pairs
     uint32_t total_lanes;
 };
 
-__device__ const HuffTable d_huff = make_huff();
 __device__ const CrcTable d_crc = make_crc();
 
-// ------------------------------------------------------------------ bit reader
-// MSB-first reader over the global byte buffer (contract of reference
-// src/bitstream.c:1077-1111, 1198-1206): a 64-bit window refilled by aligned
-// dwords; read(0) returns 0 without consuming.
-struct BitReader {
-    const uint32_t *base;
-    uint64_t last_dw;   // highest loadable dword index
-    uint64_t next;      // next dword to load
-    uint64_t w;         // window, MSB aligned
-    int avail;          // valid bits in w
+__device__ __forceinline__ int32_t mask_q(int32_t x, uint32_t q)
+{
+    return (int32_t)((uint32_t)x & (0xFFFFFFFFu << q));
+}
+__device__ __forceinline__ uint32_t nib(uint32_t pack, uint32_t i) { return (pack >> (4 * i)) & 0xFu; }
+__device__ __forceinline__ int32_t lo16(uint32_t v) { return (int32_t)(v << 16) >> 16; }
+__device__ __forceinline__ int32_t hi16(uint32_t v) { return (int32_t)v >> 16; }
 
+// value the reference subtracts from huffman_offset (src/mlp.c:1152-1176)
+__device__ __forceinline__ int32_t huff_center(uint32_t codebook, uint32_t lb)
+{
+    if (codebook) {
+        const int ss = (int)lb + 2 - (int)codebook;
+        return 7 * (1 << lb) + (ss >= 0 ? (1 << ss) : 0);
+    }
+    const int ss = (int)lb - 1;
+    return ss >= 0 ? (1 << ss) : 0;
+}
+
+// ---------------------------------------------------------------- cold helpers
+// Synchronous fill of one 64-byte chunk into a lane's ring slots (used after
+// seeks and inside long headers; the row loop prefetches instead).
+// dst: this lane's 16-byte slot in the chunk's first plane; planes are 64 slots apart.
+__device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint4 *dst)
+{
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    dst[0] = a;
+    dst[64] = b;
+    dst[128] = c;
+    dst[192] = d;
+}
+
+// Byte-wise ends of the parity/CRC check (src/mlp.c:1397-1398 and 690-706).
+// st = crc | fin << 8 | bad_parity << 16 | bad_crc << 17 ; returns (par << 32) | new st.
+__device__ __attribute__((noinline)) uint64_t crc_tail(uint32_t v, uint32_t first_byte, uint32_t rem,
+                                                       uint32_t st, uint32_t par, const uint8_t *tab)
+{
+    uint32_t crc = st & 0xFF, fin = (st >> 8) & 0xFF, flags = st >> 16;
+    for (uint32_t i = first_byte; i < 4 && rem; i++, rem--) {
+        const uint32_t b = (v >> (8 * i)) & 0xFF;
+        if (rem > 3) {
+            par ^= b;
+            crc = tab[crc ^ b];
+        } else if (rem == 3) {              // last data byte: "final_crc" = state xor byte
+            par ^= b;
+            fin = crc ^ b;
+        } else if (rem == 2) {              // parity byte
+            uint32_t p = par ^ (par >> 16);
+            p = (p ^ (p >> 8)) & 0xFF;
+            if (((p ^ b) & 0xFF) != 0xA9)
+                flags |= 1;
+        } else {                            // CRC-8 byte
+            if (fin != b)
+                flags |= 2;
+        }
+    }
+    return ((uint64_t)par << 32) | (crc | (fin << 8) | (flags << 16));
+}
+
+// IIR taps (src/mlp.c:1289-1291, 1299) are rare on DVD-Audio discs: kept out of
+// line so the row loop does not carry their addresses in registers.
+__device__ __attribute__((noinline)) int64_t iir_mac(const int32_t *ws, uint32_t stride)
+{
+    int64_t acc = 0;
+    for (uint32_t j = 0; j < 8; j++)
+        acc += (int64_t)ws[(size_t)j * stride] * (int64_t)ws[(size_t)(8 + j) * stride];
+    return acc;
+}
+
+__device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride, int32_t v)
+{
+    for (int j = 7; j > 0; j--)
+        ws[(size_t)(8 + j) * stride] = ws[(size_t)(8 + j - 1) * stride];
+    ws[(size_t)8 * stride] = v;
+}
+
+// ------------------------------------------------------------------ bit reader
+// MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206)
+// over a per-lane LDS ring.  Ring layout: [plane][lane][4 dwords]; the dword with
+// absolute index d sits in plane (d >> 2) & 15, so a lane's 16-byte slots of one
+// plane are contiguous across lanes (conflict-free 16-byte fills).
+struct BitReader {
+    const uint4 *gsrc;      // global bytes as 16-byte units
+    uint32_t *ring;         // this lane's slot base: wave ring + lane * 4
+    const uint8_t *crc_tab; // LDS, 4 x 256
+    uint64_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
+    uint64_t next;          // absolute index of the next dword to consume
+    int32_t ahead;          // dwords resident in the ring at/after `next` (<= 0: none)
+    int32_t behind;         // dwords still resident in the ring before `next`
+    uint64_t w;             // bit window, MSB aligned
+    int32_t avail;          // valid bits in w
+    // parity / CRC-8 state riding on the dword stream
+    uint32_t crc_rem;       // bytes left in [substream data .. parity, crc]; 0 = off
+    uint32_t crc_st;        // crc | fin << 8 | bad_parity << 16 | bad_crc << 17
+    uint32_t par;
+
+    __device__ __forceinline__ uint32_t *slot(uint64_t d) const
+    {
+        return ring + (((uint32_t)(d >> 2) & (RING_PLANES - 1)) * 256u) + ((uint32_t)d & 3u);
+    }
+    __device__ __forceinline__ void fill_sync()
+    {
+        const uint64_t fillpos = next + (int64_t)ahead;          // multiple of 16
+        const uint64_t c = fillpos < max_chunk ? fillpos : max_chunk;
+        ring_fill_sync(gsrc + (c >> 2), reinterpret_cast<uint4 *>(slot(fillpos)));
+        filled();
+    }
+    // bookkeeping after one chunk has been written at next + ahead
+    __device__ __forceinline__ void filled()
+    {
+        ahead += CHUNK_DWORDS;
+        if (behind + ahead > RING_DWORDS)
+            behind = RING_DWORDS - ahead;                       // the oldest chunk was overwritten
+    }
+    __device__ __forceinline__ uint32_t fetch()
+    {
+        if (ahead <= 0)
+            fill_sync();
+        const uint32_t v = *slot(next);
+        next++;
+        ahead--;
+        behind++;
+        if (crc_rem) {
+            if (crc_rem >= 7) {
+                // slicing-by-4: only the first lookup depends on the running state
+                const uint32_t c = crc_st & 0xFF;
+                const uint32_t n = crc_tab[768 + ((c ^ v) & 0xFF)] ^ crc_tab[512 + ((v >> 8) & 0xFF)] ^
+                                   crc_tab[256 + ((v >> 16) & 0xFF)] ^ crc_tab[v >> 24];
+                crc_st = (crc_st & ~0xFFu) | n;
+                par ^= v;
+                crc_rem -= 4;
+            } else {
+                const uint64_t r = crc_tail(v, 0, crc_rem, crc_st, par, crc_tab);
+                crc_st = (uint32_t)r;
+                par = (uint32_t)(r >> 32);
+                crc_rem = crc_rem > 4 ? crc_rem - 4 : 0;
+            }
+        }
+        return __builtin_bswap32(v);
+    }
+    // repositions the reader; the parity/CRC check must be off (crc_rem == 0)
     __device__ __forceinline__ void seek_byte(uint64_t byte_pos)
     {
-        next = byte_pos >> 2;
+        const uint64_t t = byte_pos >> 2;
+        const int64_t delta = (int64_t)(t - next);
+        if (delta >= 0 ? delta < (int64_t)ahead : -delta <= (int64_t)behind) {
+            ahead -= (int32_t)delta;                             // still resident: just move
+            behind += (int32_t)delta;
+        } else {
+            ahead = -(int32_t)(t & (CHUNK_DWORDS - 1));          // ring empty, chunk aligned
+            behind = (int32_t)(t & (CHUNK_DWORDS - 1));
+        }
+        next = t;
+        const uint32_t d = fetch();
         const int skip = (int)(byte_pos & 3) * 8;
-        const uint64_t i = next < last_dw ? next : last_dw;
-        const uint32_t d = __builtin_bswap32(base[i]);
-        next++;
-        w = skip ? ((uint64_t)d << (32 + skip)) : ((uint64_t)d << 32);
+        w = ((uint64_t)d << 32) << skip;
         avail = 32 - skip;
+    }
+    // starts the parity/CRC check at byte_pos (just sought to): n data bytes + 2 trailer bytes
+    __device__ __forceinline__ void crc_begin(uint64_t byte_pos, uint32_t n_data)
+    {
+        const uint32_t first = (uint32_t)(byte_pos & 3);
+        const uint32_t total = n_data + 2;
+        const uint32_t raw = *slot(next - 1);                    // the dword seek_byte fetched
+        const uint64_t r = crc_tail(raw, first, total, 0x3C, 0, crc_tab);
+        crc_st = (uint32_t)r;
+        par = (uint32_t)(r >> 32);
+        const uint32_t used = 4 - first;
+        crc_rem = total > used ? total - used : 0;
     }
     __device__ __forceinline__ uint64_t tell_bits() const { return next * 32 - (uint64_t)avail; }
     __device__ __forceinline__ void refill()
     {
         while (avail <= 32) {
-            const uint64_t i = next < last_dw ? next : last_dw;
-            const uint32_t d = __builtin_bswap32(base[i]);
-            next++;
+            const uint32_t d = fetch();
             w |= (uint64_t)d << (32 - avail);
             avail += 32;
         }
@@ -114,92 +272,51 @@ struct BitReader {
         refill();
         if (n == 0)
             return 0;
-        const int32_t v = (int32_t)(w >> 32) >> (32 - n);   // arithmetic: sign bit first
+        const int32_t v = (int32_t)(w >> 32) >> (32 - n);   // sign bit first, two's complement
         w <<= n;
         avail -= n;
         return v;
     }
     __device__ __forceinline__ uint32_t peek9() const { return (uint32_t)(w >> 55); }
-    __device__ __forceinline__ void skip_bits(uint32_t n)
-    {
-        // arbitrary skip: re-seek
-        const uint64_t bit = tell_bits() + n;
-        seek_byte(bit >> 3);
-        take((int)(bit & 7));
-    }
 };
 
-// Per-wave LDS image of the per-lane decoder parameters.  Everything the row
-// loop needs per slot (slot k = channel min_channel + k) sits behind one
-// conflict-free ds_read_b128 (coefficients) and two ds_read_b32.
-template <int NS> struct WaveLds {
-    uint32_t cf[NS][64][4];          // FIR coefficients, 8 x int16 packed in pairs, zero beyond the order
-    uint32_t pk[NS][64];             // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
-                                     // fir_order<<19 | fir_shift<<23 | iir_shift<<27
-    int32_t sho[NS][64];             // signed huffman offset (src/mlp.c:1152-1176)
-    uint32_t mat[MAXMAT * 5][64];    // matrix coefficients (Q2.14 fits int16), packed in pairs
-    int32_t xch[MAXCH][64];          // substream exchange for 2-substream streams
-};
-
-__device__ __forceinline__ int32_t mask_q(int32_t x, uint32_t q)
+// Arithmetic decode of the three code books (mlp_tables.h: huff_entry):
+// returns value | length << 8, value 0xFF for the two invalid codes.
+__device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 {
-    return (int32_t)((uint32_t)x & (0xFFFFFFFFu << q));
-}
-__device__ __forceinline__ uint32_t nib(uint32_t pack, uint32_t i) { return (pack >> (4 * i)) & 0xFu; }
-__device__ __forceinline__ int32_t lo16(uint32_t v) { return (int32_t)(v << 16) >> 16; }
-__device__ __forceinline__ int32_t hi16(uint32_t v) { return (int32_t)v >> 16; }
-
-// value the reference subtracts from huffman_offset (src/mlp.c:1152-1176)
-__device__ __forceinline__ int32_t huff_center(uint32_t codebook, uint32_t lb)
-{
-    if (codebook) {
-        const int ss = (int)lb + 2 - (int)codebook;
-        return 7 * (1 << lb) + (ss >= 0 ? (1 << ss) : 0);
+    if (t & 0x100u) {
+        const uint32_t sub = 3u - cb;                        // extra bits after the leading 1
+        const uint32_t bits = (t >> (8u - sub)) & ((1u << sub) - 1u);
+        return (7u + bits) | ((sub + 1u) << 8);
     }
-    const int ss = (int)lb - 1;
-    return ss >= 0 ? (1 << ss) : 0;
-}
-
-// IIR taps (reference src/mlp.c:1289-1291, 1299) are rare on DVD-Audio discs: their
-// coefficients and history live in the workspace, [(slot * 16 + j) * stride + lane],
-// j < 8 coefficients, 8 + j history (8 = most recent).  Kept out of line so the
-// row loop does not carry their addresses in registers.
-__device__ __attribute__((noinline)) int64_t iir_mac(const int32_t *ws, uint32_t stride)
-{
-    int64_t acc = 0;
-    for (uint32_t j = 0; j < 8; j++)
-        acc += (int64_t)ws[(size_t)j * stride] * (int64_t)ws[(size_t)(8 + j) * stride];
-    return acc;
-}
-
-__device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride, int32_t v)
-{
-    for (int j = 7; j > 0; j--)
-        ws[(size_t)(8 + j) * stride] = ws[(size_t)(8 + j - 1) * stride];
-    ws[(size_t)8 * stride] = v;
+    const uint32_t r = t & 0x7Fu;
+    const uint32_t z = (uint32_t)__clz((int)r) - 25u;        // leading zeros in 7 bits, 7 if r == 0
+    const uint32_t len = (z > 6u ? 6u : z) + 3u;
+    const uint32_t base = cb == 1u ? 11u : (cb == 2u ? 9u : 8u);
+    uint32_t val = (t & 0x80u) ? base + z : 6u - z;
+    val = z > 6u ? 0xFFu : val;
+    return val | (len << 8);
 }
 
 // ----------------------------------------------------------------------------
-template <int NS>
+template <int NS, bool PAIRED>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
-    __shared__ uint16_t s_huff[3 * 512];
+    constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     __shared__ uint8_t s_crc[4 * 256];
-    __shared__ WaveLds<NS> s_w[DEC_WAVES];
+    __shared__ uint4 s_ring[DEC_WAVES][RING_PLANES][64];
+    __shared__ int32_t s_xch[PAIRED ? DEC_WAVES : 1][MAXCH][PAIRED ? 64 : 1];
 
-    for (int i = threadIdx.x; i < 3 * 512; i += DEC_THREADS)
-        s_huff[i] = d_huff.e[i];
     for (int i = threadIdx.x; i < 4 * 256; i += DEC_THREADS)
         s_crc[i] = d_crc.t[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    WaveLds<NS> &W = s_w[threadIdx.x >> 6];
+    const int wv = threadIdx.x >> 6;
     const uint32_t gl = blockIdx.x * DEC_THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
-    const uint32_t L = a.lanes_per_seg;
     const uint32_t segi = gl / L;
     const uint32_t sub = gl - segi * L;     // substream handled by this lane
     bool active = segi < n_seg;
@@ -227,12 +344,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         active = false;                                         // reported by the index
     if (active && (sub >= S || sr.nframes == 0))
         active = false;
+    if (active && S > L) {
+        status |= ST_ENVELOPE;                                  // 2-substream stream in a 1-lane launch
+        active = false;
+    }
     if (active && (rpa == 0 || nch_out == 0)) {
         status |= ST_ENVELOPE;
         active = false;
     }
     const bool is_last_sub = (sub + 1 == S);
-    const bool paired = (S == 2);
 
     uint64_t out_base = 0, out_stride = 0;
     if (active) {
@@ -241,16 +361,30 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     }
     const uint64_t row0 = (uint64_t)fbase * rpa;     // first PCM frame of this segment in its stream
     const uint64_t row_limit = row0 + (uint64_t)sr.nframes * rpa;
+    const bool vec_ok = (((out_base | out_stride) & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0);   // 16-byte aligned rows
 
     BitReader rd;
-    rd.base = reinterpret_cast<const uint32_t *>(a.bytes);
-    rd.last_dw = (a.total_bytes + 63) >> 2;
+    rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
+    rd.ring = reinterpret_cast<uint32_t *>(&s_ring[wv][0][lane]);
+    rd.crc_tab = s_crc;
+    rd.max_chunk = ((a.total_bytes + 63) >> 6) << 4;            // the chunk holding the spare bytes
     rd.next = 0;
+    rd.ahead = 0;
+    rd.behind = 0;
     rd.w = 0;
     rd.avail = 0;
+    rd.crc_rem = 0;
+    rd.crc_st = 0;
+    rd.par = 0;
 
-    // ---- per-lane decoder state (reference struct substream, src/mlp.c:103-115)
-    int32_t st[NS][8];                // FIR history in VGPRs: st[k][0] = most recent output
+    // ---- per-lane decoder state (reference struct substream, src/mlp.c:103-115), in VGPRs
+    int32_t st[NS][8];                // FIR history: st[k][0] = most recent output
+    uint32_t cf[NS][4];               // FIR coefficients, int16 pairs, zero beyond the order
+    uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
+                                      // fir_order<<19 | fir_shift<<23 | iir_shift<<27
+    int32_t sho[NS];                  // signed huffman offset (src/mlp.c:1152-1176)
+    uint32_t mreg[2][5];              // coefficients of matrices 0 and 1 (int16 pairs)
 #pragma unroll
     for (int k = 0; k < NS; k++) {
 #pragma unroll
@@ -258,10 +392,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             st[k][j] = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            W.cf[k][lane][j] = 0;
-        W.pk[k][lane] = 24u << 2;     // codebook 0, 24 LSBs
-        W.sho[k][lane] = -(1 << 23);
+            cf[k][j] = 0;
+        pk[k] = 24u << 2;             // codebook 0, 24 LSBs
+        sho[k] = -(1 << 23);
     }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            mreg[m][j] = 0;
     uint32_t flags = 0xFF;
     uint32_t block_size = 8;
     uint32_t min_ch = 0, max_ch = 0, max_mat_ch = 0, noise_shift = 0, seed = 0;
@@ -280,6 +419,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     uint32_t frames_done = 0;
     uint64_t row = row0;              // next output PCM frame index
     uint32_t rows_written = 0;
+    uint32_t rows_done = 0;           // rows decoded by this lane (lockstep across the wave)
+    int32_t ob[6][OUT_ROWS];          // output staging: last 4 PCM frames per output channel
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int i = 0; i < OUT_ROWS; i++)
+            ob[c][i] = 0;
 
     for (;;) {
         // =================================================== header phase
@@ -289,13 +435,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     active = false;
                 } else {
                     // ---- frame header "4p 12u 16p" (src/mlp.c:392-394)
+                    rd.crc_rem = 0;
                     rd.seek_byte(cur);
                     const uint32_t hdr = rd.read(32);
                     const uint32_t fsize = 2u * ((hdr >> 16) & 0xFFFu);
                     const uint64_t frame_end = cur + fsize;
                     // ---- major sync only on the segment's first frame (validated by the index)
                     if (frames_done == 0)
-                        rd.skip_bits(28 * 8);
+                        rd.seek_byte(cur + 4 + 28);
                     // ---- substream info "1u 1u 1u 1p 12u" (+16p) (src/mlp.c:463-468, 660-667)
                     uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0;
                     bool bad = false;
@@ -321,48 +468,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         status |= ST_EOF;
                         active = false;
                     } else {
-                        uint64_t data_hi = ss_hi;
-                        if (check0) {
-                            // ---- parity + CRC-8 over [ss_lo, ss_hi - 2) (src/mlp.c:675-706)
-                            data_hi = ss_hi - 2;
-                            uint32_t par = 0, crc = 0x3C, fin = 0;
-                            uint64_t p = ss_lo;
-                            if (data_hi > ss_lo) {
-                                const uint64_t last = data_hi - 1;   // final byte handled apart
-                                while (p < last && (p & 3)) {
-                                    const uint32_t bt = a.bytes[p++];
-                                    par ^= bt;
-                                    crc = s_crc[crc ^ bt];
-                                }
-                                const uint32_t *dw = reinterpret_cast<const uint32_t *>(a.bytes);
-                                while (p + 4 <= last) {
-                                    const uint32_t v = dw[p >> 2];
-                                    par ^= v;
-                                    crc = s_crc[768 + ((crc ^ v) & 0xFF)] ^ s_crc[512 + ((v >> 8) & 0xFF)] ^
-                                          s_crc[256 + ((v >> 16) & 0xFF)] ^ s_crc[v >> 24];
-                                    p += 4;
-                                }
-                                while (p < last) {
-                                    const uint32_t bt = a.bytes[p++];
-                                    par ^= bt;
-                                    crc = s_crc[crc ^ bt];
-                                }
-                                const uint32_t lb = a.bytes[last];
-                                par ^= lb;
-                                fin = crc ^ lb;                      // "final_crc"
-                            }
-                            par = (par ^ (par >> 16));
-                            par = (par ^ (par >> 8)) & 0xFF;
-                            if (((par ^ a.bytes[data_hi]) & 0xFF) != 0xA9) {
-                                status |= ST_PARITY;
-                                active = false;
-                            } else if ((fin & 0xFF) != a.bytes[data_hi + 1]) {
-                                status |= ST_CRC;
-                                active = false;
-                            }
-                        }
+                        const uint64_t data_hi = check0 ? ss_hi - 2 : ss_hi;
                         ss_end_bit = data_hi * 8;
                         rd.seek_byte(ss_lo);
+                        // ---- parity + CRC-8 over [ss_lo, ss_hi - 2) (src/mlp.c:675-706) ride on
+                        //      the ring consumption from here on
+                        if (check0)
+                            rd.crc_begin(ss_lo, (uint32_t)(data_hi - ss_lo));
                         in_frame = true;
                         frame_rows = 0;
                         blocks_in_frame = 0;
@@ -452,10 +564,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                     int32_t v = 0;
                                     if (c < max_mat_ch + 3 && rd.read(1))
                                         v = (int32_t)((uint32_t)rd.read_signed((int)frac + 2) << (14 - frac));
-                                    if (c & 1)
-                                        W.mat[m * 5 + (c >> 1)][lane] = pair | ((uint32_t)v << 16);
-                                    else
+                                    if (c & 1) {
+                                        const uint32_t word = pair | ((uint32_t)v << 16);
+                                        a.mat_ws[(size_t)(m * 5 + (c >> 1)) * a.total_lanes + gl] = word;
+#pragma unroll
+                                        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+                                            for (int jj = 0; jj < 5; jj++)
+                                                if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1))
+                                                    mreg[mm][jj] = word;
+                                    } else {
                                         pair = (uint32_t)v & 0xFFFFu;
+                                    }
                                 }
                             }
                         } else if (restart) {
@@ -487,28 +607,36 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                             qss_pack = 0;
                             qss_changed = true;
                         }
-                        // ---- per-channel parameters (runtime loop: cold code, LDS-resident state)
+                        // ---- per-channel parameters (runtime loop: cold code)
                         for (uint32_t k = 0; k < nslots && ok; k++) {
                             const uint32_t c = min_ch + k;
-                            const uint32_t pk = W.pk[k][lane];
-                            uint32_t codebook = pk & 3u;
-                            const uint32_t lb_old = (pk >> 2) & 31u, q_old = (pk >> 7) & 15u;
-                            uint32_t iir_order = (pk >> 15) & 0xFu, fir_order = (pk >> 19) & 0xFu;
-                            uint32_t fir_shift = (pk >> 23) & 0xFu, iir_shift = (pk >> 27) & 0xFu;
+                            uint32_t pk_old = 0;
+                            int32_t sho_old = 0;
+#pragma unroll
+                            for (int kk = 0; kk < NS; kk++)
+                                if ((uint32_t)kk == k) {
+                                    pk_old = pk[kk];
+                                    sho_old = sho[kk];
+                                }
+                            uint32_t codebook = pk_old & 3u;
+                            const uint32_t lb_old = (pk_old >> 2) & 31u, q_old = (pk_old >> 7) & 15u;
+                            uint32_t iir_order = (pk_old >> 15) & 0xFu, fir_order = (pk_old >> 19) & 0xFu;
+                            uint32_t fir_shift = (pk_old >> 23) & 0xFu, iir_shift = (pk_old >> 27) & 0xFu;
                             uint32_t lsbs = lb_old + q_old;
-                            int32_t hoff = W.sho[k][lane] + huff_center(codebook, lb_old);
+                            int32_t hoff = sho_old + huff_center(codebook, lb_old);
                             bool touched = qss_changed;
-                            bool zero_fir = false;
+                            bool new_fir = false;
+                            uint32_t ncf[4] = {0, 0, 0, 0};
                             if (rd.read(1)) {
                                 touched = true;
                                 if ((flags & 0x10u) && rd.read(1)) {               // flags[3]
                                     // ---- FIR (src/mlp.c:1033-1068)
                                     fir_order = rd.read(4);
+                                    new_fir = true;
                                     if (fir_order > 8) {
                                         ok = false;
                                     } else if (fir_order == 0) {
                                         fir_shift = 0;
-                                        zero_fir = true;
                                     } else {
                                         fir_shift = rd.read(4);
                                         const uint32_t cbits = rd.read(5);
@@ -516,15 +644,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                         if (cbits < 1 || cbits > 16 || cbits + cshift > 16) {
                                             ok = false;
                                         } else {
-                                            uint32_t pair = 0;
-                                            for (uint32_t j = 0; j < 8; j++) {
+#pragma unroll
+                                            for (int j = 0; j < 8; j++) {
                                                 int32_t v = 0;
-                                                if (j < fir_order)
+                                                if ((uint32_t)j < fir_order)
                                                     v = (int32_t)((uint32_t)rd.read_signed((int)cbits) << cshift);
                                                 if (j & 1)
-                                                    W.cf[k][lane][j >> 1] = pair | ((uint32_t)v << 16);
+                                                    ncf[j >> 1] |= (uint32_t)v << 16;
                                                 else
-                                                    pair = (uint32_t)v & 0xFFFFu;
+                                                    ncf[j >> 1] = (uint32_t)v & 0xFFFFu;
                                             }
                                             if (rd.read(1))
                                                 ok = false;
@@ -533,7 +661,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                 } else if (restart) {
                                     fir_order = 0;
                                     fir_shift = 0;
-                                    zero_fir = true;
+                                    new_fir = true;
                                 }
                                 if (ok && (flags & 0x20u) && rd.read(1)) {         // flags[2]
                                     // ---- IIR (src/mlp.c:1075-1119): cold storage in the workspace
@@ -589,15 +717,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                             } else if (restart) {
                                 touched = true;
                                 fir_order = fir_shift = iir_order = iir_shift = 0;
-                                zero_fir = true;
+                                new_fir = true;
                                 hoff = 0;
                                 codebook = 0;
                                 lsbs = 24;
-                            }
-                            if (zero_fir) {
-#pragma unroll
-                                for (int j = 0; j < 4; j++)
-                                    W.cf[k][lane][j] = 0;
                             }
                             if (touched && ok) {
                                 // derived per-block constants (src/mlp.c:1152-1176, 1260-1270)
@@ -625,10 +748,21 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                     }
                                     if (fir_order && frames_done == 0 && blocks_in_frame == 0)
                                         status |= ST_CHAINED;      // needs the previous segment's history
-                                    W.sho[k][lane] = hoff - huff_center(codebook, lb);
-                                    W.pk[k][lane] = codebook | (lb << 2) | (q << 7) | (shift << 11) |
-                                                    (iir_order << 15) | (fir_order << 19) | (fir_shift << 23) |
-                                                    (iir_shift << 27);
+                                    const int32_t nsho = hoff - huff_center(codebook, lb);
+                                    const uint32_t npk = codebook | (lb << 2) | (q << 7) | (shift << 11) |
+                                                         (iir_order << 15) | (fir_order << 19) |
+                                                         (fir_shift << 23) | (iir_shift << 27);
+#pragma unroll
+                                    for (int kk = 0; kk < NS; kk++)
+                                        if ((uint32_t)kk == k) {
+                                            pk[kk] = npk;
+                                            sho[kk] = nsho;
+                                            if (new_fir) {
+#pragma unroll
+                                                for (int j = 0; j < 4; j++)
+                                                    cf[kk][j] = ncf[j];
+                                            }
+                                        }
                                     iir_any = (iir_any & ~(1u << k)) | ((iir_order ? 1u : 0u) << k);
                                 }
                             }
@@ -654,6 +788,23 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             break;
 
         // ====================================================== row phase
+        // a row needs at most 8 x 33 + 6 bits = 34 bytes: keep 12 dwords resident, and fetch the
+        // next 64-byte chunk now so that it lands while the row is being decoded
+        if (active && rd.ahead < 12)
+            rd.fill_sync();
+        const bool pf = active && rd.ahead <= (RING_DWORDS - 2 * CHUNK_DWORDS);
+        uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+        uint64_t pf_pos = 0;
+        if (pf) {
+            pf_pos = rd.next + (int64_t)rd.ahead;
+            const uint64_t c = pf_pos < rd.max_chunk ? pf_pos : rd.max_chunk;
+            const uint4 *src = rd.gsrc + (c >> 2);
+            p0 = src[0];
+            p1 = src[1];
+            p2 = src[2];
+            p3 = src[3];
+        }
+
         if (active) {
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
             uint32_t bypass_bits = 0;
@@ -667,15 +818,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             for (int k = 0; k < NS; k++) {
                 val[k] = 0;
                 if ((uint32_t)k < nslots) {
-                    const uint32_t pk = W.pk[k][lane];
-                    const int32_t sho = W.sho[k][lane];
-                    const uint4 c4 = *reinterpret_cast<const uint4 *>(&W.cf[k][lane][0]);
-                    const uint32_t cb = pk & 3u, lb = (pk >> 2) & 31u, q = (pk >> 7) & 15u,
-                                   shift = (pk >> 11) & 15u;
+                    const uint32_t pkk = pk[k];
+                    const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
+                                   shift = (pkk >> 11) & 15u;
                     rd.refill();
                     uint32_t msb = 0;
                     if (cb) {
-                        const uint32_t e = s_huff[(cb - 1) * 512 + rd.peek9()];
+                        const uint32_t e = huff_decode(cb, rd.peek9());
                         msb = e & 0xFFu;
                         if (msb == 0xFFu) {
                             status |= ST_HUFFMAN;
@@ -684,16 +833,16 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         rd.take((int)(e >> 8));
                     }
                     const uint32_t lsbv = rd.take((int)lb);
-                    const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho) << q);
+                    const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
                     // ---- FIR/IIR reconstruction (src/mlp.c:1278-1300)
-                    int64_t acc = (int64_t)lo16(c4.x) * (int64_t)st[k][0];
-                    acc += (int64_t)hi16(c4.x) * (int64_t)st[k][1];
-                    acc += (int64_t)lo16(c4.y) * (int64_t)st[k][2];
-                    acc += (int64_t)hi16(c4.y) * (int64_t)st[k][3];
-                    acc += (int64_t)lo16(c4.z) * (int64_t)st[k][4];
-                    acc += (int64_t)hi16(c4.z) * (int64_t)st[k][5];
-                    acc += (int64_t)lo16(c4.w) * (int64_t)st[k][6];
-                    acc += (int64_t)hi16(c4.w) * (int64_t)st[k][7];
+                    int64_t acc = (int64_t)lo16(cf[k][0]) * (int64_t)st[k][0];
+                    acc += (int64_t)hi16(cf[k][0]) * (int64_t)st[k][1];
+                    acc += (int64_t)lo16(cf[k][1]) * (int64_t)st[k][2];
+                    acc += (int64_t)hi16(cf[k][1]) * (int64_t)st[k][3];
+                    acc += (int64_t)lo16(cf[k][2]) * (int64_t)st[k][4];
+                    acc += (int64_t)hi16(cf[k][2]) * (int64_t)st[k][5];
+                    acc += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
+                    acc += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
                     const bool iir_on = (iir_any >> k) & 1u;
                     if (iir_on)
                         acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
@@ -712,23 +861,33 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 
             // ---- gather the frame's channels 0..7 for the rematrix
             int32_t ch[MAXCH];
-            if (!paired && min_ch == 0) {
-#pragma unroll
-                for (int c = 0; c < MAXCH; c++)
-                    ch[c] = c < NS ? val[c < NS ? c : 0] : 0;
-            } else {
+            if (PAIRED) {
                 // substreams of one segment sit in adjacent lanes; exchange through LDS
-                const int slot0 = lane & ~(int)(L - 1);
+                const int slot0 = PAIRED ? (lane & ~1) : 0;
+                int32_t(*X)[PAIRED ? 64 : 1] = s_xch[PAIRED ? wv : 0];
 #pragma unroll
                 for (int k = 0; k < NS; k++)
                     if ((uint32_t)k < nslots && min_ch + k < MAXCH)
-                        W.xch[min_ch + k][slot0] = val[k];
+                        X[min_ch + k][slot0] = val[k];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int c = 0; c < MAXCH; c++)
-                    ch[c] = W.xch[c][slot0];
+                    ch[c] = X[c][slot0];
+            } else if (min_ch == 0) {
+#pragma unroll
+                for (int c = 0; c < MAXCH; c++)
+                    ch[c] = c < NS ? val[c < NS ? c : 0] : 0;
+            } else {
+                // single substream whose first channel is not 0: place by select
+#pragma unroll
+                for (int c = 0; c < MAXCH; c++) {
+                    ch[c] = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; k++)
+                        ch[c] = (min_ch + k == (uint32_t)c && (uint32_t)k < nslots) ? val[k] : ch[c];
+                }
             }
 
             if (is_last_sub) {
@@ -739,9 +898,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 seed = (seed << 16) ^ shifted ^ (shifted << 5);
                 for (uint32_t m = 0; m < matrix_len; m++) {
                     uint32_t mc[5];
+                    if (m < 2) {
 #pragma unroll
-                    for (int j = 0; j < 5; j++)
-                        mc[j] = W.mat[m * 5 + j][lane];
+                        for (int j = 0; j < 5; j++)
+                            mc[j] = m == 0 ? mreg[0][j] : mreg[1][j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 5; j++)
+                            mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
+                    }
                     int64_t acc = 0;
 #pragma unroll
                     for (int c = 0; c < MAXCH; c++) {
@@ -766,25 +931,43 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     for (int c = 0; c < MAXCH; c++)
                         ch[c] = ((uint32_t)c == oc) ? nv : ch[c];
                 }
-                // ---- output shift + RIFF order (src/mlp.c:515-533)
+                // ---- output shift (src/mlp.c:515-525) into the 4-frame staging registers
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    int32_t v = ch[c];
+                    if ((uint32_t)c <= max_mat_ch)
+                        v = (int32_t)((uint32_t)v << nib(oshift_pack, c));
+#pragma unroll
+                    for (int i = 0; i < OUT_ROWS - 1; i++)
+                        ob[c][i] = ob[c][i + 1];
+                    ob[c][OUT_ROWS - 1] = v;
+                }
+                // ---- RIFF order (src/mlp.c:527-533): every 4th frame, one 16-byte store per channel
                 if (row >= out_stride) {
                     status |= ST_OVERFLOW;
                     active = false;
                 } else if (row < row_limit) {
+                    rows_written++;
+                    if ((rows_done & (OUT_ROWS - 1)) == OUT_ROWS - 1) {
 #pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        if ((uint32_t)c < nch_out) {
-                            const uint32_t wc = nib(wavepk, c);
-                            int32_t v = ch[c];
-                            if ((uint32_t)c <= max_mat_ch)
-                                v = (int32_t)((uint32_t)v << nib(oshift_pack, c));
-                            a.pcm[out_base + (uint64_t)wc * out_stride + row] = v;
+                        for (int c = 0; c < 6; c++) {
+                            if ((uint32_t)c < nch_out) {
+                                const uint32_t wc = nib(wavepk, c);
+                                int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
+                                if (vec_ok) {
+                                    *reinterpret_cast<int4 *>(dst) = make_int4(ob[c][0], ob[c][1], ob[c][2], ob[c][3]);
+                                } else {
+#pragma unroll
+                                    for (int i = 0; i < OUT_ROWS; i++)
+                                        dst[i] = ob[c][i];
+                                }
+                            }
                         }
                     }
-                    rows_written++;
                 }
             }
             row++;
+            rows_done++;
             if (row > row_limit) {
                 status |= ST_TIMING;       // more PCM frames than the standard access-unit length
                 active = false;
@@ -798,14 +981,35 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         status |= ST_TIMING;
                         active = false;
                     }
+                    if (rd.tell_bits() > ss_end_bit) {
+                        status |= ST_EOF;
+                        active = false;
+                    }
+                    // ---- drain the rest of the substream through the parity/CRC check
+                    while (rd.crc_rem && active)
+                        rd.fetch();
+                    if (rd.crc_st >> 16) {
+                        status |= (rd.crc_st & (1u << 16)) ? ST_PARITY : ST_CRC;
+                        active = false;
+                    }
                     in_frame = false;
                     frames_done++;
-                }
-                if (rd.tell_bits() > ss_end_bit) {
+                } else if (rd.tell_bits() > ss_end_bit) {
                     status |= ST_EOF;
                     active = false;
                 }
             }
+        }
+
+        // ---- the prefetched chunk lands in the ring
+        if (pf) {
+            uint4 *dst = reinterpret_cast<uint4 *>(rd.slot(pf_pos));
+            dst[0] = p0;
+            dst[64] = p1;
+            dst[128] = p2;
+            dst[192] = p3;
+            if (rd.next + (int64_t)rd.ahead == pf_pos)
+                rd.filled();
         }
     }
 

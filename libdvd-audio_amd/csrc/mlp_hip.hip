@@ -48,6 +48,7 @@ struct dvda_mlp_hip_ctx {
     StreamRec *d_streams;      // [max_streams]
     uint32_t *d_n_cand;        // single counter (points at d_tile_base[tiles])
     int32_t *d_iir;
+    uint32_t *d_mat;
     uint32_t iir_lanes;
     // call state
     const uint8_t *d_bytes;
@@ -76,6 +77,7 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_seg_rows);
     (void)hipFree(c->d_streams);
     (void)hipFree(c->d_iir);
+    (void)hipFree(c->d_mat);
     for (hipEvent_t e : c->ev)
         (void)hipEventDestroy(e);
 }
@@ -119,6 +121,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     // two lanes per segment at most, rounded up to whole workgroups
     c->iir_lanes = (uint32_t)(((2 * ns + DEC_THREADS - 1) / DEC_THREADS) * DEC_THREADS);
     alloc((void **)&c->d_iir, (size_t)c->iir_lanes * MAXCH * 16 * sizeof(int32_t));
+    alloc((void **)&c->d_mat, (size_t)c->iir_lanes * MAXMAT * 5 * sizeof(uint32_t));
     if (e != hipSuccess) {
         fprintf(stderr, "dvda_mlp_hip: workspace allocation failed: %s\n", hipGetErrorString(e));
         free_ws(c);
@@ -245,18 +248,18 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.seg_fbase = c->d_seg_fbase;
     a.n_seg_ptr = c->d_n_cand;
     a.max_seg = c->max_segments;
-    a.lanes_per_seg = 2;   // substream count is a per-stream property known only on the device
     a.streams = c->d_streams;
-    a.stream_off = c->d_stream_off;
     a.pcm = d_pcm;
     a.out_off = d_out_off;
     a.out_stride = d_out_stride;
     a.seg_status = c->d_seg_status;
     a.seg_rows = c->d_seg_rows;
     a.iir_ws = c->d_iir;
+    a.mat_ws = c->d_mat;
     a.total_lanes = c->iir_lanes;
-    a.lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
-    const uint64_t lanes = (uint64_t)c->max_segments * a.lanes_per_seg;
+    // two lanes per segment unless the caller knows every stream has one substream
+    const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
+    const uint64_t lanes = (uint64_t)c->max_segments * lanes_per_seg;
     const unsigned blocks = (unsigned)((lanes + DEC_THREADS - 1) / DEC_THREADS);
 
     if (c->ev_used + 2 > c->ev.size()) {
@@ -267,7 +270,10 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         c->ev.push_back(e1);
     }
     HIP_TRY(hipEventRecord(c->ev[c->ev_used], st));
-    hipLaunchKernelGGL(k_decode<6>, dim3(blocks), dim3(DEC_THREADS), 0, st, a);
+    if (lanes_per_seg == 2)
+        hipLaunchKernelGGL((k_decode<6, true>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_decode<6, false>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
     HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], st));
     c->ev_used += 2;
     hipLaunchKernelGGL(k_finalize, dim3((c->n_streams + 255) / 256), dim3(256), 0, st, c->d_seg,
