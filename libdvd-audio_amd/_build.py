@@ -34,15 +34,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the MI355X decode path cannot be built")
 
 
-def build_hip(force=False, verbose=False):
-    if not force and not _stale(HIP_SO, HIP_SRCS):
-        return HIP_SO
+def build_hip(force=False, verbose=False, defines=(), out=None):
+    """defines/out: diagnostic variants for tools/ab_bench.sh (never the shipped library)."""
+    target = out or HIP_SO
+    if not force and not _stale(target, HIP_SRCS):
+        return target
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", HIP_SO, HIP_SRCS[0]]
+           "-o", target, HIP_SRCS[0]] + ["-D" + d for d in defines]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
-    return HIP_SO
+    return target
 
 
 def build_synth(force=False):

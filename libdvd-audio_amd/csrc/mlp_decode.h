@@ -48,6 +48,26 @@ constexpr int RING_DWORDS = RING_PLANES * 4;    // 64 dwords
 constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
 constexpr int OUT_ROWS = 4;                     // PCM frames per 16-byte store
 
+// Diagnostic build switches (tools/ab_bench.sh): never defined in the shipped library.
+//   DVDA_EXP_NOSTORE  keep PCM values alive but do not store them (prices the write path)
+//   DVDA_EXP_NOCRC    skip the parity/CRC-8 check (prices it)
+//   DVDA_EXP_STAMP    accumulate s_memtime deltas per loop phase into DecodeArgs.dbg
+#if defined(DVDA_EXP_STAMP)
+#define DVDA_STAMP(i)                                                    \
+    do {                                                                 \
+        const unsigned long long t_ = clock64();                         \
+        stamp_acc[i] += t_ - stamp_t;                                    \
+        stamp_t = t_;                                                    \
+    } while (0)
+#else
+#define DVDA_STAMP(i) ((void)0)
+#endif
+#if defined(DVDA_EXP_NOSTORE)
+#define DVDA_STORE_V4(dst, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
+#else
+#define DVDA_STORE_V4(dst, a_, b_, c_, d_) (*reinterpret_cast<int4 *>(dst) = make_int4(a_, b_, c_, d_))
+#endif
+
 // status bits (mirror include/dvda_mlp_hip.h)
 constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_RESTART = 1u << 5,
                    ST_PARAMS = 1u << 6, ST_HUFFMAN = 1u << 7, ST_FILTER = 1u << 8,
@@ -71,6 +91,7 @@ struct DecodeArgs {
     int32_t *iir_ws;               // cold: [(slot*16 + j) * total_lanes + lane], j<8 coeff, 8+j history
     uint32_t *mat_ws;              // cold: [(m*5 + j) * total_lanes + lane], packed int16 pairs
     uint32_t total_lanes;
+    unsigned long long *dbg;       // diagnostic builds only (DVDA_EXP_STAMP): per-phase cycle sums
 };
 
 __device__ const CrcTable d_crc = make_crc();
@@ -156,48 +177,46 @@ __device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride,
 // over a per-lane LDS ring.  Ring layout: [plane][lane][4 dwords]; the dword with
 // absolute index d sits in plane (d >> 2) & 15, so a lane's 16-byte slots of one
 // plane are contiguous across lanes (conflict-free 16-byte fills).
+//
+// Three stream dwords are held in registers: (hi, lo) form the 64-bit window the
+// current symbol is cut from at bit offset ofs (< 32 between symbols) and nx is
+// the dword after them, already loaded -- so advancing the window never waits
+// for LDS.  The row loop advances branch-free (select by ofs >> 5); the cold
+// header parser uses read()/advance().  Dword indices are 32-bit: a batch
+// buffer is limited to 16 GiB (checked by dvda_mlp_hip_index).
 struct BitReader {
     const uint4 *gsrc;      // global bytes as 16-byte units
     uint32_t *ring;         // this lane's slot base: wave ring + lane * 4
     const uint8_t *crc_tab; // LDS, 4 x 256
-    uint64_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
-    uint64_t next;          // absolute index of the next dword to consume
-    int32_t ahead;          // dwords resident in the ring at/after `next` (<= 0: none)
-    int32_t behind;         // dwords still resident in the ring before `next`
-    uint64_t w;             // bit window, MSB aligned
-    int32_t avail;          // valid bits in w
-    // parity / CRC-8 state riding on the dword stream
+    uint32_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
+    uint32_t hi, lo, nx;    // stream dwords next-3, next-2, next-1 (big-endian order)
+    uint32_t ofs;           // bit offset of the next unread bit inside (hi:lo)
+    uint32_t next;          // absolute index of the dword after nx
+    uint32_t fillpos;       // ring holds dwords [lo_valid, fillpos); fillpos is a multiple of 16
+    uint32_t lo_valid;
+    // parity / CRC-8 over the substream, hashed from the ring behind the parser
+    uint32_t crc_pos;       // next dword to hash
     uint32_t crc_rem;       // bytes left in [substream data .. parity, crc]; 0 = off
     uint32_t crc_st;        // crc | fin << 8 | bad_parity << 16 | bad_crc << 17
     uint32_t par;
 
-    __device__ __forceinline__ uint32_t *slot(uint64_t d) const
+    __device__ __forceinline__ uint32_t *slot(uint32_t d) const
     {
-        return ring + (((uint32_t)(d >> 2) & (RING_PLANES - 1)) * 256u) + ((uint32_t)d & 3u);
+        return ring + (((d >> 2) & (RING_PLANES - 1)) * 256u) + (d & 3u);
     }
-    __device__ __forceinline__ void fill_sync()
-    {
-        const uint64_t fillpos = next + (int64_t)ahead;          // multiple of 16
-        const uint64_t c = fillpos < max_chunk ? fillpos : max_chunk;
-        ring_fill_sync(gsrc + (c >> 2), reinterpret_cast<uint4 *>(slot(fillpos)));
-        filled();
-    }
-    // bookkeeping after one chunk has been written at next + ahead
+    __device__ __forceinline__ uint32_t ld(uint32_t d) const { return __builtin_bswap32(*slot(d)); }
     __device__ __forceinline__ void filled()
     {
-        ahead += CHUNK_DWORDS;
-        if (behind + ahead > RING_DWORDS)
-            behind = RING_DWORDS - ahead;                       // the oldest chunk was overwritten
+        fillpos += CHUNK_DWORDS;
+        if (fillpos - lo_valid > (uint32_t)RING_DWORDS)
+            lo_valid = fillpos - RING_DWORDS;                   // the oldest chunk was overwritten
     }
-    __device__ __forceinline__ uint32_t fetch()
+    // hashes ring dwords [crc_pos, limit) into the parity/CRC state (limit <= fillpos)
+    __device__ __forceinline__ void crc_catchup(uint32_t limit)
     {
-        if (ahead <= 0)
-            fill_sync();
-        const uint32_t v = *slot(next);
-        next++;
-        ahead--;
-        behind++;
-        if (crc_rem) {
+        while (crc_rem && (int32_t)(limit - crc_pos) > 0) {
+            const uint32_t v = *slot(crc_pos);
+            crc_pos++;
             if (crc_rem >= 7) {
                 // slicing-by-4: only the first lookup depends on the running state
                 const uint32_t c = crc_st & 0xFF;
@@ -213,71 +232,93 @@ struct BitReader {
                 crc_rem = crc_rem > 4 ? crc_rem - 4 : 0;
             }
         }
-        return __builtin_bswap32(v);
     }
-    // repositions the reader; the parity/CRC check must be off (crc_rem == 0)
+    __device__ __forceinline__ void fill_sync()
+    {
+        // the chunk about to be overwritten must already be hashed
+        if (crc_rem && (int32_t)(fillpos + CHUNK_DWORDS - RING_DWORDS - crc_pos) > 0)
+            crc_catchup(fillpos);
+        const uint32_t c = fillpos < max_chunk ? fillpos : max_chunk;
+        ring_fill_sync(gsrc + (c >> 2), reinterpret_cast<uint4 *>(slot(fillpos)));
+        filled();
+    }
+    __device__ __forceinline__ void ensure(uint32_t n)           // n dwords resident at/after next
+    {
+        while ((int32_t)(fillpos - next) < (int32_t)n)
+            fill_sync();
+    }
+    __device__ __forceinline__ void advance()
+    {
+        ensure(1);
+        hi = lo;
+        lo = nx;
+        nx = ld(next);
+        next++;
+        ofs -= 32;
+    }
+    // repositions the reader; the parity/CRC check must be finished (crc_rem == 0)
     __device__ __forceinline__ void seek_byte(uint64_t byte_pos)
     {
-        const uint64_t t = byte_pos >> 2;
-        const int64_t delta = (int64_t)(t - next);
-        if (delta >= 0 ? delta < (int64_t)ahead : -delta <= (int64_t)behind) {
-            ahead -= (int32_t)delta;                             // still resident: just move
-            behind += (int32_t)delta;
-        } else {
-            ahead = -(int32_t)(t & (CHUNK_DWORDS - 1));          // ring empty, chunk aligned
-            behind = (int32_t)(t & (CHUNK_DWORDS - 1));
+        const uint32_t t = (uint32_t)(byte_pos >> 2);
+        if (!((int32_t)(t - lo_valid) >= 0 && (int32_t)(fillpos - t) > 0)) {
+            fillpos = t & ~(uint32_t)(CHUNK_DWORDS - 1);        // outside the ring: restart it
+            lo_valid = fillpos;
         }
         next = t;
-        const uint32_t d = fetch();
-        const int skip = (int)(byte_pos & 3) * 8;
-        w = ((uint64_t)d << 32) << skip;
-        avail = 32 - skip;
+        ensure(3);
+        hi = ld(t);
+        lo = ld(t + 1);
+        nx = ld(t + 2);
+        next = t + 3;
+        ofs = (uint32_t)(byte_pos & 3) * 8;
     }
     // starts the parity/CRC check at byte_pos (just sought to): n data bytes + 2 trailer bytes
     __device__ __forceinline__ void crc_begin(uint64_t byte_pos, uint32_t n_data)
     {
         const uint32_t first = (uint32_t)(byte_pos & 3);
         const uint32_t total = n_data + 2;
-        const uint32_t raw = *slot(next - 1);                    // the dword seek_byte fetched
-        const uint64_t r = crc_tail(raw, first, total, 0x3C, 0, crc_tab);
+        crc_pos = (uint32_t)(byte_pos >> 2);
+        const uint64_t r = crc_tail(*slot(crc_pos), first, total, 0x3C, 0, crc_tab);
+        crc_pos++;
         crc_st = (uint32_t)r;
         par = (uint32_t)(r >> 32);
         const uint32_t used = 4 - first;
         crc_rem = total > used ? total - used : 0;
     }
-    __device__ __forceinline__ uint64_t tell_bits() const { return next * 32 - (uint64_t)avail; }
-    __device__ __forceinline__ void refill()
+    // hashes the rest of the substream (through its two trailer bytes)
+    __device__ __forceinline__ void crc_finish()
     {
-        while (avail <= 32) {
-            const uint32_t d = fetch();
-            w |= (uint64_t)d << (32 - avail);
-            avail += 32;
+        while (crc_rem) {
+            if ((int32_t)(fillpos - crc_pos) <= 0)
+                fill_sync();
+            crc_catchup(crc_pos + 1);
         }
     }
-    // n in [0, 32]; requires avail >= n
-    __device__ __forceinline__ uint32_t take(int n)
+    __device__ __forceinline__ uint64_t tell_bits() const { return (uint64_t)(next - 3) * 32 + ofs; }
+    __device__ __forceinline__ uint32_t peek32() const
     {
-        const uint32_t v = n ? (uint32_t)(w >> (64 - n)) : 0u;
-        w = n ? (w << n) : w;
-        avail -= n;
+        return (uint32_t)(((((uint64_t)hi) << 32) | lo) << ofs >> 32);
+    }
+    // n in [0, 32]
+    __device__ __forceinline__ uint32_t read(uint32_t n)
+    {
+        const uint32_t top = peek32();
+        const uint32_t v = n ? top >> (32 - n) : 0u;
+        ofs += n;
+        while (ofs >= 32)
+            advance();
         return v;
     }
-    __device__ __forceinline__ uint32_t read(int n)
+    __device__ __forceinline__ int32_t read_signed(uint32_t n)
     {
-        refill();
-        return take(n);
-    }
-    __device__ __forceinline__ int32_t read_signed(int n)
-    {
-        refill();
         if (n == 0)
             return 0;
-        const int32_t v = (int32_t)(w >> 32) >> (32 - n);   // sign bit first, two's complement
-        w <<= n;
-        avail -= n;
+        const int32_t v = (int32_t)peek32() >> (32 - n);         // sign bit first, two's complement
+        ofs += n;
+        while (ofs >= 32)
+            advance();
         return v;
     }
-    __device__ __forceinline__ uint32_t peek9() const { return (uint32_t)(w >> 55); }
 };
 
 // Arithmetic decode of the three code books (mlp_tables.h: huff_entry):
@@ -368,12 +409,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
     rd.ring = reinterpret_cast<uint32_t *>(&s_ring[wv][0][lane]);
     rd.crc_tab = s_crc;
-    rd.max_chunk = ((a.total_bytes + 63) >> 6) << 4;            // the chunk holding the spare bytes
-    rd.next = 0;
-    rd.ahead = 0;
-    rd.behind = 0;
-    rd.w = 0;
-    rd.avail = 0;
+    rd.max_chunk = (uint32_t)(((a.total_bytes + 63) >> 6) << 4);  // the chunk holding the spare bytes
+    rd.hi = rd.lo = rd.nx = 0;
+    rd.ofs = 0;
+    rd.next = 3;
+    rd.fillpos = 0;
+    rd.lo_valid = 0;
+    rd.crc_pos = 0;
     rd.crc_rem = 0;
     rd.crc_st = 0;
     rd.par = 0;
@@ -385,6 +427,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                       // fir_order<<19 | fir_shift<<23 | iir_shift<<27
     int32_t sho[NS];                  // signed huffman offset (src/mlp.c:1152-1176)
     uint32_t mreg[2][5];              // coefficients of matrices 0 and 1 (int16 pairs)
+    uint32_t mnoise[2] = {0, 0};      // their two noise coefficients (follow channel max_matrix_channel)
 #pragma unroll
     for (int k = 0; k < NS; k++) {
 #pragma unroll
@@ -427,7 +470,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         for (int i = 0; i < OUT_ROWS; i++)
             ob[c][i] = 0;
 
+#if defined(DVDA_EXP_STAMP)
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = clock64();
+#endif
     for (;;) {
+        DVDA_STAMP(5);
         // =================================================== header phase
         if (active && rows_left == 0) {
             if (!in_frame) {
@@ -473,8 +521,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         rd.seek_byte(ss_lo);
                         // ---- parity + CRC-8 over [ss_lo, ss_hi - 2) (src/mlp.c:675-706) ride on
                         //      the ring consumption from here on
+#if !defined(DVDA_EXP_NOCRC)
                         if (check0)
                             rd.crc_begin(ss_lo, (uint32_t)(data_hi - ss_lo));
+#endif
                         in_frame = true;
                         frame_rows = 0;
                         blocks_in_frame = 0;
@@ -559,11 +609,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                 }
                                 outch_pack |= oc << (4 * m);
                                 bypass_mask |= rd.read(1) << m;
-                                uint32_t pair = 0;
+                                uint32_t pair = 0, noise = 0;
                                 for (uint32_t c = 0; c < 10; c++) {
                                     int32_t v = 0;
                                     if (c < max_mat_ch + 3 && rd.read(1))
-                                        v = (int32_t)((uint32_t)rd.read_signed((int)frac + 2) << (14 - frac));
+                                        v = (int32_t)((uint32_t)rd.read_signed(frac + 2) << (14 - frac));
+                                    if (c == max_mat_ch + 1)
+                                        noise |= (uint32_t)v & 0xFFFFu;
+                                    if (c == max_mat_ch + 2)
+                                        noise |= (uint32_t)v << 16;
                                     if (c & 1) {
                                         const uint32_t word = pair | ((uint32_t)v << 16);
                                         a.mat_ws[(size_t)(m * 5 + (c >> 1)) * a.total_lanes + gl] = word;
@@ -577,6 +631,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                         pair = (uint32_t)v & 0xFFFFu;
                                     }
                                 }
+                                if (m == 0)
+                                    mnoise[0] = noise;
+                                if (m == 1)
+                                    mnoise[1] = noise;
                             }
                         } else if (restart) {
                             matrix_len = 0;
@@ -648,7 +706,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                             for (int j = 0; j < 8; j++) {
                                                 int32_t v = 0;
                                                 if ((uint32_t)j < fir_order)
-                                                    v = (int32_t)((uint32_t)rd.read_signed((int)cbits) << cshift);
+                                                    v = (int32_t)((uint32_t)rd.read_signed(cbits) << cshift);
                                                 if (j & 1)
                                                     ncf[j >> 1] |= (uint32_t)v << 16;
                                                 else
@@ -681,7 +739,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                             for (uint32_t j = 0; j < 8; j++) {
                                                 int32_t v = 0;
                                                 if (j < iir_order)
-                                                    v = (int32_t)((uint32_t)rd.read_signed((int)cbits) << cshift);
+                                                    v = (int32_t)((uint32_t)rd.read_signed(cbits) << cshift);
                                                 ws[(size_t)j * a.total_lanes] = v;
                                             }
                                             if (rd.read(1)) {
@@ -693,7 +751,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                                 for (uint32_t j = 0; j < 8; j++) {
                                                     int32_t v = 0;
                                                     if (j < iir_order)
-                                                        v = (int32_t)((uint32_t)rd.read_signed((int)sbits) << sshift);
+                                                        v = (int32_t)((uint32_t)rd.read_signed(sbits) << sshift);
                                                     ws[(size_t)(8 + j) * a.total_lanes] = v;   // [8] = most recent
                                                 }
                                             } else {
@@ -786,24 +844,28 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         }
         if (!__any(active))
             break;
+        DVDA_STAMP(0);
 
         // ====================================================== row phase
-        // a row needs at most 8 x 33 + 6 bits = 34 bytes: keep 12 dwords resident, and fetch the
-        // next 64-byte chunk now so that it lands while the row is being decoded
-        if (active && rd.ahead < 12)
-            rd.fill_sync();
-        const bool pf = active && rd.ahead <= (RING_DWORDS - 2 * CHUNK_DWORDS);
+        // A row needs at most 8 x 33 + 6 bits = 34 bytes.  Keep 12 dwords resident past `next`
+        // (cold top-up), hash what the parser has passed, and fetch the next 64-byte chunk now
+        // so that it lands in the ring while this row is being decoded.
+        if (active) {
+            rd.ensure(12);
+            rd.crc_catchup(rd.next);
+        }
+        const bool pf = active && (int32_t)(rd.fillpos - rd.next) <= (RING_DWORDS - 2 * CHUNK_DWORDS) &&
+                        (!rd.crc_rem || (int32_t)(rd.fillpos + CHUNK_DWORDS - RING_DWORDS - rd.crc_pos) <= 0);
         uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
-        uint64_t pf_pos = 0;
         if (pf) {
-            pf_pos = rd.next + (int64_t)rd.ahead;
-            const uint64_t c = pf_pos < rd.max_chunk ? pf_pos : rd.max_chunk;
+            const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
             const uint4 *src = rd.gsrc + (c >> 2);
             p0 = src[0];
             p1 = src[1];
             p2 = src[2];
             p3 = src[3];
         }
+        DVDA_STAMP(1);
 
         if (active) {
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
@@ -814,50 +876,65 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         bypass_bits |= rd.read(1) << m;
             }
             int32_t val[NS];
+            uint32_t bad_code = 0;
 #pragma unroll
             for (int k = 0; k < NS; k++) {
-                val[k] = 0;
-                if ((uint32_t)k < nslots) {
-                    const uint32_t pkk = pk[k];
-                    const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
-                                   shift = (pkk >> 11) & 15u;
-                    rd.refill();
-                    uint32_t msb = 0;
-                    if (cb) {
-                        const uint32_t e = huff_decode(cb, rd.peek9());
-                        msb = e & 0xFFu;
-                        if (msb == 0xFFu) {
-                            status |= ST_HUFFMAN;
-                            active = false;
-                        }
-                        rd.take((int)(e >> 8));
-                    }
-                    const uint32_t lsbv = rd.take((int)lb);
-                    const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
-                    // ---- FIR/IIR reconstruction (src/mlp.c:1278-1300)
-                    int64_t acc = (int64_t)lo16(cf[k][0]) * (int64_t)st[k][0];
-                    acc += (int64_t)hi16(cf[k][0]) * (int64_t)st[k][1];
-                    acc += (int64_t)lo16(cf[k][1]) * (int64_t)st[k][2];
-                    acc += (int64_t)hi16(cf[k][1]) * (int64_t)st[k][3];
-                    acc += (int64_t)lo16(cf[k][2]) * (int64_t)st[k][4];
-                    acc += (int64_t)hi16(cf[k][2]) * (int64_t)st[k][5];
-                    acc += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
-                    acc += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
-                    const bool iir_on = (iir_any >> k) & 1u;
-                    if (iir_on)
-                        acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
-                    const int32_t ssum = (int32_t)(acc >> shift);
-                    const int32_t value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
+                // branch-free symbol decode: slots beyond the lane's channel count read 0 bits
+                const bool in = (uint32_t)k < nslots;
+                const uint32_t pkk = in ? pk[k] : 0u;
+                const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
+                               shift = (pkk >> 11) & 15u;
+                const uint32_t cand1 = rd.ld(rd.next), cand2 = rd.ld(rd.next + 1);
+                const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
+                const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
+                const uint32_t e = huff_decode(cb ? cb : 1u, top >> 23);
+                const uint32_t msb = cb ? (e & 0xFFu) : 0u;
+                const uint32_t len = cb ? (e >> 8) : 0u;
+                bad_code |= (msb == 0xFFu) ? 1u : 0u;
+                const uint32_t o2 = rd.ofs + len;
+                const uint32_t top2 = (uint32_t)((win << o2) >> 32);
+                const uint32_t lsbv = (top2 >> 1) >> (31u - lb);          // lb == 0 -> 0
+                const uint32_t o3 = o2 + lb;                              // <= 31 + 9 + 24 = 64
+                const uint32_t adv = o3 >> 5;                             // 0, 1 or 2 dwords consumed
+                const uint32_t nh = adv == 0 ? rd.hi : (adv == 1 ? rd.lo : rd.nx);
+                const uint32_t nl = adv == 0 ? rd.lo : (adv == 1 ? rd.nx : cand1);
+                const uint32_t nn = adv == 0 ? rd.nx : (adv == 1 ? cand1 : cand2);
+                rd.hi = nh;
+                rd.lo = nl;
+                rd.nx = nn;
+                rd.next += adv;
+                rd.ofs = o3 & 31u;
+                const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
+                // ---- FIR/IIR reconstruction (src/mlp.c:1278-1300)
+                int64_t acc0 = (int64_t)lo16(cf[k][0]) * (int64_t)st[k][0];
+                int64_t acc1 = (int64_t)hi16(cf[k][0]) * (int64_t)st[k][1];
+                acc0 += (int64_t)lo16(cf[k][1]) * (int64_t)st[k][2];
+                acc1 += (int64_t)hi16(cf[k][1]) * (int64_t)st[k][3];
+                acc0 += (int64_t)lo16(cf[k][2]) * (int64_t)st[k][4];
+                acc1 += (int64_t)hi16(cf[k][2]) * (int64_t)st[k][5];
+                acc0 += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
+                acc1 += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
+                int64_t acc = acc0 + acc1;
+                const bool iir_on = in && ((iir_any >> k) & 1u);
+                if (iir_on)
+                    acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
+                const int32_t ssum = (int32_t)(acc >> shift);
+                const int32_t value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
+                // history moves only for channels this lane really carries
 #pragma unroll
-                    for (int j = 7; j > 0; j--)
-                        st[k][j] = st[k][j - 1];
-                    st[k][0] = value;
-                    if (iir_on)
-                        iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
-                                 (int32_t)((uint32_t)value - (uint32_t)ssum));
-                    val[k] = value;
-                }
+                for (int j = 7; j > 0; j--)
+                    st[k][j] = in ? st[k][j - 1] : st[k][j];
+                st[k][0] = in ? value : st[k][0];
+                if (iir_on)
+                    iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
+                             (int32_t)((uint32_t)value - (uint32_t)ssum));
+                val[k] = in ? value : 0;
             }
+            if (bad_code) {
+                status |= ST_HUFFMAN;
+                active = false;
+            }
+            DVDA_STAMP(2);
 
             // ---- gather the frame's channels 0..7 for the rematrix
             int32_t ch[MAXCH];
@@ -898,32 +975,33 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 seed = (seed << 16) ^ shifted ^ (shifted << 5);
                 for (uint32_t m = 0; m < matrix_len; m++) {
                     uint32_t mc[5];
+                    uint32_t nz;
                     if (m < 2) {
 #pragma unroll
                         for (int j = 0; j < 5; j++)
                             mc[j] = m == 0 ? mreg[0][j] : mreg[1][j];
+                        nz = m == 0 ? mnoise[0] : mnoise[1];
                     } else {
 #pragma unroll
                         for (int j = 0; j < 5; j++)
                             mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
+                        // the two noise coefficients follow channel max_matrix_channel
+                        int32_t cn0 = 0, cn1 = 0;
+#pragma unroll
+                        for (int c = 1; c < 10; c++) {
+                            const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
+                            cn0 = ((uint32_t)c == max_mat_ch + 1) ? coef : cn0;
+                            cn1 = ((uint32_t)c == max_mat_ch + 2) ? coef : cn1;
+                        }
+                        nz = ((uint32_t)cn0 & 0xFFFFu) | ((uint32_t)cn1 << 16);
                     }
-                    int64_t acc = 0;
+                    int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
 #pragma unroll
                     for (int c = 0; c < MAXCH; c++) {
                         const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
                         if ((uint32_t)c <= max_mat_ch)
                             acc += (int64_t)ch[c] * (int64_t)coef;
                     }
-                    // the two noise coefficients follow channel max_matrix_channel
-                    int32_t cn0 = 0, cn1 = 0;
-#pragma unroll
-                    for (int c = 1; c < 10; c++) {
-                        const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
-                        cn0 = ((uint32_t)c == max_mat_ch + 1) ? coef : cn0;
-                        cn1 = ((uint32_t)c == max_mat_ch + 2) ? coef : cn1;
-                    }
-                    acc += (int64_t)n0 * (int64_t)cn0;
-                    acc += (int64_t)n1 * (int64_t)cn1;
                     const uint32_t oc = nib(outch_pack, m);
                     const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
                                                  ((bypass_bits >> m) & 1u));
@@ -931,16 +1009,17 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     for (int c = 0; c < MAXCH; c++)
                         ch[c] = ((uint32_t)c == oc) ? nv : ch[c];
                 }
-                // ---- output shift (src/mlp.c:515-525) into the 4-frame staging registers
+                // ---- output shift (src/mlp.c:515-525) into the 4-frame staging registers; the
+                //      phase is the same in every lane (rows advance in lockstep)
+                const uint32_t ph = rows_done & (OUT_ROWS - 1);
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
                     int32_t v = ch[c];
                     if ((uint32_t)c <= max_mat_ch)
                         v = (int32_t)((uint32_t)v << nib(oshift_pack, c));
 #pragma unroll
-                    for (int i = 0; i < OUT_ROWS - 1; i++)
-                        ob[c][i] = ob[c][i + 1];
-                    ob[c][OUT_ROWS - 1] = v;
+                    for (int i = 0; i < OUT_ROWS; i++)
+                        ob[c][i] = (ph == (uint32_t)i) ? v : ob[c][i];
                 }
                 // ---- RIFF order (src/mlp.c:527-533): every 4th frame, one 16-byte store per channel
                 if (row >= out_stride) {
@@ -948,14 +1027,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     active = false;
                 } else if (row < row_limit) {
                     rows_written++;
-                    if ((rows_done & (OUT_ROWS - 1)) == OUT_ROWS - 1) {
+                    if (ph == OUT_ROWS - 1) {
 #pragma unroll
                         for (int c = 0; c < 6; c++) {
                             if ((uint32_t)c < nch_out) {
                                 const uint32_t wc = nib(wavepk, c);
                                 int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
                                 if (vec_ok) {
-                                    *reinterpret_cast<int4 *>(dst) = make_int4(ob[c][0], ob[c][1], ob[c][2], ob[c][3]);
+                                    DVDA_STORE_V4(dst, ob[c][0], ob[c][1], ob[c][2], ob[c][3]);
                                 } else {
 #pragma unroll
                                     for (int i = 0; i < OUT_ROWS; i++)
@@ -985,13 +1064,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         status |= ST_EOF;
                         active = false;
                     }
-                    // ---- drain the rest of the substream through the parity/CRC check
-                    while (rd.crc_rem && active)
-                        rd.fetch();
+                    // ---- the rest of the substream goes through the parity/CRC check
+                    if (active)
+                        rd.crc_finish();
+                    rd.crc_rem = 0;
                     if (rd.crc_st >> 16) {
                         status |= (rd.crc_st & (1u << 16)) ? ST_PARITY : ST_CRC;
                         active = false;
                     }
+                    rd.crc_st = 0;
                     in_frame = false;
                     frames_done++;
                 } else if (rd.tell_bits() > ss_end_bit) {
@@ -1000,19 +1081,26 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 }
             }
         }
+        DVDA_STAMP(3);
 
         // ---- the prefetched chunk lands in the ring
         if (pf) {
-            uint4 *dst = reinterpret_cast<uint4 *>(rd.slot(pf_pos));
+            uint4 *dst = reinterpret_cast<uint4 *>(rd.slot(rd.fillpos));
             dst[0] = p0;
             dst[64] = p1;
             dst[128] = p2;
             dst[192] = p3;
-            if (rd.next + (int64_t)rd.ahead == pf_pos)
-                rd.filled();
+            rd.filled();
         }
+        DVDA_STAMP(4);
     }
 
+#if defined(DVDA_EXP_STAMP)
+    DVDA_STAMP(4);
+    if (lane == 0 && a.dbg)
+        for (int i = 0; i < 6; i++)
+            atomicAdd(&a.dbg[i], stamp_acc[i]);
+#endif
     if (segi < n_seg) {
         if (status)
             atomicOr(&a.seg_status[segi], status);

@@ -49,6 +49,7 @@ struct dvda_mlp_hip_ctx {
     uint32_t *d_n_cand;        // single counter (points at d_tile_base[tiles])
     int32_t *d_iir;
     uint32_t *d_mat;
+    unsigned long long *d_dbg;
     uint32_t iir_lanes;
     // call state
     const uint8_t *d_bytes;
@@ -78,6 +79,7 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_streams);
     (void)hipFree(c->d_iir);
     (void)hipFree(c->d_mat);
+    (void)hipFree(c->d_dbg);
     for (hipEvent_t e : c->ev)
         (void)hipEventDestroy(e);
 }
@@ -122,6 +124,9 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->iir_lanes = (uint32_t)(((2 * ns + DEC_THREADS - 1) / DEC_THREADS) * DEC_THREADS);
     alloc((void **)&c->d_iir, (size_t)c->iir_lanes * MAXCH * 16 * sizeof(int32_t));
     alloc((void **)&c->d_mat, (size_t)c->iir_lanes * MAXMAT * 5 * sizeof(uint32_t));
+    alloc((void **)&c->d_dbg, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemset(c->d_dbg, 0, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         fprintf(stderr, "dvda_mlp_hip: workspace allocation failed: %s\n", hipGetErrorString(e));
         free_ws(c);
@@ -257,6 +262,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.iir_ws = c->d_iir;
     a.mat_ws = c->d_mat;
     a.total_lanes = c->iir_lanes;
+    a.dbg = c->d_dbg;
     // two lanes per segment unless the caller knows every stream has one substream
     const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
     const uint64_t lanes = (uint64_t)c->max_segments * lanes_per_seg;
@@ -352,5 +358,17 @@ extern "C" int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *c, double *avg_ms, uin
     *avg_ms = n ? total / n : 0.0;
     if (launches)
         *launches = n;
+    return DVDA_HIP_OK;
+}
+
+// diagnostic builds (DVDA_EXP_STAMP): reads and clears the per-phase cycle sums
+extern "C" int dvda_mlp_hip_debug_counters(dvda_mlp_hip_ctx *c, unsigned long long *out16)
+{
+    if (!c || !out16)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, c->d_dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->d_dbg, 0, 16 * sizeof(unsigned long long)));
     return DVDA_HIP_OK;
 }

@@ -49,7 +49,8 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        so = _build.build_hip()
+        import os
+        so = os.environ.get("DVDA_MLP_HIP_LIB") or _build.build_hip()   # override: diagnostic A/B builds
         L = ctypes.CDLL(so)
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
         L.dvda_mlp_hip_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32, u32]

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Diagnostic: runs one bench-sized decode with the DVDA_EXP_STAMP build and prints where a
+wave's loop iteration spends its cycles (shares, not absolute times)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["DVDA_MLP_HIP_LIB"] = os.path.join(ROOT, "libdvd-audio_amd", "exp_stamp.so")
+import numpy as np, torch
+import libdvd_audio_amd as pkg
+syn, hip = pkg.synth, pkg.hipdec
+cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512)
+flat, offs, sizes, frames = syn.batch(cfg, 1, 512)
+dev = torch.device("cuda", 0)
+d_bytes = torch.from_numpy(flat).to(dev)
+n = 512
+d_off = torch.from_numpy(offs.astype(np.int64)).to(dev); d_len = torch.from_numpy(sizes.astype(np.int64)).to(dev)
+out_off = np.zeros(n, np.int64); out_off[1:] = np.cumsum(frames[:-1].astype(np.int64) * 6)
+d_oo = torch.from_numpy(out_off).to(dev); d_st = torch.from_numpy(frames.astype(np.int64)).to(dev)
+d_pcm = torch.empty(int(frames.sum()) * 6, dtype=torch.int32, device=dev)
+ctx = hip.Context(0, n, n * 64, lanes_per_segment=1)
+for it in range(2):
+    ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), n, 0)
+    ctx.decode(d_pcm.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), 0)
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 16)()
+    hip.lib().dvda_mlp_hip_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    hip.lib().dvda_mlp_hip_debug_counters(ctx._h, out)
+v = np.array(list(out)[:6], dtype=np.float64)
+names = ["header phase", "prefetch issue / sync fill", "parse+filter (row)", "rematrix+store", "ring commit", "loop top"]
+for nme, x in zip(names, v):
+    print("%-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / v.sum(), x))
+print(ctx.kernel_time())
