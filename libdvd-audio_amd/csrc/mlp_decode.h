@@ -43,8 +43,8 @@ constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
-constexpr int RING_PLANES = 16;                 // 16 planes x 16 B = 256 B per lane
-constexpr int RING_DWORDS = RING_PLANES * 4;    // 64 dwords
+constexpr int RING_PLANES = 8;                  // 8 planes x 16 B = 128 B per lane
+constexpr int RING_DWORDS = RING_PLANES * 4;    // 32 dwords
 constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
 constexpr int OUT_ROWS = 4;                     // PCM frames per 16-byte store
 
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             rd.ensure(12);
             rd.crc_catchup(rd.next);
         }
-        const bool pf = active && (int32_t)(rd.fillpos - rd.next) <= (RING_DWORDS - 2 * CHUNK_DWORDS) &&
+        const bool pf = active && (int32_t)(rd.fillpos - rd.next) <= (RING_DWORDS - CHUNK_DWORDS) &&
                         (!rd.crc_rem || (int32_t)(rd.fillpos + CHUNK_DWORDS - RING_DWORDS - rd.crc_pos) <= 0);
         uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
         if (pf) {
