@@ -72,8 +72,13 @@ constexpr int OUT_ROWS = 4;                     // PCM frames per 16-byte store
 constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_RESTART = 1u << 5,
                    ST_PARAMS = 1u << 6, ST_HUFFMAN = 1u << 7, ST_FILTER = 1u << 8,
                    ST_ENVELOPE = 1u << 9, ST_IRREGULAR = 1u << 16, ST_TIMING = 1u << 17,
-                   ST_MIDFRAME = 1u << 18, ST_CHAINED = 1u << 19, ST_OVERFLOW = 1u << 20;
+                   ST_MIDFRAME = 1u << 18, ST_CHAINED = 1u << 19, ST_OVERFLOW = 1u << 20,
+                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23;
 constexpr uint32_t ST_FATAL_INDEX = (1u << 0) | (1u << 1) | ST_EOF | ST_IRREGULAR;
+// conditions the fast pass only reports; the general pass (k_decode<.., GENERAL = true>) decodes them
+constexpr uint32_t ST_DEFERRED = ST_CHAINED | ST_MIDFRAME | ST_TIMING;
+constexpr int FB_ROWS = 1024;                   // PCM frames one access unit may hold in the general pass
+constexpr int FB_WORDS = FB_ROWS * (MAXCH + 1); // 8 channels + bypassed-LSB bits per frame
 
 struct DecodeArgs {
     const uint8_t *bytes;
@@ -92,6 +97,10 @@ struct DecodeArgs {
     uint32_t *mat_ws;              // cold: [(m*5 + j) * total_lanes + lane], packed int16 pairs
     uint32_t total_lanes;
     unsigned long long *dbg;       // diagnostic builds only (DVDA_EXP_STAMP): per-phase cycle sums
+    int32_t *fir_ws;               // FIR history at each segment's end: [(slot*8 + j) * total_lanes + lane]
+    int32_t *fb;                   // general pass: frame buffers [fb_slots][FB_ROWS][9]
+    uint32_t *fb_counter;
+    uint32_t fb_slots;
 };
 
 __device__ const CrcTable d_crc = make_crc();
@@ -340,7 +349,16 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 }
 
 // ----------------------------------------------------------------------------
-template <int NS, bool PAIRED>
+// GENERAL = false: the fast pass.  One lane per (segment, substream); conditions it cannot
+//   decode exactly are reported per segment (ST_DEFERRED) and the lane stops or goes on as noted.
+// GENERAL = true: the general pass, launched after it on the same grid.  A lane acts only when
+//   its segment heads a run of deferred segments: it resumes from the FIR history the fast pass
+//   saved for the previous segment (src/mlp.c never clears it), walks on through every following
+//   segment that depends on it, buffers each access unit's filtered frames and rematrixes them at
+//   the unit's end with the parameters its last block left (src/mlp.c:504-525), and -- for a
+//   stream whose access units do not have the standard length -- decodes the whole stream in
+//   order with a running output position.
+template <int NS, bool PAIRED, bool GENERAL>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
@@ -358,9 +376,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
-    const uint32_t segi = gl / L;
+    uint32_t segi = gl / L;
     const uint32_t sub = gl - segi * L;     // substream handled by this lane
     bool active = segi < n_seg;
+    uint32_t seg_lane = gl;                 // lane index that owns segment `segi` in the workspaces
 
     SegRec sr;
     sr.off = sr.end = 0;
@@ -368,11 +387,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     sr.nframes = 0;
     sr.flags = 0;
     sr.sync = 0;
-    uint32_t fbase = 0, stream_sync = 0;
+    uint32_t fbase = 0, stream_sync = 0, stream_first = 0, stream_status = 0;
     if (active) {
         sr = a.seg[segi];
-        const uint32_t stream_first = a.streams[sr.stream].first_seg;
+        stream_first = a.streams[sr.stream].first_seg;
         stream_sync = a.streams[sr.stream].sync;
+        stream_status = a.streams[sr.stream].status;
         fbase = a.seg_fbase[segi] - a.seg_fbase[stream_first];
     }
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
@@ -400,8 +420,54 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         out_base = a.out_off[sr.stream];
         out_stride = a.out_stride[sr.stream];
     }
-    const uint64_t row0 = (uint64_t)fbase * rpa;     // first PCM frame of this segment in its stream
-    const uint64_t row_limit = row0 + (uint64_t)sr.nframes * rpa;
+    uint64_t row0 = (uint64_t)fbase * rpa;           // first PCM frame of this segment in its stream
+    uint64_t row_limit = row0 + (uint64_t)sr.nframes * rpa;
+    // general pass: does this lane head a run, and does the whole stream go in order?
+    const bool seq = GENERAL && (stream_status & ST_TIMING);
+    bool resume_fir = false, general_head = false;
+    int32_t *fbuf = nullptr;
+    if (GENERAL && active) {
+        const uint32_t st_j = a.seg_status[segi];
+        bool head;
+        if (seq) {
+            head = segi == stream_first;
+        } else {
+            // segments the general pass has already decoded carry ST_GENERAL
+            const bool flagged = (st_j & (ST_CHAINED | ST_MIDFRAME)) != 0 && !(st_j & ST_GENERAL);
+            const uint32_t st_p = segi > stream_first ? a.seg_status[segi - 1] : 0u;
+            const bool prev_flagged = (st_p & (ST_CHAINED | ST_MIDFRAME)) != 0 && !(st_p & ST_GENERAL);
+            head = flagged && !((st_j & ST_CHAINED) && prev_flagged);
+            resume_fir = head && (st_j & ST_CHAINED);
+        }
+        if (head && (st_j & ST_CHAINED) && segi == stream_first) {
+            status |= ST_ENVELOPE;          // FIR taps on a fresh decoder: the reference reads out of bounds
+            head = false;
+        }
+        if (st_j & ~(ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | (1u << 21)))
+            head = false;                   // a real error was already reported for this segment
+        if (head && is_last_sub) {
+            const uint32_t slot = atomicAdd(a.fb_counter, 1u);
+            if (slot >= a.fb_slots)
+                status |= ST_CAPACITY;
+            else
+                fbuf = a.fb + (size_t)slot * FB_WORDS;
+        }
+        if (PAIRED) {
+            // both lanes of a pair must agree on the capacity verdict
+            const uint32_t other = __shfl_xor(status & ST_CAPACITY, 1);
+            status |= other;
+        }
+        if (!head || (status & ST_CAPACITY))
+            active = false;
+        general_head = active;
+        if (active) {
+            atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | (1u << 21));
+            if (seq) {
+                row0 = 0;
+                row_limit = ~0ull;
+            }
+        }
+    }
     const bool vec_ok = (((out_base | out_stride) & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0);   // 16-byte aligned rows
 
@@ -444,6 +510,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
         for (int j = 0; j < 5; j++)
             mreg[m][j] = 0;
+    if (GENERAL && resume_fir) {
+        // history left by the previous segment's lane in the fast pass
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                st[k][j] = a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + (gl - L)];
+    }
     uint32_t flags = 0xFF;
     uint32_t block_size = 8;
     uint32_t min_ch = 0, max_ch = 0, max_mat_ch = 0, noise_shift = 0, seed = 0;
@@ -470,6 +544,56 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         for (int i = 0; i < OUT_ROWS; i++)
             ob[c][i] = 0;
 
+
+    // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
+    //      ch[0..7] in MLP channel order, shifted in place
+    auto rematrix = [&](int32_t(&ch)[MAXCH], uint32_t bypass_bits) {
+        const uint32_t shifted = (seed >> 7) & 0xFFFFu;
+        const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
+        const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
+        seed = (seed << 16) ^ shifted ^ (shifted << 5);
+        for (uint32_t m = 0; m < matrix_len; m++) {
+            uint32_t mc[5];
+            uint32_t nz;
+            if (m < 2) {
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+                    mc[j] = m == 0 ? mreg[0][j] : mreg[1][j];
+                nz = m == 0 ? mnoise[0] : mnoise[1];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+                    mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
+                // the two noise coefficients follow channel max_matrix_channel
+                int32_t cn0 = 0, cn1 = 0;
+#pragma unroll
+                for (int c = 1; c < 10; c++) {
+                    const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
+                    cn0 = ((uint32_t)c == max_mat_ch + 1) ? coef : cn0;
+                    cn1 = ((uint32_t)c == max_mat_ch + 2) ? coef : cn1;
+                }
+                nz = ((uint32_t)cn0 & 0xFFFFu) | ((uint32_t)cn1 << 16);
+            }
+            int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
+#pragma unroll
+            for (int c = 0; c < MAXCH; c++) {
+                const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
+                if ((uint32_t)c <= max_mat_ch)
+                    acc += (int64_t)ch[c] * (int64_t)coef;
+            }
+            const uint32_t oc = nib(outch_pack, m);
+            const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
+                                         ((bypass_bits >> m) & 1u));
+#pragma unroll
+            for (int c = 0; c < MAXCH; c++)
+                ch[c] = ((uint32_t)c == oc) ? nv : ch[c];
+        }
+#pragma unroll
+        for (int c = 0; c < MAXCH; c++)
+            if ((uint32_t)c <= max_mat_ch)
+                ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
+    };
+
 #if defined(DVDA_EXP_STAMP)
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = clock64();
@@ -480,8 +604,48 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         if (active && rows_left == 0) {
             if (!in_frame) {
                 if (frames_done == sr.nframes) {
-                    active = false;
-                } else {
+                    // ---- segment finished: publish it; the general pass walks on while the next
+                    //      segment of the stream depends on this one (or the stream goes in order)
+                    if (a.fir_ws) {
+#pragma unroll
+                        for (int k = 0; k < NS; k++)
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + seg_lane] = st[k][j];
+                    }
+                    bool go_on = false;
+                    if (GENERAL) {
+                        atomicOr(&a.seg_status[segi], status | ((status & ~(ST_DEFERRED | ST_OVERFLOW)) ? 0u : ST_GENERAL));
+                        if (is_last_sub)
+                            a.seg_rows[segi] = rows_written;
+                        const uint32_t nxt = segi + 1;
+                        if (!(status & ~(ST_DEFERRED | ST_OVERFLOW)) && nxt < n_seg) {
+                            const SegRec nr = a.seg[nxt];
+                            const uint32_t nst = a.seg_status[nxt];
+                            if (nr.stream == sr.stream && !(nr.flags & ST_FATAL_INDEX) && nr.nframes &&
+                                !(nst & ~(ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | (1u << 21))) &&
+                                (seq || (nst & ST_CHAINED))) {
+                                go_on = true;
+                                atomicAnd(&a.seg_status[nxt], ST_DEFERRED | ST_FATAL_INDEX | (1u << 21));
+                                segi = nxt;
+                                seg_lane += L;
+                                sr = nr;
+                                if (!seq) {
+                                    row0 = (uint64_t)(a.seg_fbase[nxt] - a.seg_fbase[stream_first]) * rpa;
+                                    row_limit = row0 + (uint64_t)nr.nframes * rpa;
+                                    row = row0;
+                                }
+                                cur = nr.off;
+                                frames_done = 0;
+                                rows_written = 0;
+                            }
+                        }
+                        status = 0;
+                    }
+                    if (!go_on)
+                        active = false;
+                }
+                if (active && frames_done != sr.nframes) {
                     // ---- frame header "4p 12u 16p" (src/mlp.c:392-394)
                     rd.crc_rem = 0;
                     rd.seek_byte(cur);
@@ -836,6 +1000,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 if (!ok) {
                     status |= err;
                     active = false;
+                } else if (!GENERAL && (status & ST_CHAINED)) {
+                    active = false;            // left to the general pass (needs the previous history)
                 } else {
                     rows_left = block_size;
                     blocks_in_frame++;
@@ -968,77 +1134,49 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             }
 
             if (is_last_sub) {
-                // ---- noise + rematrix (src/mlp.c:1327-1355), per row
-                const uint32_t shifted = (seed >> 7) & 0xFFFFu;
-                const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
-                const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
-                seed = (seed << 16) ^ shifted ^ (shifted << 5);
-                for (uint32_t m = 0; m < matrix_len; m++) {
-                    uint32_t mc[5];
-                    uint32_t nz;
-                    if (m < 2) {
-#pragma unroll
-                        for (int j = 0; j < 5; j++)
-                            mc[j] = m == 0 ? mreg[0][j] : mreg[1][j];
-                        nz = m == 0 ? mnoise[0] : mnoise[1];
+                if (GENERAL) {
+                    // ---- general pass: park the filtered frame; it is rematrixed at the end of
+                    //      the access unit with the parameters its last block leaves
+                    if (frame_rows >= (uint32_t)FB_ROWS) {
+                        status |= ST_ENVELOPE;
+                        active = false;
                     } else {
+                        int32_t *fr = fbuf + (size_t)frame_rows * (MAXCH + 1);
 #pragma unroll
-                        for (int j = 0; j < 5; j++)
-                            mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
-                        // the two noise coefficients follow channel max_matrix_channel
-                        int32_t cn0 = 0, cn1 = 0;
-#pragma unroll
-                        for (int c = 1; c < 10; c++) {
-                            const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
-                            cn0 = ((uint32_t)c == max_mat_ch + 1) ? coef : cn0;
-                            cn1 = ((uint32_t)c == max_mat_ch + 2) ? coef : cn1;
-                        }
-                        nz = ((uint32_t)cn0 & 0xFFFFu) | ((uint32_t)cn1 << 16);
+                        for (int c = 0; c < MAXCH; c++)
+                            fr[c] = ch[c];
+                        fr[MAXCH] = (int32_t)bypass_bits;
                     }
-                    int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
+                } else {
+                    rematrix(ch, bypass_bits);
+                    // ---- into the 4-frame staging registers; the phase is the same in every lane
+                    //      (rows advance in lockstep)
+                    const uint32_t ph = rows_done & (OUT_ROWS - 1);
 #pragma unroll
-                    for (int c = 0; c < MAXCH; c++) {
-                        const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
-                        if ((uint32_t)c <= max_mat_ch)
-                            acc += (int64_t)ch[c] * (int64_t)coef;
+                    for (int c = 0; c < 6; c++) {
+#pragma unroll
+                        for (int i = 0; i < OUT_ROWS; i++)
+                            ob[c][i] = (ph == (uint32_t)i) ? ch[c] : ob[c][i];
                     }
-                    const uint32_t oc = nib(outch_pack, m);
-                    const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
-                                                 ((bypass_bits >> m) & 1u));
+                    // ---- RIFF order (src/mlp.c:527-533): every 4th frame, one 16-byte store per channel
+                    if (row >= out_stride) {
+                        status |= ST_OVERFLOW;
+                        active = false;
+                    } else if (row < row_limit) {
+                        rows_written++;
+                        if (ph == OUT_ROWS - 1) {
 #pragma unroll
-                    for (int c = 0; c < MAXCH; c++)
-                        ch[c] = ((uint32_t)c == oc) ? nv : ch[c];
-                }
-                // ---- output shift (src/mlp.c:515-525) into the 4-frame staging registers; the
-                //      phase is the same in every lane (rows advance in lockstep)
-                const uint32_t ph = rows_done & (OUT_ROWS - 1);
+                            for (int c = 0; c < 6; c++) {
+                                if ((uint32_t)c < nch_out) {
+                                    const uint32_t wc = nib(wavepk, c);
+                                    int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
+                                    if (vec_ok) {
+                                        DVDA_STORE_V4(dst, ob[c][0], ob[c][1], ob[c][2], ob[c][3]);
+                                    } else {
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    int32_t v = ch[c];
-                    if ((uint32_t)c <= max_mat_ch)
-                        v = (int32_t)((uint32_t)v << nib(oshift_pack, c));
-#pragma unroll
-                    for (int i = 0; i < OUT_ROWS; i++)
-                        ob[c][i] = (ph == (uint32_t)i) ? v : ob[c][i];
-                }
-                // ---- RIFF order (src/mlp.c:527-533): every 4th frame, one 16-byte store per channel
-                if (row >= out_stride) {
-                    status |= ST_OVERFLOW;
-                    active = false;
-                } else if (row < row_limit) {
-                    rows_written++;
-                    if (ph == OUT_ROWS - 1) {
-#pragma unroll
-                        for (int c = 0; c < 6; c++) {
-                            if ((uint32_t)c < nch_out) {
-                                const uint32_t wc = nib(wavepk, c);
-                                int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
-                                if (vec_ok) {
-                                    DVDA_STORE_V4(dst, ob[c][0], ob[c][1], ob[c][2], ob[c][3]);
-                                } else {
-#pragma unroll
-                                    for (int i = 0; i < OUT_ROWS; i++)
-                                        dst[i] = ob[c][i];
+                                        for (int i = 0; i < OUT_ROWS; i++)
+                                            dst[i] = ob[c][i];
+                                    }
                                 }
                             }
                         }
@@ -1056,8 +1194,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             if (active && rows_left == 0) {
                 // ---- "last block" bit (src/mlp.c:729); the substream tail is padding
                 if (rd.read(1)) {
-                    if (frame_rows != rpa) {
-                        status |= ST_TIMING;
+                    if (frame_rows != rpa && !seq) {
+                        status |= ST_TIMING;   // the general pass decodes such a stream in order
                         active = false;
                     }
                     if (rd.tell_bits() > ss_end_bit) {
@@ -1073,6 +1211,28 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         active = false;
                     }
                     rd.crc_st = 0;
+                    if (GENERAL && is_last_sub && active) {
+                        // ---- rematrix the whole access unit with the parameters in force now
+                        const uint64_t frow0 = row - frame_rows;
+                        for (uint32_t r = 0; r < frame_rows; r++) {
+                            const int32_t *fr = fbuf + (size_t)r * (MAXCH + 1);
+                            int32_t ch[MAXCH];
+#pragma unroll
+                            for (int c = 0; c < MAXCH; c++)
+                                ch[c] = fr[c];
+                            rematrix(ch, (uint32_t)fr[MAXCH]);
+                            const uint64_t orow = frow0 + r;
+                            if (orow >= out_stride) {
+                                status |= ST_OVERFLOW;      // keep counting: rows = size needed
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 6; c++)
+                                    if ((uint32_t)c < nch_out)
+                                        a.pcm[out_base + (uint64_t)nib(wavepk, c) * out_stride + orow] = ch[c];
+                            }
+                            rows_written++;
+                        }
+                    }
                     in_frame = false;
                     frames_done++;
                 } else if (rd.tell_bits() > ss_end_bit) {
@@ -1104,7 +1264,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     if (segi < n_seg) {
         if (status)
             atomicOr(&a.seg_status[segi], status);
-        if (is_last_sub && sub < S)
+        if ((!GENERAL || general_head) && is_last_sub && sub < S)
             a.seg_rows[segi] = rows_written;
     }
 }

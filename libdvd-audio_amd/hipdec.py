@@ -12,9 +12,11 @@ from . import _build
 
 ST = dict(NO_SYNC=1 << 0, SYNC_CHANGE=1 << 1, PARITY=1 << 2, CRC=1 << 3, EOF=1 << 4, RESTART=1 << 5,
           PARAMS=1 << 6, HUFFMAN=1 << 7, FILTER=1 << 8, ENVELOPE=1 << 9, IRREGULAR=1 << 16,
-          TIMING=1 << 17, MIDFRAME=1 << 18, CHAINED=1 << 19, OVERFLOW=1 << 20, TRUNCATED=1 << 21)
-# bits that do not invalidate the decoded PCM
-ST_BENIGN = ST["TRUNCATED"]
+          TIMING=1 << 17, MIDFRAME=1 << 18, CHAINED=1 << 19, OVERFLOW=1 << 20, TRUNCATED=1 << 21,
+          CAPACITY=1 << 22, GENERAL=1 << 23)
+# bits that do not invalidate the decoded PCM: the three conditions the fast pass defers are
+# informational once the general pass has decoded them (any failure there sets an error bit)
+ST_BENIGN = ST["TRUNCATED"] | ST["CHAINED"] | ST["MIDFRAME"] | ST["TIMING"] | ST["GENERAL"]
 
 
 class StreamInfo(ctypes.Structure):
@@ -176,6 +178,20 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2):
         d_stride = torch.tensor(rows, dtype=torch.int64, device=dev)
         ctx.decode(d_pcm.data_ptr(), d_out_off.data_ptr(), d_stride.data_ptr(), st)
         infos = ctx.stream_info(stream=st)
+        if any(inf.status & ST["OVERFLOW"] for inf in infos):
+            # access units longer than the standard timing: the general pass reported the
+            # size it needs; allocate exactly that and decode again
+            rows = [max(r, int(inf.pcm_frames)) for r, inf in zip(rows, infos)]
+            out_off, pos = [], 0
+            for r, c in zip(rows, nch):
+                out_off.append(pos)
+                pos += r * c
+            d_pcm = torch.zeros(max(pos, 1), dtype=torch.int32, device=dev)
+            d_out_off = torch.tensor(out_off, dtype=torch.int64, device=dev)
+            d_stride = torch.tensor(rows, dtype=torch.int64, device=dev)
+            ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), len(streams), st)
+            ctx.decode(d_pcm.data_ptr(), d_out_off.data_ptr(), d_stride.data_ptr(), st)
+            infos = ctx.stream_info(stream=st)
         host = d_pcm.cpu().numpy()
         pcm = []
         for i, inf in enumerate(infos):
