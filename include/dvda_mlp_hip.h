@@ -70,6 +70,12 @@ extern "C" {
                                             previous segment (informational once chained)        */
 #define DVDA_ST_OVERFLOW     (1u << 20)  /* output capacity (out_stride) too small               */
 #define DVDA_ST_TRUNCATED    (1u << 21)  /* stream ends inside a frame (tail not consumed)       */
+#define DVDA_ST_CAPACITY     (1u << 22)  /* general-pass workspace exhausted (too many deferred runs) */
+#define DVDA_ST_GENERAL      (1u << 23)  /* segment was decoded by the general pass (informational)   */
+/* DVDA_ST_CHAINED, _MIDFRAME and _TIMING are raised by the fast pass and then decoded exactly by
+ * the general pass that follows it; they stay set as information.  Bits that do not invalidate
+ * the PCM: */
+#define DVDA_ST_BENIGN (DVDA_ST_TRUNCATED | DVDA_ST_CHAINED | DVDA_ST_MIDFRAME | DVDA_ST_TIMING | DVDA_ST_GENERAL)
 
 typedef struct dvda_mlp_hip_ctx dvda_mlp_hip_ctx;
 
@@ -123,7 +129,51 @@ int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *ctx, uint32_t *n_segments, void
  * Blocks until those launches have finished. */
 int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *launches);
 
+/* Number of lanes the decode kernels use per segment: 1 when every stream of the batch is known
+ * to carry a single substream (faster), 2 (default) otherwise. */
+int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
+
+/* Per-segment results of the last decode (blocks on `stream`). */
+typedef struct dvda_mlp_segment_info {
+    uint64_t offset, end;     /* byte range of the segment in the input buffer */
+    uint32_t stream, mlp_frames, pcm_frames, status;
+} dvda_mlp_segment_info;
+int dvda_mlp_hip_segment_info(dvda_mlp_hip_ctx *ctx, uint32_t segment, dvda_mlp_segment_info *info,
+                              void *stream);
+
+/* FIR history (reference struct filter_parameters.state, src/mlp.c:73-77, never cleared there)
+ * at the END of `segment`, for both substreams: host_fir[2][48] = [substream][channel slot * 8 + tap],
+ * tap 0 = most recent output.  Blocks on `stream`. */
+int dvda_mlp_hip_segment_fir(dvda_mlp_hip_ctx *ctx, uint32_t segment, int32_t *host_fir, void *stream);
+
+/* FIR history the streams START with (device pointer, [n_streams][2][48], or NULL = fresh
+ * decoders).  Lets a caller decode a stream in pieces cut at major syncs. */
+int dvda_mlp_hip_set_initial_fir(dvda_mlp_hip_ctx *ctx, const int32_t *d_init_fir);
+
 const char *dvda_mlp_hip_version(void);
+
+/* ------------------------------------------------------------------ tier B */
+/* The mlp.h mirror: same three calls, same meaning as reference src/mlp.h:29-42 /
+ * src/mlp.c:265-354, with the reference's containers replaced by plain memory:
+ *   stream_parameters  -> five unsigned codes (src/stream_parameters.h:23-29)
+ *   BitstreamReader*   -> (data, len): the bytes the reference would enqueue (src/mlp.c:349-351)
+ *   aa_int* samples    -> planar[c] points at the PCM frames decoded by THIS call for RIFF
+ *                         channel c (valid until the next call); the binding appends them to
+ *                         samples->_[c]
+ * decode_packet returns the number of PCM frames decoded by the call; 0 = nothing decodable
+ * yet (bytes stay queued) exactly as in the reference.  Where the reference assert()s, the
+ * call returns 0 and dvda_hip_mlpdecoder_status() reports the DVDA_ST_* bits.
+ * Compatibility tier: every call is a small GPU batch; use tier A for throughput. */
+typedef struct dvda_hip_mlpdecoder dvda_hip_mlpdecoder;
+
+dvda_hip_mlpdecoder *dvda_hip_open_mlpdecoder(unsigned group_0_bps, unsigned group_1_bps,
+                                              unsigned group_0_rate, unsigned group_1_rate,
+                                              unsigned channel_assignment, int device);
+void dvda_hip_close_mlpdecoder(dvda_hip_mlpdecoder *decoder);
+unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *decoder, const uint8_t *data,
+                                           size_t len, const int32_t **planar, unsigned *channels);
+unsigned dvda_hip_mlpdecoder_status(const dvda_hip_mlpdecoder *decoder);
+size_t dvda_hip_mlpdecoder_queued_bytes(const dvda_hip_mlpdecoder *decoder);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ HIP_SO = os.path.join(HERE, "libdvda_mlp_hip.so")
 SYNTH_SO = os.path.join(HERE, "synth", "libmlp_synth.so")
 
 HIP_SRCS = [os.path.join(HERE, "csrc", f) for f in
-            ("mlp_hip.hip", "mlp_decode.h", "mlp_index.h", "mlp_tables.h")]
+            ("mlp_hip.hip", "mlp_stream.c", "mlp_decode.h", "mlp_index.h", "mlp_tables.h")]
 HIP_SRCS.append(os.path.join(os.path.dirname(HERE), "include", "dvda_mlp_hip.h"))
 SYNTH_SRCS = [os.path.join(HERE, "synth", f) for f in ("mlp_synth.c", "mlp_synth.h")]
 
@@ -39,11 +39,19 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     target = out or HIP_SO
     if not force and not _stale(target, HIP_SRCS):
         return target
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", target, HIP_SRCS[0]] + ["-D" + d for d in defines]
+    # the kernels + batch tier are HIP C++; the streaming tier (mlp.h mirror) is plain C
+    tag = os.path.basename(target).replace(".so", "")
+    obj_c = os.path.join(HERE, "csrc", "mlp_stream_%s.o" % tag)
+    obj_hip = os.path.join(HERE, "csrc", "mlp_hip_%s.o" % tag)
+    subprocess.run(["gcc", "-O2", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-c", "-o", obj_c, HIP_SRCS[1]], check=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+           "-o", obj_hip, HIP_SRCS[0]] + ["-D" + d for d in defines]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, obj_hip, obj_c],
+                   check=True)
     return target
 
 

@@ -101,6 +101,7 @@ struct DecodeArgs {
     int32_t *fb;                   // general pass: frame buffers [fb_slots][FB_ROWS][9]
     uint32_t *fb_counter;
     uint32_t fb_slots;
+    const int32_t *init_fir;       // optional: FIR history a stream starts with, [stream][2][48] (streaming tier)
 };
 
 __device__ const CrcTable d_crc = make_crc();
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     uint64_t row_limit = row0 + (uint64_t)sr.nframes * rpa;
     // general pass: does this lane head a run, and does the whole stream go in order?
     const bool seq = GENERAL && (stream_status & ST_TIMING);
-    bool resume_fir = false, general_head = false;
+    bool resume_fir = false, general_head = false, resume_from_init = false;
     int32_t *fbuf = nullptr;
     if (GENERAL && active) {
         const uint32_t st_j = a.seg_status[segi];
@@ -439,9 +440,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             head = flagged && !((st_j & ST_CHAINED) && prev_flagged);
             resume_fir = head && (st_j & ST_CHAINED);
         }
+        bool resume_init = false;
         if (head && (st_j & ST_CHAINED) && segi == stream_first) {
-            status |= ST_ENVELOPE;          // FIR taps on a fresh decoder: the reference reads out of bounds
-            head = false;
+            if (a.init_fir) {
+                resume_init = true;         // history carried over from an earlier call
+                resume_fir = false;
+            } else {
+                status |= ST_ENVELOPE;      // FIR taps on a fresh decoder: the reference reads out of bounds
+                head = false;
+            }
         }
         if (st_j & ~(ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | (1u << 21)))
             head = false;                   // a real error was already reported for this segment
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         if (!head || (status & ST_CAPACITY))
             active = false;
         general_head = active;
+        resume_from_init = active && resume_init;
         if (active) {
             atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | (1u << 21));
             if (seq) {
@@ -517,6 +525,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 st[k][j] = a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + (gl - L)];
+    }
+    if (GENERAL && resume_from_init) {
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                st[k][j] = a.init_fir[((size_t)sr.stream * 2 + sub) * 48 + k * 8 + j];
     }
     uint32_t flags = 0xFF;
     uint32_t block_size = 8;
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 if (frames_done == sr.nframes) {
                     // ---- segment finished: publish it; the general pass walks on while the next
                     //      segment of the stream depends on this one (or the stream goes in order)
-                    if (a.fir_ws) {
+                    if (GENERAL && a.fir_ws) {
 #pragma unroll
                         for (int k = 0; k < NS; k++)
 #pragma unroll
@@ -1261,6 +1276,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         for (int i = 0; i < 6; i++)
             atomicAdd(&a.dbg[i], stamp_acc[i]);
 #endif
+    if (!GENERAL && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
+        // FIR history at the segment's end, for a following segment that depends on it
+#pragma unroll
+        for (int k = 0; k < NS; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st[k][j];
+    }
     if (segi < n_seg) {
         if (status)
             atomicOr(&a.seg_status[segi], status);

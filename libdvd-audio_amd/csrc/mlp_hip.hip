@@ -54,6 +54,7 @@ struct dvda_mlp_hip_ctx {
     int32_t *d_fb;
     uint32_t *d_fb_counter;
     uint32_t fb_slots;
+    const int32_t *d_init_fir;
     uint32_t iir_lanes;
     // call state
     const uint8_t *d_bytes;
@@ -114,6 +115,8 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->tiles_cap = 0;
     c->indexed = false;
     c->ev_used = 0;
+    c->d_init_fir = nullptr;
+    c->lanes_per_seg = 2;
     const size_t ns = (size_t)max_segments;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -278,6 +281,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.fb = c->d_fb;
     a.fb_counter = c->d_fb_counter;
     a.fb_slots = c->fb_slots;
+    a.init_fir = c->d_init_fir;
     // two lanes per segment unless the caller knows every stream has one substream
     const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
     const uint64_t lanes = (uint64_t)c->max_segments * lanes_per_seg;
@@ -398,5 +402,59 @@ extern "C" int dvda_mlp_hip_debug_counters(dvda_mlp_hip_ctx *c, unsigned long lo
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out16, c->d_dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(c->d_dbg, 0, 16 * sizeof(unsigned long long)));
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_set_initial_fir(dvda_mlp_hip_ctx *c, const int32_t *d_init_fir)
+{
+    if (!c)
+        return DVDA_HIP_EINVAL;
+    c->d_init_fir = d_init_fir;
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_segment_info(dvda_mlp_hip_ctx *c, uint32_t segment, dvda_mlp_segment_info *info,
+                                         void *stream_)
+{
+    if (!c || !info)
+        return DVDA_HIP_EINVAL;
+    if (!c->indexed)
+        return DVDA_HIP_ESTATE;
+    if (segment >= c->max_segments)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    SegRec r;
+    uint32_t rows = 0, st = 0;
+    HIP_TRY(hipMemcpy(&r, c->d_seg + segment, sizeof(r), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&rows, c->d_seg_rows + segment, sizeof(rows), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&st, c->d_seg_status + segment, sizeof(st), hipMemcpyDeviceToHost));
+    info->offset = r.off;
+    info->end = r.end;
+    info->stream = r.stream;
+    info->mlp_frames = r.nframes;
+    info->pcm_frames = rows;
+    info->status = st | r.flags;
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_segment_fir(dvda_mlp_hip_ctx *c, uint32_t segment, int32_t *host_fir, void *stream_)
+{
+    if (!c || !host_fir)
+        return DVDA_HIP_EINVAL;
+    if (!c->indexed)
+        return DVDA_HIP_ESTATE;
+    const uint32_t L = c->lanes_per_seg ? c->lanes_per_seg : 2;
+    if ((uint64_t)segment * L + L > c->iir_lanes)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    memset(host_fir, 0, 2 * 48 * sizeof(int32_t));
+    for (uint32_t s = 0; s < L; s++) {
+        // element (slot*8 + tap) of lane l lives at fir[(slot*8 + tap) * lanes + l]: a 48-row column
+        HIP_TRY(hipMemcpy2D(host_fir + s * 48, sizeof(int32_t), c->d_fir + (size_t)segment * L + s,
+                            (size_t)c->iir_lanes * sizeof(int32_t), sizeof(int32_t), 48,
+                            hipMemcpyDeviceToHost));
+    }
     return DVDA_HIP_OK;
 }

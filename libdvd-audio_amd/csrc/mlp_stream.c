@@ -1,0 +1,286 @@
+/* mlp_stream.c -- tier B of include/dvda_mlp_hip.h: the mlp.h mirror, host side, plain C.
+ *
+ * Mirrors reference src/mlp.c:265-382 (open / close / decode_packet + the byte queue and the
+ * "decode while a whole frame is queued" loop) on top of the batch tier.  The reference carries
+ * decoder state from packet to packet inside MLPDecoder; here the state that can cross a call
+ * is reduced to what the format really needs by cutting only at major syncs:
+ *
+ *   - the queue keeps every byte from the last major-sync access unit onward, so each call
+ *     re-decodes at most one restart segment it has seen before (parameters, noise seed, IIR
+ *     history are all re-established by that segment's restart header, src/mlp.c:867-990);
+ *   - the FIR history -- the one thing the reference never resets (src/mlp.c:297-304, 1302) --
+ *     is fetched from the device at the end of the previous segment and handed back as the
+ *     stream's initial history on the next call;
+ *   - PCM frames of the retained segment that were already returned are skipped.
+ *
+ * Every call is one small GPU batch: this is the compatibility tier, not the fast path.
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/dvda_mlp_hip.h"
+
+struct dvda_hip_mlpdecoder {
+    int device;
+    unsigned params[5];          /* as given at open (the reference stores and ignores them too) */
+    dvda_mlp_hip_ctx *ctx;
+    uint32_t ctx_segments;
+    /* byte queue: starts at a major-sync access unit once one has been seen */
+    uint8_t *q;
+    size_t qlen, qcap;
+    size_t decoded_end;          /* bytes of q covered by access units already decoded */
+    uint64_t rows_before;        /* PCM frames of q's first segment already handed out */
+    int have_fir;
+    int32_t fir[2 * 48];         /* FIR history at the start of q's first segment */
+    int have_sync;
+    uint8_t sync_params[4];      /* bytes 8,9,11(low 5 bits) and 20(high nibble) of the first sync */
+    unsigned status;
+    /* device / host buffers, grown on demand */
+    uint8_t *d_bytes;
+    size_t d_bytes_cap;
+    uint64_t *d_meta;            /* off, len, out_off, out_stride */
+    int32_t *d_pcm;
+    size_t d_pcm_cap;
+    int32_t *d_fir;
+    int32_t *h_pcm;
+    size_t h_pcm_cap;
+};
+
+static unsigned rows_per_au(unsigned rate_code)
+{
+    switch (rate_code) {
+    case 0: case 8: return 40;
+    case 1: case 9: return 80;
+    case 2: case 10: return 160;
+    default: return 0;
+    }
+}
+
+/* major-sync access unit at q[pos]?  (reference src/mlp.c:621-639) */
+static int sync_at(const uint8_t *q, size_t pos, size_t size)
+{
+    return size >= 32 && q[pos + 4] == 0xF8 && q[pos + 5] == 0x72 && q[pos + 6] == 0x6F &&
+           q[pos + 7] == 0xBB && ((q[pos + 20] >> 4) == 1 || (q[pos + 20] >> 4) == 2);
+}
+
+dvda_hip_mlpdecoder *dvda_hip_open_mlpdecoder(unsigned g0_bps, unsigned g1_bps, unsigned g0_rate,
+                                              unsigned g1_rate, unsigned channel_assignment, int device)
+{
+    dvda_hip_mlpdecoder *d = (dvda_hip_mlpdecoder *)calloc(1, sizeof(*d));
+    if (!d)
+        return NULL;
+    d->device = device;
+    d->params[0] = g0_bps;
+    d->params[1] = g1_bps;
+    d->params[2] = g0_rate;
+    d->params[3] = g1_rate;
+    d->params[4] = channel_assignment;
+    d->ctx_segments = 4096;
+    if (dvda_mlp_hip_create(&d->ctx, device, 1, d->ctx_segments) != DVDA_HIP_OK) {
+        free(d);
+        return NULL;                    /* no GPU: fail loudly, there is no CPU decoder here */
+    }
+    if (hipMalloc((void **)&d->d_meta, 4 * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&d->d_fir, sizeof(d->fir)) != hipSuccess) {
+        dvda_hip_close_mlpdecoder(d);
+        return NULL;
+    }
+    return d;
+}
+
+void dvda_hip_close_mlpdecoder(dvda_hip_mlpdecoder *d)
+{
+    if (!d)
+        return;
+    (void)hipSetDevice(d->device);
+    dvda_mlp_hip_destroy(d->ctx);
+    (void)hipFree(d->d_bytes);
+    (void)hipFree(d->d_meta);
+    (void)hipFree(d->d_pcm);
+    (void)hipFree(d->d_fir);
+    free(d->h_pcm);
+    free(d->q);
+    free(d);
+}
+
+unsigned dvda_hip_mlpdecoder_status(const dvda_hip_mlpdecoder *d) { return d ? d->status : ~0u; }
+size_t dvda_hip_mlpdecoder_queued_bytes(const dvda_hip_mlpdecoder *d) { return d ? d->qlen - d->decoded_end : 0; }
+
+static int grow_dev(void **p, size_t *cap, size_t need)
+{
+    if (need <= *cap)
+        return 1;
+    (void)hipFree(*p);
+    *p = NULL;
+    *cap = 0;
+    need += need / 2 + 4096;
+    if (hipMalloc(p, need) != hipSuccess)
+        return 0;
+    *cap = need;
+    return 1;
+}
+
+unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t *data, size_t len,
+                                           const int32_t **planar, unsigned *channels)
+{
+    size_t pos, complete_end = 0, last_sync = 0;
+    uint32_t n_sync = 0;
+    dvda_mlp_stream_info info;
+    uint64_t meta[4];
+    uint64_t rows_cap, R, fresh;
+    unsigned c, attempt;
+    size_t padded;
+
+    if (channels)
+        *channels = 0;
+    if (!d || (len && !data))
+        return 0;
+    /* ---- enqueue everything (src/mlp.c:349-351) */
+    if (d->qlen + len > d->qcap) {
+        size_t nc = d->qcap ? d->qcap : 8192;
+        uint8_t *nq;
+        while (nc < d->qlen + len)
+            nc *= 2;
+        nq = (uint8_t *)realloc(d->q, nc);
+        if (!nq)
+            return 0;
+        d->q = nq;
+        d->qcap = nc;
+    }
+    if (len)
+        memcpy(d->q + d->qlen, data, len);
+    d->qlen += len;
+
+    /* ---- which access units are complete? (src/mlp.c:384-405) */
+    for (pos = 0; pos + 4 <= d->qlen;) {
+        const size_t size = 2 * ((((size_t)d->q[pos] & 0x0F) << 8) | d->q[pos + 1]);
+        if (size < 4) {
+            d->status |= DVDA_ST_EOF;   /* the reference stalls forever on such a header */
+            break;
+        }
+        if (pos + size > d->qlen)
+            break;
+        if (sync_at(d->q, pos, size)) {
+            const uint8_t p[4] = {d->q[pos + 8], d->q[pos + 9], (uint8_t)(d->q[pos + 11] & 0x1F),
+                                  (uint8_t)(d->q[pos + 20] >> 4)};
+            if (!d->have_sync) {
+                memcpy(d->sync_params, p, 4);
+                d->have_sync = 1;
+            } else if (memcmp(d->sync_params, p, 3) != 0) {
+                d->status |= DVDA_ST_SYNC_CHANGE;   /* reference drops such frames (src/mlp.c:450-455) */
+                return 0;
+            }
+            n_sync++;
+            last_sync = pos;
+        } else if (pos == 0) {
+            d->status |= DVDA_ST_NO_SYNC;           /* substream count unknown: undefined in the reference */
+            return 0;
+        }
+        pos += size;
+        complete_end = pos;
+    }
+    if (complete_end <= d->decoded_end)
+        return 0;                                   /* nothing newly decodable: bytes stay queued */
+
+    /* ---- one small batch on the GPU over q[0, complete_end) */
+    if (hipSetDevice(d->device) != hipSuccess)
+        return 0;
+    if (n_sync + 1 > d->ctx_segments) {
+        dvda_mlp_hip_destroy(d->ctx);
+        d->ctx = NULL;
+        d->ctx_segments = 2 * (n_sync + 1);
+        if (dvda_mlp_hip_create(&d->ctx, d->device, 1, d->ctx_segments) != DVDA_HIP_OK)
+            return 0;
+    }
+    padded = (complete_end + 15) & ~(size_t)15;
+    if (!grow_dev((void **)&d->d_bytes, &d->d_bytes_cap, padded + 64))
+        return 0;
+    if (hipMemset(d->d_bytes + complete_end, 0, padded + 64 - complete_end) != hipSuccess ||
+        hipMemcpy(d->d_bytes, d->q, complete_end, hipMemcpyHostToDevice) != hipSuccess)
+        return 0;
+    meta[0] = 0;
+    meta[1] = complete_end;
+    meta[2] = 0;
+    meta[3] = 0;
+    if (hipMemcpy(d->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
+        return 0;
+    if (dvda_mlp_hip_index(d->ctx, d->d_bytes, padded, d->d_meta, d->d_meta + 1, 1, NULL) ||
+        dvda_mlp_hip_stream_info(d->ctx, &info, 1, NULL))
+        return 0;
+    if (info.status & ~DVDA_ST_BENIGN) {
+        d->status |= info.status;
+        return 0;
+    }
+    rows_cap = info.mlp_frames * rows_per_au(info.group0_rate);
+    if (d->have_fir) {
+        if (hipMemcpy(d->d_fir, d->fir, sizeof(d->fir), hipMemcpyHostToDevice) != hipSuccess)
+            return 0;
+        dvda_mlp_hip_set_initial_fir(d->ctx, d->d_fir);
+    } else {
+        dvda_mlp_hip_set_initial_fir(d->ctx, NULL);
+    }
+    for (attempt = 0; attempt < 2; attempt++) {
+        if (!grow_dev((void **)&d->d_pcm, &d->d_pcm_cap, (size_t)(rows_cap ? rows_cap : 1) * info.channels * 4))
+            return 0;
+        meta[3] = rows_cap;
+        if (hipMemcpy(d->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
+            return 0;
+        if (attempt && dvda_mlp_hip_index(d->ctx, d->d_bytes, padded, d->d_meta, d->d_meta + 1, 1, NULL))
+            return 0;
+        if (dvda_mlp_hip_decode(d->ctx, d->d_pcm, d->d_meta + 2, d->d_meta + 3, NULL) ||
+            dvda_mlp_hip_stream_info(d->ctx, &info, 1, NULL))
+            return 0;
+        if (!(info.status & DVDA_ST_OVERFLOW))
+            break;
+        rows_cap = info.pcm_frames;                 /* non-standard timing: exact size, once more */
+    }
+    if (info.status & ~DVDA_ST_BENIGN) {
+        d->status |= info.status;                   /* the reference would have assert()ed */
+        return 0;
+    }
+    R = info.pcm_frames;
+    if (R < d->rows_before)
+        return 0;
+    fresh = R - d->rows_before;
+
+    /* ---- PCM frames decoded by THIS call, planar, RIFF order (src/mlp.c:527-533) */
+    if ((size_t)R * info.channels * 4 > d->h_pcm_cap) {
+        free(d->h_pcm);
+        d->h_pcm_cap = (size_t)R * info.channels * 4 * 2 + 4096;
+        d->h_pcm = (int32_t *)malloc(d->h_pcm_cap);
+        if (!d->h_pcm) {
+            d->h_pcm_cap = 0;
+            return 0;
+        }
+    }
+    for (c = 0; c < info.channels; c++) {
+        if (fresh && hipMemcpy(d->h_pcm + (size_t)c * fresh, d->d_pcm + (size_t)c * rows_cap + d->rows_before,
+                               (size_t)fresh * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return 0;
+        if (planar)
+            planar[c] = d->h_pcm + (size_t)c * fresh;
+    }
+    if (channels)
+        *channels = info.channels;
+
+    /* ---- keep what the next call needs: bytes from the last major sync on, the FIR history in
+     *      front of that segment, and how many of its frames have been handed out */
+    if (n_sync >= 2) {
+        dvda_mlp_segment_info si;
+        if (dvda_mlp_hip_segment_fir(d->ctx, n_sync - 2, d->fir, NULL) ||
+            dvda_mlp_hip_segment_info(d->ctx, n_sync - 1, &si, NULL))
+            return 0;
+        d->have_fir = 1;
+        d->rows_before = si.pcm_frames;
+        memmove(d->q, d->q + last_sync, d->qlen - last_sync);
+        d->qlen -= last_sync;
+        d->decoded_end = complete_end - last_sync;
+    } else {
+        d->rows_before = R;
+        d->decoded_end = complete_end;
+    }
+    return (unsigned)fresh;
+}

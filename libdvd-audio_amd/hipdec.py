@@ -37,7 +37,10 @@ _lib = None
 
 EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
            "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
-           "dvda_mlp_hip_version")
+           "dvda_mlp_hip_version", "dvda_mlp_hip_set_lanes_per_segment", "dvda_mlp_hip_segment_info",
+           "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
+           "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
+           "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes")
 
 
 def lib():
@@ -65,6 +68,18 @@ def lib():
         L.dvda_mlp_hip_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
         L.dvda_mlp_hip_set_lanes_per_segment.argtypes = [vp, u32]
         L.dvda_mlp_hip_version.restype = ctypes.c_char_p
+        L.dvda_hip_open_mlpdecoder.restype = vp
+        L.dvda_hip_open_mlpdecoder.argtypes = [ctypes.c_uint] * 5 + [ctypes.c_int]
+        L.dvda_hip_close_mlpdecoder.argtypes = [vp]
+        L.dvda_hip_close_mlpdecoder.restype = None
+        L.dvda_hip_mlpdecoder_decode_packet.restype = ctypes.c_uint
+        L.dvda_hip_mlpdecoder_decode_packet.argtypes = [vp, vp, ctypes.c_size_t,
+                                                        ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)),
+                                                        ctypes.POINTER(ctypes.c_uint)]
+        L.dvda_hip_mlpdecoder_status.restype = ctypes.c_uint
+        L.dvda_hip_mlpdecoder_status.argtypes = [vp]
+        L.dvda_hip_mlpdecoder_queued_bytes.restype = ctypes.c_size_t
+        L.dvda_hip_mlpdecoder_queued_bytes.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -201,3 +216,52 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2):
         return pcm, list(infos)
     finally:
         ctx.close()
+
+
+class MLPDecoder:
+    """Host-side mirror of the reference's mlp.h interface (src/mlp.h:29-42):
+
+        dvda_open_mlpdecoder(parameters)         -> MLPDecoder(g0_bps, g1_bps, g0_rate, g1_rate, assignment)
+        dvda_mlpdecoder_decode_packet(d, r, s)   -> d.decode_packet(bytes, samples)
+        dvda_close_mlpdecoder(d)                 -> d.close()
+
+    `samples` plays the role of the reference's aa_int: a list with one growable list/array per
+    RIFF channel; decode_packet appends the PCM frames decoded by that call to every channel
+    and returns their number (0 = nothing decodable yet, the bytes stay queued)."""
+
+    def __init__(self, group_0_bps, group_1_bps, group_0_rate, group_1_rate, channel_assignment, device=0):
+        self._h = lib().dvda_hip_open_mlpdecoder(group_0_bps, group_1_bps, group_0_rate, group_1_rate,
+                                                 channel_assignment, device)
+        if not self._h:
+            raise HipError("dvda_hip_open_mlpdecoder failed (no GPU / HIP error): there is no CPU fallback")
+
+    def decode_packet(self, data, samples):
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8)) if not isinstance(data, np.ndarray) \
+            else np.ascontiguousarray(data, np.uint8)
+        planar = (ctypes.POINTER(ctypes.c_int32) * 6)()
+        nch = ctypes.c_uint()
+        n = lib().dvda_hip_mlpdecoder_decode_packet(self._h, buf.ctypes.data if len(buf) else None, len(buf),
+                                                    planar, ctypes.byref(nch))
+        if n:
+            for c in range(nch.value):
+                samples[c].extend(np.ctypeslib.as_array(planar[c], shape=(n,)).tolist())
+        return int(n)
+
+    @property
+    def status(self):
+        return int(lib().dvda_hip_mlpdecoder_status(self._h))
+
+    @property
+    def queued_bytes(self):
+        return int(lib().dvda_hip_mlpdecoder_queued_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            lib().dvda_hip_close_mlpdecoder(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

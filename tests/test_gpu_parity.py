@@ -97,3 +97,45 @@ def test_fuzz_all_features(pkg, oracle, S):
                            restart_interval=[5, 3, 8, 2][seed % 4])
         cases.append((cfg, 500 + seed))
     _check(pkg, oracle, cases, lanes=2)
+
+
+@pytest.mark.parametrize("chunk", [2013, 777, 5000])
+@pytest.mark.parametrize("feature", ["recipe", "chained", "all"])
+def test_streaming_tier_mirrors_mlp_h(pkg, oracle, feature, chunk):
+    """open / decode_packet / close with PES-payload sized chunks: the PCM and the per-call
+    return values must equal what the oracle's (= the reference's) decode_packet returns."""
+    import ctypes
+    syn, hip = pkg.synth, pkg.hipdec
+    if feature == "recipe":
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=40)
+    elif feature == "chained":
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=40, profile=1,
+                           features=syn.SF["CHAINED"] | syn.SF["FIRRAND"], restart_interval=4)
+    else:
+        cfg = syn.make_cfg(assignment=1, rate_code=0, n_substreams=2, n_aus=40, profile=1,
+                           features=syn.SF_ALL, restart_interval=5)
+    data, frames = syn.stream(cfg, 77)
+    nch = syn.channels(cfg.assignment)
+    # the oracle, packet by packet
+    ol = oracle.lib
+    ol.mlp_oracle_open.restype = ctypes.c_void_p
+    ol.mlp_oracle_decode_packet.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    ol.mlp_oracle_decode_packet.restype = ctypes.c_uint
+    ol.mlp_oracle_close.argtypes = [ctypes.c_void_p]
+    od = ol.mlp_oracle_open(nch)
+    dec = hip.MLPDecoder(cfg.bps_code, cfg.bps_code, cfg.rate_code, cfg.rate_code, cfg.assignment)
+    samples = [[] for _ in range(nch)]
+    try:
+        for off in range(0, len(data), chunk):
+            piece = np.ascontiguousarray(data[off:off + chunk])
+            want_n = ol.mlp_oracle_decode_packet(od, piece.ctypes.data, len(piece))
+            got_n = dec.decode_packet(piece, samples)
+            assert dec.status & ~hip.ST_BENIGN == 0, hex(dec.status)
+            assert got_n == want_n, "packet at %d: %d vs %d" % (off, got_n, want_n)
+    finally:
+        ol.mlp_oracle_close(od)
+        dec.close()
+    want, r, st = oracle.decode(data, nch, frames)
+    assert st == 0
+    got = np.asarray(samples, np.int32)
+    assert got.shape == want.shape and np.array_equal(got, want)
