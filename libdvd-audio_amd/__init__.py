@@ -10,6 +10,6 @@ The directory name carries a hyphen (it mirrors the reference's name); import it
 `import libdvd_audio_amd` (the alias module at the repo root) or with importlib.
 """
 from . import _build  # noqa: F401
-from . import hipdec, synth  # noqa: F401
+from . import hipdec, shard, synth  # noqa: F401
 
-__all__ = ["hipdec", "synth", "_build"]
+__all__ = ["hipdec", "shard", "synth", "_build"]

@@ -1,0 +1,37 @@
+"""Multi-GPU partition of the path: titles (independent MLP streams) are dealt to ranks; the only
+exchange is the batch summary.  One process per GPU, torch.distributed ("nccl" = RCCL over xGMI
+on the GPU node, "gloo" in the CPU tests) -- no data-path collective exists or is needed."""
+import numpy as np
+
+
+def shard_titles(sizes, world, rank):
+    """Greedy longest-processing-time assignment of titles to ranks by compressed size
+    (SURVEY.md 8(e)).  Deterministic: every rank computes the same partition.
+    Returns the sorted indices of the titles owned by `rank`."""
+    sizes = np.asarray(sizes, np.int64)
+    order = np.argsort(-sizes, kind="stable")
+    load = np.zeros(world, np.int64)
+    owner = np.empty(len(sizes), np.int64)
+    for i in order:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += sizes[i]
+    return np.flatnonzero(owner == rank)
+
+
+def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checksum, seconds):
+    """The path's one collective: all ranks learn {sum frames, sum samples, sum bytes, sum errors,
+    xor-free additive checksum} and the slowest rank's time.  `dist` is torch.distributed (already
+    initialised) or None for a single process."""
+    import torch
+    tot = torch.tensor([float(pcm_frames), float(samples), float(comp_bytes), float(errors)],
+                       dtype=torch.float64, device=device)
+    chk = torch.tensor([int(checksum) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+    tmax = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return {"pcm_frames": int(tot[0].item()), "samples": int(tot[1].item()),
+            "compressed_bytes": int(tot[2].item()), "errors": int(tot[3].item()),
+            "checksum": int(chk[0].item()), "seconds": float(tmax[0].item())}
