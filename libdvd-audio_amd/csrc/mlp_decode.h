@@ -43,10 +43,16 @@ constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
-constexpr int RING_PLANES = 8;                  // 8 planes x 16 B = 128 B per lane
-constexpr int RING_DWORDS = RING_PLANES * 4;    // 32 dwords
+#ifndef DVDA_RING_PLANES
+#define DVDA_RING_PLANES 8
+#endif
+constexpr int RING_PLANES = DVDA_RING_PLANES;   // planes x 16 B per lane (8 = 128-byte ring)
+constexpr int RING_DWORDS = RING_PLANES * 4;
 constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
-constexpr int OUT_ROWS = 4;                     // PCM frames per 16-byte store
+#ifndef DVDA_OUT_ROWS
+#define DVDA_OUT_ROWS 4
+#endif
+constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel: 8 = one 32-byte sector per flush
 
 // Diagnostic build switches (tools/ab_bench.sh): never defined in the shipped library.
 //   DVDA_EXP_NOSTORE  keep PCM values alive but do not store them (prices the write path)
@@ -1035,7 +1041,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             rd.ensure(12);
             rd.crc_catchup(rd.next);
         }
-        const bool pf = active && (int32_t)(rd.fillpos - rd.next) <= (RING_DWORDS - CHUNK_DWORDS) &&
+        // both 64-byte halves of a 128-byte line are requested in consecutive rows, while the line
+        // is still in L2 (one HBM fetch per line); a new line is started when half the ring is free
+        const int32_t ahead_now = (int32_t)(rd.fillpos - rd.next);
+#if defined(DVDA_LINE_PREFETCH)
+        const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS) &&
+                        ((rd.fillpos & CHUNK_DWORDS) || ahead_now <= RING_DWORDS / 2) &&
+#else
+        const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS) &&
+#endif
                         (!rd.crc_rem || (int32_t)(rd.fillpos + CHUNK_DWORDS - RING_DWORDS - rd.crc_pos) <= 0);
         uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
         if (pf) {
@@ -1164,8 +1178,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     }
                 } else {
                     rematrix(ch, bypass_bits);
-                    // ---- into the 4-frame staging registers; the phase is the same in every lane
-                    //      (rows advance in lockstep)
+                    // ---- into the staging registers; the phase is the same in every lane (rows advance
+                    //      in lockstep)
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
 #pragma unroll
                     for (int c = 0; c < 6; c++) {
@@ -1173,7 +1187,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         for (int i = 0; i < OUT_ROWS; i++)
                             ob[c][i] = (ph == (uint32_t)i) ? ch[c] : ob[c][i];
                     }
-                    // ---- RIFF order (src/mlp.c:527-533): every 4th frame, one 16-byte store per channel
+                    // ---- RIFF order (src/mlp.c:527-533): every OUT_ROWS-th frame each channel's staged
+                    //      frames leave as 16-byte stores that together cover whole 32-byte sectors
                     if (row >= out_stride) {
                         status |= ST_OVERFLOW;
                         active = false;
@@ -1186,7 +1201,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                     const uint32_t wc = nib(wavepk, c);
                                     int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
                                     if (vec_ok) {
-                                        DVDA_STORE_V4(dst, ob[c][0], ob[c][1], ob[c][2], ob[c][3]);
+#pragma unroll
+                                        for (int i = 0; i < OUT_ROWS; i += 4)
+                                            DVDA_STORE_V4(dst + i, ob[c][i], ob[c][i + 1], ob[c][i + 2], ob[c][i + 3]);
                                     } else {
 #pragma unroll
                                         for (int i = 0; i < OUT_ROWS; i++)
