@@ -175,19 +175,28 @@ def main():
         if not bit_exact:
             raise SystemExit("HIP decode differs from the oracle")
 
-    # ---- whole-job aggregate
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(samples_per_step), float(comp_bytes)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)   # the path's only collective: the batch summary
-    elapsed_max = float(t.item())
-    job_samples = float(tot[0].item())
+    # ---- whole-job aggregate: the path's one collective is this summary (RCCL all-reduce of a
+    #      few words over xGMI; nothing on the data path is exchanged)
+    checksum = int(d_pcm.to(torch.int64).sum().item()) if args.verify else 0
+    summ = pkg.shard.reduce_summary(dist if world > 1 else None, dev, rows_total, samples_per_step,
+                                    comp_bytes, 0, checksum, elapsed)
+    elapsed_max = summ["seconds"]
+    job_samples = float(summ["samples"])
 
     if rank == 0:
         ms_per_step = elapsed_max / args.steps * 1e3
         value = job_samples * args.steps / elapsed_max / 1e6
         algo_bytes = comp_bytes + 4 * samples_per_step      # per launch, this rank
+        # HBM-side bytes of one k_decode launch from the rocprofv3 PMC passes of THIS workload
+        # (tools/prof_pmc.sh -> tools/pmc_traffic.py -> profiles/traffic.json); null when the
+        # committed profile was taken on another workload size
+        traffic_bytes = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("samples_per_launch") == samples_per_step and tj.get("compressed_bytes") == comp_bytes:
+                traffic_bytes = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "decoded PCM Msamples/s (bit-exact) on 6ch/96k/24b MLP",
@@ -216,7 +225,7 @@ def main():
                 "kernel": "k_decode", "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic_bytes,
                 "kernel_ms": round(kernel_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

@@ -63,11 +63,12 @@ extern "C" {
 /* conditions the batch tier reports instead of guessing: */
 #define DVDA_ST_IRREGULAR    (1u << 16)  /* frame chain does not land on the next major sync     */
 #define DVDA_ST_TIMING       (1u << 17)  /* an access unit's PCM-frame count differs from the
-                                            stream's standard 40/80/160: needs the two-pass mode */
+                                            stream's standard 40/80/160: stream decoded in order
+                                            by the general pass                                  */
 #define DVDA_ST_MIDFRAME     (1u << 18)  /* matrix-class parameters changed after a frame's
-                                            first block: frame re-decoded in frame-buffered mode */
-#define DVDA_ST_CHAINED      (1u << 19)  /* segment's first block uses FIR/IIR history of the
-                                            previous segment (informational once chained)        */
+                                            first block: segment re-decoded frame-buffered       */
+#define DVDA_ST_CHAINED      (1u << 19)  /* segment's first block uses the FIR history of the
+                                            previous segment: decoded as part of a run           */
 #define DVDA_ST_OVERFLOW     (1u << 20)  /* output capacity (out_stride) too small               */
 #define DVDA_ST_TRUNCATED    (1u << 21)  /* stream ends inside a frame (tail not consumed)       */
 #define DVDA_ST_CAPACITY     (1u << 22)  /* general-pass workspace exhausted (too many deferred runs) */

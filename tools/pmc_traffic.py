@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""tools/pmc_traffic.py PMC_DIR BENCH_JSON -> profiles/traffic.json
+
+HBM-side bytes of one fast-pass k_decode launch from the separate FETCH_SIZE / WRITE_SIZE passes
+of tools/prof_pmc.sh, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB)
+tallies 128-byte read requests as 64 bytes, so it is doubled; WRITE_SIZE (KiB) is exact.  The
+correction is calibrated in the same run on k_sync_mask, which streams the whole input once
+(its doubled FETCH_SIZE must equal the input size)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+pmc, bench = sys.argv[1], sys.argv[2]
+vals = defaultdict(list)
+for f in glob.glob(os.path.join(pmc, "*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            name = row["Kernel_Name"]
+            key = "decode_fast" if ("k_decode" in name and "false>" in name.split("(")[0].replace(" ", "")[-8:]) else \
+                  "sync_mask" if "k_sync_mask" in name else None
+            if key:
+                vals[(key, row["Counter_Name"])].append(float(row["Counter_Value"]))
+mean = lambda k: sum(vals[k]) / len(vals[k])
+j = None
+for line in open(bench):
+    if line.startswith("{"):
+        j = json.loads(line)
+cfg = j["config"]
+fetch = 2.0 * mean(("decode_fast", "FETCH_SIZE")) * 1024
+write = mean(("decode_fast", "WRITE_SIZE")) * 1024
+calib = 2.0 * mean(("sync_mask", "FETCH_SIZE")) * 1024
+out = {
+    "kernel": "k_decode<6,false,false> (fast pass)",
+    "hbm_bytes_per_launch": int(fetch + write),
+    "fetch_bytes_corrected": int(fetch), "write_bytes": int(write),
+    "calibration": {"k_sync_mask_fetch_corrected": int(calib), "input_bytes": cfg["compressed_bytes_per_gpu"]},
+    "samples_per_launch": cfg["samples_per_step_per_gpu"], "compressed_bytes": cfg["compressed_bytes_per_gpu"],
+    "algorithmic_bytes": j["roofline"]["algorithmic_bytes_per_launch"],
+    "source": os.path.basename(pmc.rstrip("/")),
+}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out))
