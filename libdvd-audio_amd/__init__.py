@@ -11,5 +11,6 @@ The directory name carries a hyphen (it mirrors the reference's name); import it
 """
 from . import _build  # noqa: F401
 from . import hipdec, shard, synth  # noqa: F401
+from . import disc  # noqa: F401
 
 __all__ = ["hipdec", "shard", "synth", "_build"]
