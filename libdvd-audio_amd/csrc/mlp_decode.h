@@ -233,7 +233,7 @@ struct BitReader {
         while (crc_rem && (int32_t)(limit - crc_pos) > 0) {
             const uint32_t v = *slot(crc_pos);
             crc_pos++;
-            if (crc_rem >= 7) {
+            if (__builtin_expect(crc_rem >= 7, 1)) {
                 // slicing-by-4: only the first lookup depends on the running state
                 const uint32_t c = crc_st & 0xFF;
                 const uint32_t n = crc_tab[768 + ((c ^ v) & 0xFF)] ^ crc_tab[512 + ((v >> 8) & 0xFF)] ^
@@ -260,7 +260,7 @@ struct BitReader {
     }
     __device__ __forceinline__ void ensure(uint32_t n)           // n dwords resident at/after next
     {
-        while ((int32_t)(fillpos - next) < (int32_t)n)
+        while (__builtin_expect((int32_t)(fillpos - next) < (int32_t)n, 0))
             fill_sync();
     }
     __device__ __forceinline__ void advance()
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     for (;;) {
         DVDA_STAMP(5);
         // =================================================== header phase
-        if (active && rows_left == 0) {
+        if (__builtin_expect(active && rows_left == 0, 0)) {
             if (!in_frame) {
                 if (frames_done == sr.nframes) {
                     // ---- segment finished: publish it; the general pass walks on while the next
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 acc1 += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
                 int64_t acc = acc0 + acc1;
                 const bool iir_on = in && ((iir_any >> k) & 1u);
-                if (iir_on)
+                if (__builtin_expect(iir_on, 0))
                     acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
                 const int32_t ssum = (int32_t)(acc >> shift);
                 const int32_t value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
@@ -1120,12 +1120,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 for (int j = 7; j > 0; j--)
                     st[k][j] = in ? st[k][j - 1] : st[k][j];
                 st[k][0] = in ? value : st[k][0];
-                if (iir_on)
+                if (__builtin_expect(iir_on, 0))
                     iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
                              (int32_t)((uint32_t)value - (uint32_t)ssum));
                 val[k] = in ? value : 0;
             }
-            if (bad_code) {
+            if (__builtin_expect(bad_code != 0, 0)) {
                 status |= ST_HUFFMAN;
                 active = false;
             }
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             }
             frame_rows++;
             rows_left--;
-            if (active && rows_left == 0) {
+            if (__builtin_expect(active && rows_left == 0, 0)) {
                 // ---- "last block" bit (src/mlp.c:729); the substream tail is padding
                 if (rd.read(1)) {
                     if (frame_rows != rpa && !seq) {
