@@ -337,22 +337,23 @@ struct BitReader {
     }
 };
 
-// Arithmetic decode of the three code books (mlp_tables.h: huff_entry):
-// returns value | length << 8, value 0xFF for the two invalid codes.
+// Arithmetic, branch-free decode of the three code books (mlp_tables.h: huff_entry):
+// returns value | length << 8, value 0xFF for the two invalid codes.  cb in 1..3.
 __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 {
-    if (t & 0x100u) {
-        const uint32_t sub = 3u - cb;                        // extra bits after the leading 1
-        const uint32_t bits = (t >> (8u - sub)) & ((1u << sub) - 1u);
-        return (7u + bits) | ((sub + 1u) << 8);
-    }
+    // "1" + (3 - cb) bits -> 7 + bits, length 4 - cb
+    const uint32_t sub = 3u - cb;
+    const uint32_t bits = (t >> (8u - sub)) & ((1u << sub) - 1u);
+    const uint32_t a = (7u + bits) | ((sub + 1u) << 8);
+    // "0"^z "1" (z = 2..8) -> 8 - z ; "01" "0"^k "1" -> base + k : both are z' = leading zeros of
+    // the low 7 bits, length z' + 3
     const uint32_t r = t & 0x7Fu;
-    const uint32_t z = (uint32_t)__clz((int)r) - 25u;        // leading zeros in 7 bits, 7 if r == 0
-    const uint32_t len = (z > 6u ? 6u : z) + 3u;
+    const uint32_t z = (uint32_t)__clz((int)r) - 25u;        // 7 if r == 0
     const uint32_t base = cb == 1u ? 11u : (cb == 2u ? 9u : 8u);
     uint32_t val = (t & 0x80u) ? base + z : 6u - z;
     val = z > 6u ? 0xFFu : val;
-    return val | (len << 8);
+    const uint32_t b = val | (((z > 6u ? 6u : z) + 3u) << 8);
+    return (t & 0x100u) ? a : b;
 }
 
 // ----------------------------------------------------------------------------
