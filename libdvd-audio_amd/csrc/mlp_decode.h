@@ -372,6 +372,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     __shared__ uint8_t s_crc[4 * 256];
     __shared__ uint4 s_ring[DEC_WAVES][RING_PLANES][64];
+    __shared__ int32_t s_out[GENERAL ? 1 : DEC_WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
     __shared__ int32_t s_xch[PAIRED ? DEC_WAVES : 1][MAXCH][PAIRED ? 64 : 1];
 
     for (int i = threadIdx.x; i < 4 * 256; i += DEC_THREADS)
@@ -559,12 +560,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     uint64_t row = row0;              // next output PCM frame index
     uint32_t rows_written = 0;
     uint32_t rows_done = 0;           // rows decoded by this lane (lockstep across the wave)
-    int32_t ob[6][OUT_ROWS];          // output staging: last 4 PCM frames per output channel
-#pragma unroll
-    for (int c = 0; c < 6; c++)
-#pragma unroll
-        for (int i = 0; i < OUT_ROWS; i++)
-            ob[c][i] = 0;
 
 
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
@@ -1179,15 +1174,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     }
                 } else {
                     rematrix(ch, bypass_bits);
-                    // ---- into the staging registers; the phase is the same in every lane (rows advance
-                    //      in lockstep)
+                    // ---- into the LDS staging tile [channel][frame][lane]; rows advance in lockstep so
+                    //      the frame phase is the same in every lane
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
+                    int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
 #pragma unroll
-                    for (int c = 0; c < 6; c++) {
-#pragma unroll
-                        for (int i = 0; i < OUT_ROWS; i++)
-                            ob[c][i] = (ph == (uint32_t)i) ? ch[c] : ob[c][i];
-                    }
+                    for (int c = 0; c < 6; c++)
+                        T[c][ph][GENERAL ? 0 : lane] = ch[c];
                     // ---- RIFF order (src/mlp.c:527-533): every OUT_ROWS-th frame each channel's staged
                     //      frames leave as 16-byte stores that together cover whole 32-byte sectors
                     if (row >= out_stride) {
@@ -1201,14 +1194,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                 if ((uint32_t)c < nch_out) {
                                     const uint32_t wc = nib(wavepk, c);
                                     int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
+                                    int32_t o[OUT_ROWS];
+#pragma unroll
+                                    for (int i = 0; i < OUT_ROWS; i++)
+                                        o[i] = T[c][i][GENERAL ? 0 : lane];
                                     if (vec_ok) {
 #pragma unroll
                                         for (int i = 0; i < OUT_ROWS; i += 4)
-                                            DVDA_STORE_V4(dst + i, ob[c][i], ob[c][i + 1], ob[c][i + 2], ob[c][i + 3]);
+                                            DVDA_STORE_V4(dst + i, o[i], o[i + 1], o[i + 2], o[i + 3]);
                                     } else {
 #pragma unroll
                                         for (int i = 0; i < OUT_ROWS; i++)
-                                            dst[i] = ob[c][i];
+                                            dst[i] = o[i];
                                     }
                                 }
                             }
