@@ -565,6 +565,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
     //      ch[0..7] in MLP channel order, shifted in place
     auto rematrix = [&](int32_t(&ch)[MAXCH], uint32_t bypass_bits) {
+        const bool wide_matrix = __any(max_mat_ch >= 6);       // wave-uniform
         const uint32_t shifted = (seed >> 7) & 0xFFFFu;
         const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
         const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
@@ -593,10 +594,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             }
             int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
 #pragma unroll
-            for (int c = 0; c < MAXCH; c++) {
+            for (int c = 0; c < 6; c++) {
                 const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
                 if ((uint32_t)c <= max_mat_ch)
                     acc += (int64_t)ch[c] * (int64_t)coef;
+            }
+            if (__builtin_expect(wide_matrix, 0)) {       // channels 6 and 7: never on DVD-Audio layouts
+#pragma unroll
+                for (int c = 6; c < MAXCH; c++) {
+                    const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
+                    if ((uint32_t)c <= max_mat_ch)
+                        acc += (int64_t)ch[c] * (int64_t)coef;
+                }
             }
             const uint32_t oc = nib(outch_pack, m);
             const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
