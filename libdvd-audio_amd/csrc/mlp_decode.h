@@ -108,6 +108,7 @@ struct DecodeArgs {
     uint32_t *fb_counter;
     uint32_t fb_slots;
     const int32_t *init_fir;       // optional: FIR history a stream starts with, [stream][2][48] (streaming tier)
+    uint32_t *deferred;            // set by the fast pass when anything is left to the general pass
 };
 
 __device__ const CrcTable d_crc = make_crc();
@@ -370,6 +371,8 @@ template <int NS, bool PAIRED, bool GENERAL>
 __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
+    if (GENERAL && *a.deferred == 0)
+        return;                                                   // nothing was deferred: whole grid exits
     __shared__ uint8_t s_crc[4 * 256];
     __shared__ uint4 s_ring[DEC_WAVES][RING_PLANES][64];
     __shared__ int32_t s_out[GENERAL ? 1 : DEC_WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
@@ -1308,6 +1311,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             for (int j = 0; j < 8; j++)
                 a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st[k][j];
     }
+    if (!GENERAL && (status & ST_DEFERRED))
+        atomicOr(a.deferred, 1u);
     if (segi < n_seg) {
         if (status)
             atomicOr(&a.seg_status[segi], status);

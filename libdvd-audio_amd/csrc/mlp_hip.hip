@@ -47,6 +47,9 @@ struct dvda_mlp_hip_ctx {
     uint32_t *d_seg_rows;      // [max_segments]
     StreamRec *d_streams;      // [max_streams]
     uint32_t *d_n_cand;        // single counter (points at d_tile_base[tiles])
+    uint32_t *d_scan_tmp;      // block sums of the multi-block scans
+    uint64_t scan_tmp_cap;
+    uint32_t *d_deferred;      // set by the fast pass when any segment is left to the general pass
     int32_t *d_iir;
     uint32_t *d_mat;
     unsigned long long *d_dbg;
@@ -82,6 +85,8 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_seg_status);
     (void)hipFree(c->d_seg_rows);
     (void)hipFree(c->d_streams);
+    (void)hipFree(c->d_scan_tmp);
+    (void)hipFree(c->d_deferred);
     (void)hipFree(c->d_iir);
     (void)hipFree(c->d_mat);
     (void)hipFree(c->d_dbg);
@@ -113,6 +118,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->max_segments = max_segments;
     c->masks_cap = 0;
     c->tiles_cap = 0;
+    c->scan_tmp_cap = 0;
     c->indexed = false;
     c->ev_used = 0;
     c->d_init_fir = nullptr;
@@ -130,6 +136,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_seg_status, ns * sizeof(uint32_t));
     alloc((void **)&c->d_seg_rows, ns * sizeof(uint32_t));
     alloc((void **)&c->d_streams, (size_t)max_streams * sizeof(StreamRec));
+    alloc((void **)&c->d_deferred, sizeof(uint32_t));
     // two lanes per segment at most, rounded up to whole workgroups
     c->iir_lanes = (uint32_t)(((2 * ns + DEC_THREADS - 1) / DEC_THREADS) * DEC_THREADS);
     alloc((void **)&c->d_iir, (size_t)c->iir_lanes * MAXCH * 16 * sizeof(int32_t));
@@ -174,6 +181,17 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
             return DVDA_HIP_ENOMEM;
         c->masks_cap = chunks;
     }
+    {
+        const uint64_t need = ((tiles > c->max_segments ? tiles : c->max_segments) + 1023) / 1024 + 2;
+        if (need > c->scan_tmp_cap) {
+            (void)hipFree(c->d_scan_tmp);
+            c->d_scan_tmp = nullptr;
+            c->scan_tmp_cap = 0;
+            if (hipMalloc((void **)&c->d_scan_tmp, need * sizeof(uint32_t)) != hipSuccess)
+                return DVDA_HIP_ENOMEM;
+            c->scan_tmp_cap = need;
+        }
+    }
     if (tiles > c->tiles_cap) {
         (void)hipFree(c->d_tile_count);
         (void)hipFree(c->d_tile_base);
@@ -185,6 +203,25 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
         c->tiles_cap = tiles;
     }
     return DVDA_HIP_OK;
+}
+
+// exclusive scan of n (host count, or *n_ptr clamped to n_cap) uint32 values; out[n] = total
+static void exscan(dvda_mlp_hip_ctx *c, hipStream_t st, const uint32_t *in, uint32_t *out, uint32_t n_host,
+                   const uint32_t *n_ptr, uint32_t n_cap)
+{
+    const uint32_t n_max = n_ptr ? n_cap : n_host;
+    if (n_max <= 4096) {
+        hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, in, out, n_host, n_ptr, n_cap);
+        return;
+    }
+    const uint32_t blocks = (n_max + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, st, in, out, c->d_scan_tmp, n_host, n_ptr,
+                       n_cap);
+    // bases of the blocks, in place; the total lands at d_scan_tmp[blocks]
+    hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, c->d_scan_tmp, c->d_scan_tmp, blocks,
+                       (const uint32_t *)nullptr, blocks);
+    hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(1024), 0, st, out, c->d_scan_tmp, blocks, n_host, n_ptr,
+                       n_cap);
 }
 
 __global__ void k_init_streams(StreamRec *s, uint32_t n)
@@ -235,15 +272,13 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     HIP_TRY(hipMemsetAsync(c->d_seg_rows, 0, (size_t)ms * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_sync_mask, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, d_bytes,
                        total_bytes, c->d_masks, c->d_tile_count);
-    hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, c->d_tile_count, c->d_tile_base,
-                       (uint32_t)tiles, (const uint32_t *)nullptr, (uint32_t)tiles);
+    exscan(c, st, c->d_tile_count, c->d_tile_base, (uint32_t)tiles, nullptr, (uint32_t)tiles);
     hipLaunchKernelGGL(k_sync_scatter, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, c->d_masks,
                        total_bytes, c->d_tile_base, c->d_cand_off, ms);
     hipLaunchKernelGGL(k_chase, dim3((ms + 255) / 256), dim3(256), 0, st, d_bytes, d_stream_off,
                        d_stream_len, n_streams, c->d_cand_off, c->d_n_cand, ms, c->d_seg,
                        c->d_seg_frames, c->d_streams);
-    hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, c->d_seg_frames, c->d_seg_fbase, 0u,
-                       (const uint32_t *)c->d_n_cand, ms);
+    exscan(c, st, c->d_seg_frames, c->d_seg_fbase, 0u, c->d_n_cand, ms);
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
                        c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams);
     HIP_TRY(hipGetLastError());
@@ -282,6 +317,8 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.fb_counter = c->d_fb_counter;
     a.fb_slots = c->fb_slots;
     a.init_fir = c->d_init_fir;
+    a.deferred = c->d_deferred;
+    HIP_TRY(hipMemsetAsync(c->d_deferred, 0, sizeof(uint32_t), st));
     // two lanes per segment unless the caller knows every stream has one substream
     const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
     const uint64_t lanes = (uint64_t)c->max_segments * lanes_per_seg;
