@@ -153,6 +153,21 @@ int dvda_mlp_hip_set_initial_fir(dvda_mlp_hip_ctx *ctx, const int32_t *d_init_fi
 
 const char *dvda_mlp_hip_version(void);
 
+/* ------------------------------------------------------------------ PCM tier */
+/* Raw-PCM AOB tracks: what reference src/dvd-audio.c:1016-1084 (decode_pcm_audio),
+ * src/packet.c:61-188 (pack header / PES walk) and src/pcm.c:99-193 (AOB byte un-swizzle, sign
+ * extension) do packet by packet, for n_sectors 2048-byte sectors resident in HBM at once.
+ * Output: planar int32, channel c at d_pcm[c * stride + frame] -- the order the reference
+ * appends into `samples`.  Only whole 2-frame chunks of a packet are decoded (src/pcm.c:149).
+ * d_work: device scratch of dvda_pcm_hip_workspace_words(n_sectors) uint32 words. */
+size_t dvda_pcm_hip_workspace_words(uint32_t n_sectors);
+int dvda_pcm_hip_decode_sectors(const uint8_t *d_sectors, uint32_t n_sectors, unsigned bits_per_sample,
+                                unsigned channels, int32_t *d_pcm, uint64_t stride, uint32_t *d_work,
+                                void *stream);
+/* blocks on `stream`; *bad_sectors = sectors whose pack / PES / codec header was malformed */
+int dvda_pcm_hip_result(const uint32_t *d_work, uint32_t n_sectors, uint64_t *pcm_frames,
+                        uint32_t *bad_sectors, void *stream);
+
 /* ------------------------------------------------------------------ tier B */
 /* The mlp.h mirror: same three calls, same meaning as reference src/mlp.h:29-42 /
  * src/mlp.c:265-354, with the reference's containers replaced by plain memory:

@@ -17,6 +17,7 @@
 #include "../../include/dvda_mlp_hip.h"
 #include "mlp_decode.h"
 #include "mlp_index.h"
+#include "pcm_unswizzle.h"
 
 using namespace mlp;
 
@@ -493,5 +494,63 @@ extern "C" int dvda_mlp_hip_segment_fir(dvda_mlp_hip_ctx *c, uint32_t segment, i
                             (size_t)c->iir_lanes * sizeof(int32_t), sizeof(int32_t), 48,
                             hipMemcpyDeviceToHost));
     }
+    return DVDA_HIP_OK;
+}
+
+// ------------------------------------------------------------------ PCM tier
+// workspace (uint32 words): sec_frames[n] | sec_base[n + 1] | block sums[n / 1024 + 2] | n_bad
+extern "C" size_t dvda_pcm_hip_workspace_words(uint32_t n_sectors)
+{
+    return (size_t)n_sectors + (size_t)n_sectors + 1 + ((size_t)n_sectors + 1023) / 1024 + 2 + 1;
+}
+
+extern "C" int dvda_pcm_hip_decode_sectors(const uint8_t *d_sectors, uint32_t n_sectors,
+                                           unsigned bits_per_sample, unsigned channels, int32_t *d_pcm,
+                                           uint64_t stride, uint32_t *d_work, void *stream_)
+{
+    if (!d_sectors || !d_pcm || !d_work || n_sectors == 0 || channels < 1 || channels > 6 ||
+        (bits_per_sample != 16 && bits_per_sample != 24) || ((uintptr_t)d_sectors & 15))
+        return DVDA_HIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    uint32_t *sec_frames = d_work;
+    uint32_t *sec_base = d_work + n_sectors;
+    uint32_t *tmp = sec_base + n_sectors + 1;
+    const uint32_t blocks = (n_sectors + 1023) / 1024;
+    uint32_t *n_bad = tmp + blocks + 2;
+    const uint32_t chunk = (bits_per_sample / 8) * channels * 2;
+    HIP_TRY(hipMemsetAsync(n_bad, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(pcm::k_pcm_scan, dim3((n_sectors + 255) / 256), dim3(256), 0, st, d_sectors, n_sectors,
+                       chunk, sec_frames, n_bad);
+    if (n_sectors <= 4096) {
+        hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, sec_frames, sec_base, n_sectors,
+                           (const uint32_t *)nullptr, n_sectors);
+    } else {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, st, sec_frames, sec_base, tmp, n_sectors,
+                           (const uint32_t *)nullptr, n_sectors);
+        hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, tmp, tmp, blocks, (const uint32_t *)nullptr,
+                           blocks);
+        hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(1024), 0, st, sec_base, tmp, blocks, n_sectors,
+                           (const uint32_t *)nullptr, n_sectors);
+    }
+    hipLaunchKernelGGL(pcm::k_pcm_unswizzle, dim3((n_sectors + 3) / 4), dim3(256), 0, st, d_sectors, n_sectors,
+                       bits_per_sample == 24 ? 1u : 0u, channels, sec_base, d_pcm, stride);
+    HIP_TRY(hipGetLastError());
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_pcm_hip_result(const uint32_t *d_work, uint32_t n_sectors, uint64_t *pcm_frames,
+                                   uint32_t *bad_sectors, void *stream_)
+{
+    if (!d_work || !pcm_frames)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    uint32_t total = 0, bad = 0;
+    const uint32_t blocks = (n_sectors + 1023) / 1024;
+    HIP_TRY(hipMemcpy(&total, d_work + n_sectors + n_sectors, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&bad, d_work + n_sectors + n_sectors + 1 + blocks + 2, sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
+    *pcm_frames = total;
+    if (bad_sectors)
+        *bad_sectors = bad;
     return DVDA_HIP_OK;
 }

@@ -1,0 +1,177 @@
+// pcm_unswizzle.h -- raw-PCM AOB sectors -> planar int32 PCM.
+//
+// What the reference does per packet on the host (src/dvd-audio.c:1016-1084 decode_pcm_audio,
+// src/packet.c:61-188 pack/PES walk, src/pcm.c:99-193 byte un-swizzle + sign extension) as two
+// data-parallel kernels over whole tracks resident in HBM:
+//
+//   k_pcm_scan      one lane per 2048-byte sector: validates the pack header, walks the PES
+//                   packets, counts the PCM frames the sector holds (whole chunks only, as
+//                   src/pcm.c:149 does) and records a malformed sector instead of stopping.
+//   (exclusive scan of the per-sector frame counts = each sector's first output frame)
+//   k_pcm_unswizzle one wavefront per sector: the sector is staged in LDS with 16-byte loads,
+//                   each lane un-swizzles one 2-frame chunk (inverse of AOB_BYTE_SWAP) and stores
+//                   8 bytes per channel, so a wavefront writes contiguous runs per channel.
+//
+// Pure byte shuffling: bound by HBM (reads 2048 B, writes <= 2.6 KB per sector).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pcm {
+
+// inv[k] = position inside the AOB chunk of byte k of the little-endian, frame-major sample block
+// (inverse of AOB_BYTE_SWAP, reference src/pcm.c:103-139)
+struct SwapTables {
+    uint8_t inv[2][6][36];
+};
+
+constexpr SwapTables make_tables()
+{
+    constexpr uint8_t s16[6][24] = {
+        {1, 0, 3, 2},
+        {1, 0, 3, 2, 5, 4, 7, 6},
+        {1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10},
+        {1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10, 13, 12, 15, 14},
+        {1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10, 13, 12, 15, 14, 17, 16, 19, 18},
+        {5, 4, 7, 6, 17, 16, 19, 18, 1, 0, 3, 2, 9, 8, 11, 10, 13, 12, 15, 14, 21, 20, 23, 22}};
+    constexpr uint8_t s24[6][36] = {
+        {2, 1, 5, 4, 0, 3},
+        {2, 1, 5, 4, 8, 7, 11, 10, 0, 3, 6, 9},
+        {8, 7, 17, 16, 6, 15, 2, 1, 5, 4, 11, 10, 14, 13, 0, 3, 9, 12},
+        {8, 7, 11, 10, 20, 19, 23, 22, 6, 9, 18, 21, 2, 1, 5, 4, 14, 13, 17, 16, 0, 3, 12, 15},
+        {8, 7, 11, 10, 14, 13, 23, 22, 26, 25, 29, 28, 6, 9, 12, 21, 24, 27,
+         2, 1, 5, 4, 17, 16, 20, 19, 0, 3, 15, 18},
+        {8, 7, 11, 10, 26, 25, 29, 28, 6, 9, 24, 27, 2, 1, 5, 4, 14, 13, 17, 16, 20, 19, 23, 22,
+         32, 31, 35, 34, 0, 3, 12, 15, 18, 21, 30, 33}};
+    SwapTables t{};
+    for (int ch = 1; ch <= 6; ch++) {
+        for (int i = 0; i < 2 * 2 * ch; i++)
+            t.inv[0][ch - 1][s16[ch - 1][i]] = (uint8_t)i;
+        for (int i = 0; i < 3 * 2 * ch; i++)
+            t.inv[1][ch - 1][s24[ch - 1][i]] = (uint8_t)i;
+    }
+    return t;
+}
+
+__device__ const SwapTables d_tables = make_tables();
+
+constexpr uint32_t SECTOR = 2048;
+constexpr int MAX_PACKETS = 8;           // audio packets per sector the kernels handle (1 in practice)
+
+// Walks the PES packets of one sector.  Calls f(payload_offset, payload_len) for every PCM audio
+// packet (payload = bytes behind the parameter block).  Returns false on a malformed sector.
+template <typename F> __device__ __forceinline__ bool walk_sector(const uint8_t *p, F f)
+{
+    if (p[0] != 0 || p[1] != 0 || p[2] != 1 || p[3] != 0xBA)
+        return false;
+    if ((p[4] >> 6) != 1 || !(p[4] & 4) || !(p[6] & 4) || !(p[8] & 4) || !(p[9] & 1) || (p[12] & 3) != 3)
+        return false;                                  // marker bits, src/packet.c:172-176
+    uint32_t pos = 14 + (p[13] & 7);
+    while (pos + 6 <= SECTOR) {
+        const uint32_t id = p[pos + 3], plen = ((uint32_t)p[pos + 4] << 8) | p[pos + 5];
+        if (p[pos] != 0 || p[pos + 1] != 0 || p[pos + 2] != 1 || pos + 6 + plen > SECTOR)
+            return false;
+        if (id == 0xBD) {                              // AUDIO_STREAM_ID, src/packet.c:119-136
+            const uint8_t *q = p + pos + 6;
+            if (plen < 7)
+                return false;
+            const uint32_t pad1 = q[2];
+            if (plen < 7 + pad1)
+                return false;
+            const uint32_t codec = q[3 + pad1], pad2 = q[6 + pad1];
+            const uint32_t hdr = 7 + pad1 + pad2;      // the 9-byte parameter block sits inside pad_2
+            if (codec != 0xA0 || pad2 < 9 || hdr > plen)
+                return false;
+            f(pos + 6 + hdr, plen - hdr);
+        }
+        pos += 6 + plen;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_pcm_scan(const uint8_t *__restrict__ sectors, uint32_t n_sectors,
+                                                  uint32_t chunk_size, uint32_t *__restrict__ sec_frames,
+                                                  uint32_t *__restrict__ n_bad)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sectors)
+        return;
+    uint32_t frames = 0;
+    const bool ok = walk_sector(sectors + (size_t)s * SECTOR,
+                                [&](uint32_t, uint32_t len) { frames += 2 * (len / chunk_size); });
+    if (!ok) {
+        frames = 0;
+        atomicAdd(n_bad, 1u);
+    }
+    sec_frames[s] = frames;
+}
+
+// one wavefront per sector, 4 sectors per 256-thread block
+__global__ __launch_bounds__(256) void k_pcm_unswizzle(const uint8_t *__restrict__ sectors, uint32_t n_sectors,
+                                                       uint32_t bps_index, uint32_t channels,
+                                                       const uint32_t *__restrict__ sec_base,
+                                                       int32_t *__restrict__ out, uint64_t stride)
+{
+    __shared__ uint4 s_sec[4][SECTOR / 16];
+    __shared__ uint32_t s_pk[4][2 * MAX_PACKETS + 1];
+    __shared__ uint8_t s_inv[36];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * 4 + wv;
+    const uint32_t nb = bps_index ? 3u : 2u;
+    const uint32_t chunk_size = nb * channels * 2;
+    if (threadIdx.x < 36)
+        s_inv[threadIdx.x] = d_tables.inv[bps_index][channels - 1][threadIdx.x];
+    if (s < n_sectors) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sectors + (size_t)s * SECTOR);
+        s_sec[wv][lane] = src[lane];
+        s_sec[wv][lane + 64] = src[lane + 64];
+    }
+    __syncthreads();
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(&s_sec[wv][0]);
+    if (s < n_sectors && lane == 0) {
+        uint32_t n = 0;
+        const bool ok = walk_sector(p, [&](uint32_t off, uint32_t len) {
+            if (n < (uint32_t)MAX_PACKETS) {
+                s_pk[wv][1 + 2 * n] = off;
+                s_pk[wv][2 + 2 * n] = len;
+                n++;
+            }
+        });
+        s_pk[wv][0] = ok ? n : 0;
+    }
+    __syncthreads();
+    if (s >= n_sectors)
+        return;
+    uint64_t frame0 = sec_base[s];
+    const bool vec_ok = ((stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+    for (uint32_t k = 0; k < s_pk[wv][0]; k++) {
+        const uint32_t off = s_pk[wv][1 + 2 * k], len = s_pk[wv][2 + 2 * k];
+        const uint32_t chunks = len / chunk_size;
+        for (uint32_t t = lane; t < chunks; t += 64) {
+            const uint8_t *c = p + off + t * chunk_size;
+            // sample j of the chunk (frame j / channels, channel j % channels), little-endian bytes
+            // j*nb .. j*nb+nb-1 of the un-swizzled block
+            for (uint32_t ch = 0; ch < channels; ch++) {
+                int32_t v[2];
+#pragma unroll
+                for (int fr = 0; fr < 2; fr++) {
+                    const uint32_t j = fr * channels + ch;
+                    uint32_t u = 0;
+                    for (uint32_t b = 0; b < nb; b++)
+                        u |= (uint32_t)c[s_inv[j * nb + b]] << (8 * b);
+                    v[fr] = nb == 2 ? (int32_t)(int16_t)u : ((int32_t)(u << 8) >> 8);   // src/pcm.c:172-193
+                }
+                int32_t *dst = out + (uint64_t)ch * stride + frame0 + 2 * t;
+                if (vec_ok && (((frame0 + 2 * t) & 1) == 0))
+                    *reinterpret_cast<int2 *>(dst) = make_int2(v[0], v[1]);
+                else {
+                    dst[0] = v[0];
+                    dst[1] = v[1];
+                }
+            }
+        }
+        frame0 += 2 * chunks;
+    }
+}
+
+} // namespace pcm

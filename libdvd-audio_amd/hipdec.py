@@ -40,7 +40,8 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_mlp_hip_version", "dvda_mlp_hip_set_lanes_per_segment", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
-           "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes")
+           "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",
+           "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result")
 
 
 def lib():
@@ -80,6 +81,10 @@ def lib():
         L.dvda_hip_mlpdecoder_status.argtypes = [vp]
         L.dvda_hip_mlpdecoder_queued_bytes.restype = ctypes.c_size_t
         L.dvda_hip_mlpdecoder_queued_bytes.argtypes = [vp]
+        L.dvda_pcm_hip_workspace_words.restype = ctypes.c_size_t
+        L.dvda_pcm_hip_workspace_words.argtypes = [u32]
+        L.dvda_pcm_hip_decode_sectors.argtypes = [vp, u32, ctypes.c_uint, ctypes.c_uint, vp, u64, vp, vp]
+        L.dvda_pcm_hip_result.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u32), vp]
         _lib = L
     return _lib
 
@@ -265,3 +270,29 @@ class MLPDecoder:
             self.close()
         except Exception:
             pass
+
+
+def pcm_decode_sectors(sectors, bits_per_sample, channels, device=0):
+    """Raw-PCM AOB sectors (bytes, multiple of 2048) -> (int32 [channels, frames], bad_sectors)
+    through dvda_pcm_hip_decode_sectors.  HIP only."""
+    import torch
+    if not torch.cuda.is_available():
+        raise HipError("no GPU visible to torch: the PCM un-swizzle path is HIP-only")
+    buf = np.ascontiguousarray(np.frombuffer(bytes(sectors), np.uint8)) if not isinstance(sectors, np.ndarray) \
+        else np.ascontiguousarray(sectors, np.uint8)
+    assert len(buf) % 2048 == 0 and len(buf)
+    n = len(buf) // 2048
+    dev = torch.device("cuda", device)
+    d_sec = torch.from_numpy(buf).to(dev)
+    cap = n * (2048 // (2 * channels * (bits_per_sample // 8))) * 2 + 2
+    cap += cap & 1
+    d_pcm = torch.zeros(channels * cap, dtype=torch.int32, device=dev)
+    d_work = torch.zeros(int(lib().dvda_pcm_hip_workspace_words(n)), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _check(lib().dvda_pcm_hip_decode_sectors(d_sec.data_ptr(), n, bits_per_sample, channels, d_pcm.data_ptr(),
+                                             cap, d_work.data_ptr(), st), "dvda_pcm_hip_decode_sectors")
+    frames, bad = ctypes.c_uint64(), ctypes.c_uint32()
+    _check(lib().dvda_pcm_hip_result(d_work.data_ptr(), n, ctypes.byref(frames), ctypes.byref(bad), st),
+           "dvda_pcm_hip_result")
+    out = d_pcm.cpu().numpy().reshape(channels, cap)[:, :frames.value].copy()
+    return out, int(bad.value)

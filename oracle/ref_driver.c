@@ -110,3 +110,33 @@ ref_mlp_decode_lens(const uint8_t *data, size_t len, size_t chunk,
     samples->del(samples);
     return total;
 }
+
+/* ---- PCM: the reference's un-swizzle, src/pcm.c:99-170 */
+#include "pcm.h"
+
+/* Decodes one packet payload (the bytes behind the 9-byte parameter block) with the reference's
+ * PCM decoder.  out is planar [channels][cap].  Returns PCM frames. */
+long
+ref_pcm_decode(const uint8_t *payload, size_t len, unsigned bits_per_sample, unsigned channels,
+               int32_t *out, size_t cap)
+{
+    PCMDecoder *dec = dvda_open_pcmdecoder(bits_per_sample, channels);
+    aa_int *samples = aa_int_new();
+    BitstreamReader *r = br_open_buffer(payload, (unsigned)len, BS_BIG_ENDIAN);
+    unsigned c;
+    long frames;
+    for (c = 0; c < channels; c++)
+        (void)samples->append(samples);
+    frames = dvda_pcmdecoder_decode_packet(dec, r, samples);
+    r->close(r);
+    for (c = 0; c < channels; c++) {
+        if (samples->_[c]->len > cap) {
+            frames = -1;
+            break;
+        }
+        memcpy(out + (size_t)c * cap, samples->_[c]->_, sizeof(int32_t) * samples->_[c]->len);
+    }
+    dvda_close_pcmdecoder(dec);
+    samples->del(samples);
+    return frames;
+}

@@ -1,0 +1,95 @@
+"""PCM un-swizzle: CPU tests pin the oracle to the compiled reference and to
+the sample values that went into the muxer; GPU tests compare the HIP kernels with the oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+
+LAYOUTS = [(16, 1, 0), (16, 2, 1), (16, 3, 2), (16, 4, 3), (16, 5, 6), (16, 6, 12),
+           (24, 1, 0), (24, 2, 1), (24, 3, 2), (24, 4, 3), (24, 5, 6), (24, 6, 12)]
+
+
+def _oracle():
+    lib = ctypes.CDLL(oracle_lib.build_oracle())
+    lib.pcm_oracle_unswizzle.restype = ctypes.c_long
+    lib.pcm_oracle_unswizzle.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint,
+                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+    lib.pcm_oracle_decode_sectors.restype = ctypes.c_long
+    lib.pcm_oracle_decode_sectors.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint,
+                                              ctypes.c_void_p, ctypes.c_size_t]
+    return lib
+
+
+def _samples(bps, ch, frames, seed):
+    rng = np.random.RandomState(seed)
+    lim = 1 << (bps - 1)
+    s = rng.randint(-lim, lim, size=(frames, ch))
+    s[0, :] = -lim
+    s[1, :] = lim - 1
+    return s
+
+
+def _sectors(pkg, bps, ch, asg, frames, seed):
+    s = _samples(bps, ch, frames, seed)
+    sec = pkg.disc.pcm_track_sectors(s, {16: 0, 24: 2}[bps], 1, asg)
+    return np.frombuffer(b"".join(sec), np.uint8).copy(), s
+
+
+@pytest.mark.parametrize("bps,ch,asg", LAYOUTS)
+def test_oracle_sector_walk_recovers_the_muxed_samples(pkg, bps, ch, asg):
+    lib = _oracle()
+    data, s = _sectors(pkg, bps, ch, asg, 1500, 3)
+    out = np.zeros((ch, len(s) + 8), np.int32)
+    r = lib.pcm_oracle_decode_sectors(data.ctypes.data, len(data) // 2048, bps, ch, out.ctypes.data, out.shape[1])
+    assert r == len(s)
+    assert np.array_equal(out[:, :r], s.T)
+
+
+@pytest.mark.skipif(not oracle_lib.Reference.available(), reason="compiled reference not present")
+@pytest.mark.parametrize("bps,ch,asg", LAYOUTS)
+def test_oracle_unswizzle_equals_reference(bps, ch, asg):
+    lib = _oracle()
+    ref = ctypes.CDLL(oracle_lib.REF_SO)
+    ref.ref_pcm_decode.restype = ctypes.c_long
+    ref.ref_pcm_decode.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint,
+                                   ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.RandomState(bps * 10 + ch)
+    for n in (0, 5, 36 * 7 + 11, 1993):
+        payload = rng.randint(0, 256, size=n).astype(np.uint8)
+        a = np.zeros((ch, 2100), np.int32)
+        b = np.zeros((ch, 2100), np.int32)
+        ra = lib.pcm_oracle_unswizzle(payload.ctypes.data, n, bps, ch, a.ctypes.data, 2100, 0)
+        rb = ref.ref_pcm_decode(payload.ctypes.data, n, bps, ch, b.ctypes.data, 2100)
+        assert ra == rb == 2 * (n // (2 * ch * (bps // 8)))
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bps,ch,asg", LAYOUTS)
+def test_gpu_unswizzle_matches_oracle(pkg, bps, ch, asg):
+    lib = _oracle()
+    data, s = _sectors(pkg, bps, ch, asg, 5000 + 2 * ch, 11)
+    want = np.zeros((ch, len(s) + 8), np.int32)
+    r = lib.pcm_oracle_decode_sectors(data.ctypes.data, len(data) // 2048, bps, ch, want.ctypes.data, want.shape[1])
+    got, bad = pkg.hipdec.pcm_decode_sectors(data, bps, ch)
+    assert bad == 0 and got.shape[1] == r == len(s)
+    assert np.array_equal(got, want[:, :r])
+    assert np.array_equal(got, s.T)
+
+
+@pytest.mark.gpu
+def test_gpu_pcm_large_track_and_bad_sector(pkg):
+    lib = _oracle()
+    data, s = _sectors(pkg, 24, 6, 12, 6 * 110 * 4100, 5)       # > 4096 sectors: multi-block scan
+    got, bad = pkg.hipdec.pcm_decode_sectors(data, 24, 6)
+    assert bad == 0 and np.array_equal(got, s.T)
+    broken = data.copy()
+    broken[2048 * 3 + 3] = 0                                     # sector 3 loses its pack start code
+    got, bad = pkg.hipdec.pcm_decode_sectors(broken, 24, 6)
+    assert bad == 1
+    n3 = 110                                                     # frames sector 3 carried
+    assert got.shape[1] == len(s) - n3
+    assert np.array_equal(got[:, :3 * n3], s.T[:, :3 * n3]) and np.array_equal(got[:, 3 * n3:], s.T[:, 4 * n3:])
