@@ -168,6 +168,13 @@ int dvda_pcm_hip_decode_sectors(const uint8_t *d_sectors, uint32_t n_sectors, un
 int dvda_pcm_hip_result(const uint32_t *d_work, uint32_t n_sectors, uint64_t *pcm_frames,
                         uint32_t *bad_sectors, void *stream);
 
+/* MLP track demux: AOB sectors of an MLP track -> the contiguous MLP byte
+ * stream (every 0xBD packet with codec 0xA1, audio header and pad_2 stripped, in order: what
+ * reference src/dvd-audio.c:1151-1227 enqueues packet by packet).  d_work as for the PCM tier;
+ * dvda_pcm_hip_result() then returns the byte count in *pcm_frames and the malformed sectors. */
+int dvda_mlp_hip_demux_sectors(const uint8_t *d_sectors, uint32_t n_sectors, uint8_t *d_mlp,
+                               uint64_t mlp_cap, uint32_t *d_work, void *stream);
+
 /* ------------------------------------------------------------------ tier B */
 /* The mlp.h mirror: same three calls, same meaning as reference src/mlp.h:29-42 /
  * src/mlp.c:265-354, with the reference's containers replaced by plain memory:

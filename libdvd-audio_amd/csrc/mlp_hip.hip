@@ -554,3 +554,35 @@ extern "C" int dvda_pcm_hip_result(const uint32_t *d_work, uint32_t n_sectors, u
         *bad_sectors = bad;
     return DVDA_HIP_OK;
 }
+
+// ------------------------------------------------------------------ MLP track demux
+extern "C" int dvda_mlp_hip_demux_sectors(const uint8_t *d_sectors, uint32_t n_sectors, uint8_t *d_mlp,
+                                          uint64_t mlp_cap, uint32_t *d_work, void *stream_)
+{
+    if (!d_sectors || !d_mlp || !d_work || n_sectors == 0 || ((uintptr_t)d_sectors & 15) || ((uintptr_t)d_mlp & 3))
+        return DVDA_HIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    uint32_t *sec_bytes = d_work;
+    uint32_t *sec_base = d_work + n_sectors;
+    uint32_t *tmp = sec_base + n_sectors + 1;
+    const uint32_t blocks = (n_sectors + 1023) / 1024;
+    uint32_t *n_bad = tmp + blocks + 2;
+    HIP_TRY(hipMemsetAsync(n_bad, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(pcm::k_mlp_sector_scan, dim3((n_sectors + 255) / 256), dim3(256), 0, st, d_sectors,
+                       n_sectors, sec_bytes, n_bad);
+    if (n_sectors <= 4096) {
+        hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, sec_bytes, sec_base, n_sectors,
+                           (const uint32_t *)nullptr, n_sectors);
+    } else {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, st, sec_bytes, sec_base, tmp, n_sectors,
+                           (const uint32_t *)nullptr, n_sectors);
+        hipLaunchKernelGGL(k_exscan_u32, dim3(1), dim3(1024), 0, st, tmp, tmp, blocks, (const uint32_t *)nullptr,
+                           blocks);
+        hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(1024), 0, st, sec_base, tmp, blocks, n_sectors,
+                           (const uint32_t *)nullptr, n_sectors);
+    }
+    hipLaunchKernelGGL(pcm::k_mlp_gather, dim3((n_sectors + 3) / 4), dim3(256), 0, st, d_sectors, n_sectors,
+                       sec_base, d_mlp, mlp_cap);
+    HIP_TRY(hipGetLastError());
+    return DVDA_HIP_OK;
+}

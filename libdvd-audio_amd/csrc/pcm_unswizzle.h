@@ -60,7 +60,7 @@ constexpr int MAX_PACKETS = 8;           // audio packets per sector the kernels
 
 // Walks the PES packets of one sector.  Calls f(payload_offset, payload_len) for every PCM audio
 // packet (payload = bytes behind the parameter block).  Returns false on a malformed sector.
-template <typename F> __device__ __forceinline__ bool walk_sector(const uint8_t *p, F f)
+template <typename F> __device__ __forceinline__ bool walk_sector(const uint8_t *p, F f, uint32_t want_codec = 0xA0)
 {
     if (p[0] != 0 || p[1] != 0 || p[2] != 1 || p[3] != 0xBA)
         return false;
@@ -80,7 +80,8 @@ template <typename F> __device__ __forceinline__ bool walk_sector(const uint8_t 
                 return false;
             const uint32_t codec = q[3 + pad1], pad2 = q[6 + pad1];
             const uint32_t hdr = 7 + pad1 + pad2;      // the 9-byte parameter block sits inside pad_2
-            if (codec != 0xA0 || pad2 < 9 || hdr > plen)
+            // PCM: the 9-byte parameter block is part of pad_2; MLP: pad_2 is plain padding
+            if (codec != want_codec || (want_codec == 0xA0 && pad2 < 9) || hdr > plen)
                 return false;
             f(pos + 6 + hdr, plen - hdr);
         }
@@ -171,6 +172,77 @@ __global__ __launch_bounds__(256) void k_pcm_unswizzle(const uint8_t *__restrict
             }
         }
         frame0 += 2 * chunks;
+    }
+}
+
+// ---------------------------------------------------------------- MLP track demux
+// AOB sectors of an MLP track -> the contiguous MLP byte stream the decoder is fed
+// (reference src/dvd-audio.c:1151-1227: every 0xBD packet with codec 0xA1, header and pad_2 stripped,
+// payloads appended in order).
+__global__ __launch_bounds__(256) void k_mlp_sector_scan(const uint8_t *__restrict__ sectors, uint32_t n_sectors,
+                                                         uint32_t *__restrict__ sec_bytes,
+                                                         uint32_t *__restrict__ n_bad)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sectors)
+        return;
+    uint32_t bytes = 0;
+    const bool ok = walk_sector(sectors + (size_t)s * SECTOR, [&](uint32_t, uint32_t len) { bytes += len; }, 0xA1);
+    if (!ok) {
+        bytes = 0;
+        atomicAdd(n_bad, 1u);
+    }
+    sec_bytes[s] = bytes;
+}
+
+// one wavefront per sector; payload bytes are copied from the LDS image of the sector
+__global__ __launch_bounds__(256) void k_mlp_gather(const uint8_t *__restrict__ sectors, uint32_t n_sectors,
+                                                    const uint32_t *__restrict__ sec_base,
+                                                    uint8_t *__restrict__ out, uint64_t out_cap)
+{
+    __shared__ uint4 s_sec[4][SECTOR / 16];
+    __shared__ uint32_t s_pk[4][2 * MAX_PACKETS + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * 4 + wv;
+    if (s < n_sectors) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sectors + (size_t)s * SECTOR);
+        s_sec[wv][lane] = src[lane];
+        s_sec[wv][lane + 64] = src[lane + 64];
+    }
+    __syncthreads();
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(&s_sec[wv][0]);
+    if (s < n_sectors && lane == 0) {
+        uint32_t n = 0;
+        const bool ok = walk_sector(p, [&](uint32_t off, uint32_t len) {
+            if (n < (uint32_t)MAX_PACKETS) {
+                s_pk[wv][1 + 2 * n] = off;
+                s_pk[wv][2 + 2 * n] = len;
+                n++;
+            }
+        }, 0xA1);
+        s_pk[wv][0] = ok ? n : 0;
+    }
+    __syncthreads();
+    if (s >= n_sectors)
+        return;
+    uint64_t dst = sec_base[s];
+    for (uint32_t k = 0; k < s_pk[wv][0]; k++) {
+        const uint32_t off = s_pk[wv][1 + 2 * k], len = s_pk[wv][2 + 2 * k];
+        // head bytes up to the first 4-byte aligned destination, then dwords, then the tail
+        const uint32_t head = (uint32_t)((4 - (dst & 3)) & 3) < len ? (uint32_t)((4 - (dst & 3)) & 3) : len;
+        if ((uint32_t)lane < head && dst + lane < out_cap)
+            out[dst + lane] = p[off + lane];
+        const uint32_t body = (len - head) >> 2;
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(out + dst + head);
+        for (uint32_t i = lane; i < body; i += 64) {
+            const uint8_t *c = p + off + head + 4 * i;
+            if (dst + head + 4 * i + 4 <= out_cap)
+                o32[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+        }
+        const uint32_t done = head + 4 * body;
+        if ((uint32_t)lane < len - done && dst + done + lane < out_cap)
+            out[dst + done + lane] = p[off + done + lane];
+        dst += len;
     }
 }
 

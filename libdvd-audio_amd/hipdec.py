@@ -41,7 +41,8 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
            "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",
-           "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result")
+           "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result",
+           "dvda_mlp_hip_demux_sectors")
 
 
 def lib():
@@ -85,6 +86,7 @@ def lib():
         L.dvda_pcm_hip_workspace_words.argtypes = [u32]
         L.dvda_pcm_hip_decode_sectors.argtypes = [vp, u32, ctypes.c_uint, ctypes.c_uint, vp, u64, vp, vp]
         L.dvda_pcm_hip_result.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u32), vp]
+        L.dvda_mlp_hip_demux_sectors.argtypes = [vp, u32, vp, u64, vp, vp]
         _lib = L
     return _lib
 
@@ -296,3 +298,23 @@ def pcm_decode_sectors(sectors, bits_per_sample, channels, device=0):
            "dvda_pcm_hip_result")
     out = d_pcm.cpu().numpy().reshape(channels, cap)[:, :frames.value].copy()
     return out, int(bad.value)
+
+
+def mlp_demux_sectors(sectors, device=0):
+    """AOB sectors of an MLP track -> (MLP bytes as uint8 array, bad_sectors), on the GPU."""
+    import torch
+    if not torch.cuda.is_available():
+        raise HipError("no GPU visible to torch: the demux path is HIP-only")
+    buf = np.ascontiguousarray(sectors, np.uint8)
+    assert len(buf) % 2048 == 0 and len(buf)
+    n = len(buf) // 2048
+    dev = torch.device("cuda", device)
+    d_sec = torch.from_numpy(buf).to(dev)
+    d_out = torch.zeros(len(buf) + 64, dtype=torch.uint8, device=dev)
+    d_work = torch.zeros(int(lib().dvda_pcm_hip_workspace_words(n)), dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _check(lib().dvda_mlp_hip_demux_sectors(d_sec.data_ptr(), n, d_out.data_ptr(), len(buf), d_work.data_ptr(), st),
+           "dvda_mlp_hip_demux_sectors")
+    nbytes, bad = ctypes.c_uint64(), ctypes.c_uint32()
+    _check(lib().dvda_pcm_hip_result(d_work.data_ptr(), n, ctypes.byref(nbytes), ctypes.byref(bad), st), "result")
+    return d_out[:nbytes.value].cpu().numpy(), int(bad.value)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "dvda_mlp_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dvda_(?:mlp_)?hip_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(dvda_(?:mlp_|pcm_)?hip_\w+)\s*\(", text)))
 
 
 def test_header_declares_the_batch_tier():

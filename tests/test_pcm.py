@@ -93,3 +93,21 @@ def test_gpu_pcm_large_track_and_bad_sector(pkg):
     n3 = 110                                                     # frames sector 3 carried
     assert got.shape[1] == len(s) - n3
     assert np.array_equal(got[:, :3 * n3], s.T[:, :3 * n3]) and np.array_equal(got[:, 3 * n3:], s.T[:, 4 * n3:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_aus,S", [(9, 1), (200, 2), (2300, 1)])
+def test_gpu_mlp_track_demux_then_decode(pkg, oracle, n_aus, S):
+    """AOB sectors -> MLP bytes on the GPU (must equal what went into the muxer),
+    then straight into the decode path."""
+    syn = pkg.synth
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=n_aus)
+    data, frames = syn.stream(cfg, 31)
+    sectors = np.frombuffer(b"".join(pkg.disc.mlp_track_sectors(data)), np.uint8).copy()
+    got, bad = pkg.hipdec.mlp_demux_sectors(sectors)
+    assert bad == 0
+    assert len(got) == len(data) and np.array_equal(got, data)
+    pcm, infos = pkg.hipdec.decode_streams([got], lanes_per_segment=2)
+    want, r, st = oracle.decode(data, 6, frames)
+    assert st == 0 and infos[0].status & ~pkg.hipdec.ST_BENIGN == 0
+    assert np.array_equal(pcm[0], want)
