@@ -175,6 +175,13 @@ int dvda_pcm_hip_result(const uint32_t *d_work, uint32_t n_sectors, uint64_t *pc
 int dvda_mlp_hip_demux_sectors(const uint8_t *d_sectors, uint32_t n_sectors, uint8_t *d_mlp,
                                uint64_t mlp_cap, uint32_t *d_work, void *stream);
 
+/* Output stage: planar int32 PCM -> the interleaved little-endian WAV payload
+ * dvda2wav writes: frame-major interleave of reference src/dvd-audio.c:781-792, each value as
+ * write_signed(bits) (utils/dvda2wav.c:326-334, src/bitstream.c:2846-2857).  bits = 16 or 24;
+ * d_out receives frames * channels * bits/8 bytes. */
+int dvda_mlp_hip_pack_wav(const int32_t *d_pcm, uint64_t stride, unsigned channels, uint64_t frames,
+                          unsigned bits_per_sample, uint8_t *d_out, void *stream);
+
 /* ------------------------------------------------------------------ tier B */
 /* The mlp.h mirror: same three calls, same meaning as reference src/mlp.h:29-42 /
  * src/mlp.c:265-354, with the reference's containers replaced by plain memory:

@@ -18,6 +18,7 @@
 #include "mlp_decode.h"
 #include "mlp_index.h"
 #include "pcm_unswizzle.h"
+#include "wav_pack.h"
 
 using namespace mlp;
 
@@ -583,6 +584,21 @@ extern "C" int dvda_mlp_hip_demux_sectors(const uint8_t *d_sectors, uint32_t n_s
     }
     hipLaunchKernelGGL(pcm::k_mlp_gather, dim3((n_sectors + 3) / 4), dim3(256), 0, st, d_sectors, n_sectors,
                        sec_base, d_mlp, mlp_cap);
+    HIP_TRY(hipGetLastError());
+    return DVDA_HIP_OK;
+}
+
+// ------------------------------------------------------------------ WAV payload
+extern "C" int dvda_mlp_hip_pack_wav(const int32_t *d_pcm, uint64_t stride, unsigned channels, uint64_t frames,
+                                     unsigned bits_per_sample, uint8_t *d_out, void *stream_)
+{
+    if (!d_pcm || !d_out || channels < 1 || channels > 6 || (bits_per_sample != 16 && bits_per_sample != 24))
+        return DVDA_HIP_EINVAL;
+    if (frames == 0)
+        return DVDA_HIP_OK;
+    const uint64_t blocks = (frames + wav::FRAMES - 1) / wav::FRAMES;
+    hipLaunchKernelGGL(wav::k_pack_wav, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, d_pcm, stride,
+                       channels, frames, bits_per_sample, d_out);
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
 }

@@ -42,7 +42,7 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
            "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",
            "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result",
-           "dvda_mlp_hip_demux_sectors")
+           "dvda_mlp_hip_demux_sectors", "dvda_mlp_hip_pack_wav")
 
 
 def lib():
@@ -87,6 +87,7 @@ def lib():
         L.dvda_pcm_hip_decode_sectors.argtypes = [vp, u32, ctypes.c_uint, ctypes.c_uint, vp, u64, vp, vp]
         L.dvda_pcm_hip_result.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u32), vp]
         L.dvda_mlp_hip_demux_sectors.argtypes = [vp, u32, vp, u64, vp, vp]
+        L.dvda_mlp_hip_pack_wav.argtypes = [vp, u64, ctypes.c_uint, u64, ctypes.c_uint, vp, vp]
         _lib = L
     return _lib
 
@@ -318,3 +319,19 @@ def mlp_demux_sectors(sectors, device=0):
     nbytes, bad = ctypes.c_uint64(), ctypes.c_uint32()
     _check(lib().dvda_pcm_hip_result(d_work.data_ptr(), n, ctypes.byref(nbytes), ctypes.byref(bad), st), "result")
     return d_out[:nbytes.value].cpu().numpy(), int(bad.value)
+
+
+def pack_wav(planar, bits_per_sample, device=0):
+    """int32 [channels, frames] -> interleaved little-endian WAV payload bytes, on the GPU."""
+    import torch
+    if not torch.cuda.is_available():
+        raise HipError("no GPU visible to torch: the WAV packing path is HIP-only")
+    planar = np.ascontiguousarray(planar, np.int32)
+    ch, frames = planar.shape
+    dev = torch.device("cuda", device)
+    d_pcm = torch.from_numpy(planar).to(dev)
+    d_out = torch.zeros(frames * ch * (bits_per_sample // 8) + 4, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _check(lib().dvda_mlp_hip_pack_wav(d_pcm.data_ptr(), frames, ch, frames, bits_per_sample, d_out.data_ptr(), st),
+           "dvda_mlp_hip_pack_wav")
+    return d_out[:frames * ch * (bits_per_sample // 8)].cpu().numpy()

@@ -110,3 +110,28 @@ pcm_oracle_decode_sectors(const uint8_t *sectors, size_t n_sectors, unsigned bps
     }
     return frames;
 }
+
+/* ---- planar int32 -> interleaved little-endian WAV payload.
+ * dvda_read interleaves frame-major in RIFF channel order (src/dvd-audio.c:781-792); dvda2wav
+ * writes every value with write_signed(bits) (utils/dvda2wav.c:326-334), which emits the low
+ * bits-1 bits and then a sign bit taken from v < 0 (src/bitstream.c:2846-2857) -- not plain
+ * truncation for out-of-range positives. */
+long
+wav_oracle_pack(const int32_t *planar, size_t stride, unsigned channels, size_t frames, unsigned bits,
+                uint8_t *out)
+{
+    const unsigned nb = bits / 8;
+    const uint32_t low = (1u << (bits - 1)) - 1u;
+    size_t f;
+    unsigned c, b;
+    if ((bits != 16 && bits != 24) || channels < 1 || channels > 6)
+        return -1;
+    for (f = 0; f < frames; f++)
+        for (c = 0; c < channels; c++) {
+            const int32_t v = planar[(size_t)c * stride + f];
+            const uint32_t u = ((uint32_t)v & low) | (v < 0 ? (1u << (bits - 1)) : 0u);
+            for (b = 0; b < nb; b++)
+                *out++ = (uint8_t)(u >> (8 * b));
+        }
+    return (long)(frames * channels * nb);
+}

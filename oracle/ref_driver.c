@@ -140,3 +140,20 @@ ref_pcm_decode(const uint8_t *payload, size_t len, unsigned bits_per_sample, uns
     samples->del(samples);
     return frames;
 }
+
+/* ---- WAV payload: dvda_read's interleave + dvda2wav's write_signed
+ *      (src/dvd-audio.c:781-792, utils/dvda2wav.c:326-334, src/bitstream.c:2846-2857) */
+long
+ref_wav_pack(const int *interleaved, size_t n, unsigned bits, uint8_t *out)
+{
+    BitstreamRecorder *r = bw_open_recorder(BS_LITTLE_ENDIAN);
+    BitstreamWriter *w = (BitstreamWriter *)r;
+    size_t i;
+    long bytes;
+    for (i = 0; i < n; i++)
+        w->write_signed(w, bits, interleaved[i]);
+    bytes = (long)r->bytes_written(r);
+    memcpy(out, r->data(r), (size_t)bytes);
+    r->close(r);
+    return bytes;
+}

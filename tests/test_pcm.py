@@ -111,3 +111,50 @@ def test_gpu_mlp_track_demux_then_decode(pkg, oracle, n_aus, S):
     want, r, st = oracle.decode(data, 6, frames)
     assert st == 0 and infos[0].status & ~pkg.hipdec.ST_BENIGN == 0
     assert np.array_equal(pcm[0], want)
+
+
+def _wav_oracle():
+    lib = _oracle()
+    lib.wav_oracle_pack.restype = ctypes.c_long
+    lib.wav_oracle_pack.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_size_t,
+                                    ctypes.c_uint, ctypes.c_void_p]
+    return lib
+
+
+def _wide_samples(ch, frames, seed):
+    """values inside and OUTSIDE the nominal width: write_signed is not plain truncation there"""
+    rng = np.random.RandomState(seed)
+    s = rng.randint(-(1 << 25), 1 << 25, size=(ch, frames)).astype(np.int32)
+    s[:, ::3] = rng.randint(-(1 << 15), 1 << 15, size=s[:, ::3].shape)
+    s[0, :4] = [(1 << 23), -(1 << 23) - 1, (1 << 31) - 1, -(1 << 31)]
+    return s
+
+
+@pytest.mark.skipif(not oracle_lib.Reference.available(), reason="compiled reference not present")
+@pytest.mark.parametrize("bits", [16, 24])
+@pytest.mark.parametrize("ch", [1, 2, 5, 6])
+def test_wav_pack_oracle_equals_reference_writer(bits, ch):
+    lib = _wav_oracle()
+    ref = ctypes.CDLL(oracle_lib.REF_SO)
+    ref.ref_wav_pack.restype = ctypes.c_long
+    ref.ref_wav_pack.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p]
+    s = _wide_samples(ch, 333, ch + bits)
+    inter = np.ascontiguousarray(s.T.reshape(-1))
+    a = np.zeros(len(inter) * 3 + 8, np.uint8)
+    b = np.zeros(len(inter) * 3 + 8, np.uint8)
+    na = lib.wav_oracle_pack(s.ctypes.data, s.shape[1], ch, s.shape[1], bits, a.ctypes.data)
+    nb = ref.ref_wav_pack(inter.ctypes.data, len(inter), bits, b.ctypes.data)
+    assert na == nb == len(inter) * bits // 8
+    assert np.array_equal(a[:na], b[:nb])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [16, 24])
+@pytest.mark.parametrize("ch,frames", [(1, 1), (2, 255), (3, 256), (5, 1000), (6, 4099)])
+def test_gpu_wav_pack_matches_oracle(pkg, bits, ch, frames):
+    lib = _wav_oracle()
+    s = _wide_samples(ch, max(frames, 4), frames)[:, :frames].copy()
+    want = np.zeros(frames * ch * 3 + 8, np.uint8)
+    n = lib.wav_oracle_pack(s.ctypes.data, frames, ch, frames, bits, want.ctypes.data)
+    got = pkg.hipdec.pack_wav(s, bits)
+    assert len(got) == n and np.array_equal(got, want[:n])
