@@ -139,3 +139,67 @@ def test_streaming_tier_mirrors_mlp_h(pkg, oracle, feature, chunk):
     assert st == 0
     got = np.asarray(samples, np.int32)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_edge_cases_truncated_ragged_and_single_unit(pkg, oracle):
+    """Ragged batch: titles of very different lengths, a truncated tail (left unconsumed, as the
+    reference leaves it queued), a stream of a single access unit, a maximum-size 192 kHz unit."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfgs = [syn.make_cfg(assignment=12, rate_code=1, n_aus=1), syn.make_cfg(assignment=1, rate_code=0, n_aus=3),
+            syn.make_cfg(assignment=12, rate_code=2, n_aus=17, restart_interval=16),
+            syn.make_cfg(assignment=12, rate_code=1, n_aus=333)]
+    streams, frames = [], []
+    for i, c in enumerate(cfgs):
+        b, f = syn.stream(c, 900 + i)
+        streams.append(b)
+        frames.append(f)
+    cut = streams[3][:len(streams[3]) - 123]            # ends inside the last access unit
+    pcm, infos = hip.decode_streams(streams[:3] + [cut], lanes_per_segment=2)
+    for i in range(3):
+        want, r, st = oracle.decode(streams[i], syn.channels(cfgs[i].assignment), frames[i])
+        assert infos[i].status & ~hip.ST_BENIGN == 0 and np.array_equal(pcm[i], want)
+    want, r, st = oracle.decode(cut, 6, frames[3])
+    assert st == 0 and r == frames[3] - 80
+    assert infos[3].status & hip.ST["TRUNCATED"] and infos[3].status & ~hip.ST_BENIGN == 0
+    assert infos[3].pcm_frames == r and np.array_equal(pcm[3], want)
+    assert infos[3].bytes_consumed < len(cut)
+
+
+def test_corruption_is_reported_not_decoded(pkg, oracle):
+    """Where the reference assert()s (parity/CRC, bad restart sync, invalid code), both the oracle
+    and the HIP path must flag the stream; untouched streams of the same batch stay exact."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=24)
+    good, frames = syn.stream(cfg, 41)
+    flip = good.copy()
+    flip[len(flip) // 2] ^= 0x04                        # payload bit: parity and CRC both break
+    crc_only = good.copy()
+    # find the first frame's CRC byte: frame 0 = header 4 + sync 28 + info 2 + substream
+    size0 = 2 * (((int(good[0]) & 0xF) << 8) | int(good[1]))
+    crc_only[size0 - 1] ^= 0xFF
+    nosync = good[size0:].copy()                        # starts with a non-sync frame
+    pcm, infos = hip.decode_streams([good, flip, crc_only, nosync, good], lanes_per_segment=1)
+    want, r, st = oracle.decode(good, 6, frames)
+    for i in (0, 4):
+        assert infos[i].status == 0 and np.array_equal(pcm[i], want)
+    _, _, st1 = oracle.decode(flip, 6, frames)
+    _, _, st2 = oracle.decode(crc_only, 6, frames)
+    _, _, st3 = oracle.decode(nosync, 6, frames)
+    assert st1 & (hip.ST["PARITY"] | hip.ST["CRC"]) and infos[1].status & (hip.ST["PARITY"] | hip.ST["CRC"])
+    assert st2 & hip.ST["CRC"] and infos[2].status & hip.ST["CRC"]
+    assert st3 & hip.ST["NO_SYNC"] and infos[3].status & hip.ST["NO_SYNC"]
+
+
+def test_linearity_free_property_checksum_of_large_batch(pkg, oracle):
+    """Full-size style check through a size-independent property: the GPU's per-title sums over a
+    larger batch equal the oracle's, and decoding is idempotent (same bytes, same PCM, twice)."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=128)
+    streams = [syn.stream(cfg, 7000 + i)[0] for i in range(48)]
+    pcm1, infos1 = hip.decode_streams(streams, lanes_per_segment=1)
+    pcm2, infos2 = hip.decode_streams(streams, lanes_per_segment=2)
+    for i, b in enumerate(streams):
+        want, r, st = oracle.decode(b, 6, 128 * 80)
+        assert st == 0 and infos1[i].status == 0 and infos2[i].status == 0
+        assert int(pcm1[i].astype(np.int64).sum()) == int(want.astype(np.int64).sum())
+        assert np.array_equal(pcm1[i], pcm2[i]) and np.array_equal(pcm1[i], want)
