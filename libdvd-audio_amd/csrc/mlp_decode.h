@@ -132,17 +132,27 @@ __device__ __forceinline__ int32_t huff_center(uint32_t codebook, uint32_t lb)
     return ss >= 0 ? (1 << ss) : 0;
 }
 
+// Ring layout: [dword index mod RING_DWORDS][lane].  A lane's dword d sits at
+// (d mod RING_DWORDS) * 64 + lane, so whatever position each lane reads, lane l always hits
+// bank l mod 32: ring reads and writes are conflict-free and an address costs two instructions.
+__device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, const uint4 &b, const uint4 &c,
+                                             const uint4 &d)
+{
+    // dst = slot of the chunk's first dword; the chunk is 16-dword aligned, so no wrap inside it
+    dst[0 * 64] = a.x;  dst[1 * 64] = a.y;  dst[2 * 64] = a.z;  dst[3 * 64] = a.w;
+    dst[4 * 64] = b.x;  dst[5 * 64] = b.y;  dst[6 * 64] = b.z;  dst[7 * 64] = b.w;
+    dst[8 * 64] = c.x;  dst[9 * 64] = c.y;  dst[10 * 64] = c.z; dst[11 * 64] = c.w;
+    dst[12 * 64] = d.x; dst[13 * 64] = d.y; dst[14 * 64] = d.z; dst[15 * 64] = d.w;
+}
+
 // ---------------------------------------------------------------- cold helpers
 // Synchronous fill of one 64-byte chunk into a lane's ring slots (used after
 // seeks and inside long headers; the row loop prefetches instead).
 // dst: this lane's 16-byte slot in the chunk's first plane; planes are 64 slots apart.
-__device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint4 *dst)
+__device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint32_t *dst)
 {
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-    dst[0] = a;
-    dst[64] = b;
-    dst[128] = c;
-    dst[192] = d;
+    ring_store16(dst, a, b, c, d);
 }
 
 // Byte-wise ends of the parity/CRC check (src/mlp.c:1397-1398 and 690-706).
@@ -191,9 +201,7 @@ __device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride,
 
 // ------------------------------------------------------------------ bit reader
 // MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206)
-// over a per-lane LDS ring.  Ring layout: [plane][lane][4 dwords]; the dword with
-// absolute index d sits in plane (d >> 2) & 15, so a lane's 16-byte slots of one
-// plane are contiguous across lanes (conflict-free 16-byte fills).
+// over a per-lane LDS ring (layout above: [dword mod RING_DWORDS][lane]).
 //
 // Three stream dwords are held in registers: (hi, lo) form the 64-bit window the
 // current symbol is cut from at bit offset ofs (< 32 between symbols) and nx is
@@ -203,7 +211,7 @@ __device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride,
 // buffer is limited to 16 GiB (checked by dvda_mlp_hip_index).
 struct BitReader {
     const uint4 *gsrc;      // global bytes as 16-byte units
-    uint32_t *ring;         // this lane's slot base: wave ring + lane * 4
+    uint32_t *ring;         // this lane's column: wave ring + lane
     const uint8_t *crc_tab; // LDS, 4 x 256
     uint32_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
     uint32_t hi, lo, nx;    // stream dwords next-3, next-2, next-1 (big-endian order)
@@ -219,7 +227,7 @@ struct BitReader {
 
     __device__ __forceinline__ uint32_t *slot(uint32_t d) const
     {
-        return ring + (((d >> 2) & (RING_PLANES - 1)) * 256u) + (d & 3u);
+        return ring + ((d & (RING_DWORDS - 1)) << 6);
     }
     __device__ __forceinline__ uint32_t ld(uint32_t d) const { return __builtin_bswap32(*slot(d)); }
     __device__ __forceinline__ void filled()
@@ -256,7 +264,7 @@ struct BitReader {
         if (crc_rem && (int32_t)(fillpos + CHUNK_DWORDS - RING_DWORDS - crc_pos) > 0)
             crc_catchup(fillpos);
         const uint32_t c = fillpos < max_chunk ? fillpos : max_chunk;
-        ring_fill_sync(gsrc + (c >> 2), reinterpret_cast<uint4 *>(slot(fillpos)));
+        ring_fill_sync(gsrc + (c >> 2), slot(fillpos));
         filled();
     }
     __device__ __forceinline__ void ensure(uint32_t n)           // n dwords resident at/after next
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     if (GENERAL && *a.deferred == 0)
         return;                                                   // nothing was deferred: whole grid exits
     __shared__ uint8_t s_crc[4 * 256];
-    __shared__ uint4 s_ring[DEC_WAVES][RING_PLANES][64];
+    __shared__ uint32_t s_ring[DEC_WAVES][RING_DWORDS][64];
     __shared__ int32_t s_out[GENERAL ? 1 : DEC_WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
     __shared__ int32_t s_xch[PAIRED ? DEC_WAVES : 1][MAXCH][PAIRED ? 64 : 1];
 
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 
     BitReader rd;
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
-    rd.ring = reinterpret_cast<uint32_t *>(&s_ring[wv][0][lane]);
+    rd.ring = &s_ring[wv][0][lane];
     rd.crc_tab = s_crc;
     rd.max_chunk = (uint32_t)(((a.total_bytes + 63) >> 6) << 4);  // the chunk holding the spare bytes
     rd.hi = rd.lo = rd.nx = 0;
@@ -1287,11 +1295,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 
         // ---- the prefetched chunk lands in the ring
         if (pf) {
-            uint4 *dst = reinterpret_cast<uint4 *>(rd.slot(rd.fillpos));
-            dst[0] = p0;
-            dst[64] = p1;
-            dst[128] = p2;
-            dst[192] = p3;
+            ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3);
             rd.filled();
         }
         DVDA_STAMP(4);
