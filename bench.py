@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", type=int, default=8, help="titles checked against the oracle")
+    ap.add_argument("--assignment", type=int, default=12,
+                    help="channel assignment of the synthetic titles (12 = 6-ch, the BASELINE metric; "
+                         "1 = 2-ch for configs[1] exploration)")
     return ap.parse_args()
 
 
@@ -95,7 +98,7 @@ def main():
     import libdvd_audio_amd as pkg
     syn, hip = pkg.synth, pkg.hipdec
 
-    assignment, rate_code = 12, 1
+    assignment, rate_code = args.assignment, 1
     nch = syn.channels(assignment)
     rpa = syn.rows_per_au(rate_code)
     cfg = syn.make_cfg(assignment=assignment, rate_code=rate_code, n_substreams=1, n_aus=args.aus)

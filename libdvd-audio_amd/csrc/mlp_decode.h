@@ -1090,8 +1090,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             uint32_t bad_code = 0;
 #pragma unroll
             for (int k = 0; k < NS; k++) {
-                // branch-free symbol decode: slots beyond the lane's channel count read 0 bits
+                // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
+                // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
                 const bool in = (uint32_t)k < nslots;
+                if (k >= 2 && !__any(in)) {
+                    val[k] = 0;
+                    continue;
+                }
                 const uint32_t pkk = in ? pk[k] : 0u;
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
