@@ -73,6 +73,8 @@ extern "C" {
 #define DVDA_ST_TRUNCATED    (1u << 21)  /* stream ends inside a frame (tail not consumed)       */
 #define DVDA_ST_CAPACITY     (1u << 22)  /* general-pass workspace exhausted (too many deferred runs) */
 #define DVDA_ST_GENERAL      (1u << 23)  /* segment was decoded by the general pass (informational)   */
+#define DVDA_ST_FALSE_SYNC   (1u << 24)  /* segment-level only: a sync pattern inside another segment's
+                                            frame chain (payload / padding bytes), resolved and skipped */
 /* DVDA_ST_CHAINED, _MIDFRAME and _TIMING are raised by the fast pass and then decoded exactly by
  * the general pass that follows it; they stay set as information.  Bits that do not invalidate
  * the PCM: */

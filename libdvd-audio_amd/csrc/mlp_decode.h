@@ -445,6 +445,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     // general pass: does this lane head a run, and does the whole stream go in order?
     const bool seq = GENERAL && (stream_status & ST_TIMING);
     bool resume_fir = false, general_head = false, resume_from_init = false;
+    uint32_t prev_seg = 0;
     int32_t *fbuf = nullptr;
     if (GENERAL && active) {
         const uint32_t st_j = a.seg_status[segi];
@@ -454,7 +455,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         } else {
             // segments the general pass has already decoded carry ST_GENERAL
             const bool flagged = (st_j & (ST_CHAINED | ST_MIDFRAME)) != 0 && !(st_j & ST_GENERAL);
-            const uint32_t st_p = segi > stream_first ? a.seg_status[segi - 1] : 0u;
+            prev_seg = segi;                                    // previous LIVE segment of the stream
+            while (prev_seg > stream_first) {
+                prev_seg--;
+                if (!(a.seg[prev_seg].flags & SEG_DEAD))
+                    break;
+            }
+            const uint32_t st_p = prev_seg < segi ? a.seg_status[prev_seg] : 0u;
             const bool prev_flagged = (st_p & (ST_CHAINED | ST_MIDFRAME)) != 0 && !(st_p & ST_GENERAL);
             head = flagged && !((st_j & ST_CHAINED) && prev_flagged);
             resume_fir = head && (st_j & ST_CHAINED);
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         for (int k = 0; k < NS; k++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                st[k][j] = a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + (gl - L)];
+                st[k][j] = a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + (prev_seg * L + sub)];
     }
     if (GENERAL && resume_from_init) {
 #pragma unroll
@@ -655,7 +662,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         atomicOr(&a.seg_status[segi], status | ((status & ~(ST_DEFERRED | ST_OVERFLOW)) ? 0u : ST_GENERAL));
                         if (is_last_sub)
                             a.seg_rows[segi] = rows_written;
-                        const uint32_t nxt = segi + 1;
+                        uint32_t nxt = segi + 1;                 // next live segment
+                        while (nxt < n_seg && a.seg[nxt].stream == sr.stream && (a.seg[nxt].flags & SEG_DEAD))
+                            nxt++;
                         if (!(status & ~(ST_DEFERRED | ST_OVERFLOW)) && nxt < n_seg) {
                             const SegRec nr = a.seg[nxt];
                             const uint32_t nst = a.seg_status[nxt];
@@ -664,8 +673,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                 (seq || (nst & ST_CHAINED))) {
                                 go_on = true;
                                 atomicAnd(&a.seg_status[nxt], ST_DEFERRED | ST_FATAL_INDEX | (1u << 21));
+                                seg_lane += (nxt - segi) * L;
                                 segi = nxt;
-                                seg_lane += L;
                                 sr = nr;
                                 if (!seq) {
                                     row0 = (uint64_t)(a.seg_fbase[nxt] - a.seg_fbase[stream_first]) * rpa;

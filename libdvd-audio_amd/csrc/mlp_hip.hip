@@ -280,6 +280,8 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     hipLaunchKernelGGL(k_chase, dim3((ms + 255) / 256), dim3(256), 0, st, d_bytes, d_stream_off,
                        d_stream_len, n_streams, c->d_cand_off, c->d_n_cand, ms, c->d_seg,
                        c->d_seg_frames, c->d_streams);
+    hipLaunchKernelGGL(k_mark_dead, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
+                       c->d_n_cand, ms, c->d_seg, c->d_seg_frames);
     exscan(c, st, c->d_seg_frames, c->d_seg_fbase, 0u, c->d_n_cand, ms);
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
                        c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams);

@@ -318,6 +318,49 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     }
 }
 
+constexpr uint32_t SEG_DEAD = 1u << 24;   // DVDA_ST_FALSE_SYNC: candidate inside another segment's frame chain
+
+// Pass 3b (before the scan): a sync pattern can occur inside payload or padding bytes.  Such a
+// false candidate is not a frame start of the real chain: the previous candidate's size-chain walk
+// passes over it and lands on a later candidate.  It is marked dead (no frames, no lanes) instead
+// of being trusted; what cannot be resolved this way stays DVDA_ST_IRREGULAR.
+__global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ stream_off,
+                                                   const uint64_t *__restrict__ stream_len,
+                                                   const uint32_t *__restrict__ n_cand_ptr, uint32_t max_cand,
+                                                   SegRec *__restrict__ seg, uint32_t *__restrict__ seg_frames)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = *n_cand_ptr;
+    if (n_cand > max_cand)
+        n_cand = max_cand;
+    if (i >= n_cand || i == 0)
+        return;
+    const uint32_t s = seg[i].stream;
+    const uint64_t off = seg[i].off;
+    if (seg[i - 1].stream != s)
+        return;                                   // first candidate of its stream
+    // does a chain land exactly here?
+    for (uint32_t q = i; q-- > 0 && i - q <= 3 && seg[q].stream == s;)
+        if (seg[q].end == off)
+            return;
+    // nobody lands here: is it inside the span of an earlier chain that lands later (or at the end)?
+    const uint64_t s_end = stream_off[s] + stream_len[s];
+    for (uint32_t q = i; q-- > 0 && i - q <= 3 && seg[q].stream == s;) {
+        const uint64_t e = seg[q].end;
+        if (e <= off || seg[q].nframes == 0)
+            continue;
+        bool lands = (e == s_end) || (seg[q].flags & (1u << 21));          // ran to the (truncated) end
+        for (uint32_t j = i + 1; !lands && j < n_cand && j <= i + 3 && seg[j].stream == s; j++)
+            lands = seg[j].off == e;
+        if (lands) {
+            seg[i].flags |= SEG_DEAD;
+            seg[i].nframes = 0;
+            seg_frames[i] = 0;
+            return;
+        }
+    }
+}
+
 // Pass 4 (after the exclusive scan of seg_frames): per-stream totals and the
 // landing check.  One lane per segment.
 __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ stream_off,
@@ -334,14 +377,19 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
     if (i >= n_cand)
         return;
     SegRec r = seg[i];
+    if (r.flags & SEG_DEAD)
+        return;
     const uint32_t s = r.stream;
     const uint64_t s_begin = stream_off[s];
     const uint64_t s_end = s_begin + stream_len[s];
-    const bool last = (i + 1 == n_cand) || (seg[i + 1].stream != s);
+    uint32_t j = i + 1;                           // next live candidate of the stream
+    while (j < n_cand && seg[j].stream == s && (seg[j].flags & SEG_DEAD))
+        j++;
+    const bool last = (j == n_cand) || (seg[j].stream != s);
     uint32_t st = r.flags;
     if (streams[s].first_seg == i && r.off != s_begin)
         st |= 1u << 0; // DVDA_ST_NO_SYNC: data before the first major sync
-    if (!last && seg[i + 1].off != r.end)
+    if (!last && seg[j].off != r.end)
         st |= 1u << 16; // chain does not land on the next candidate
     if (r.sync != streams[s].sync) {
         // reference compares the five stream parameters (src/mlp.c:450-455) and
@@ -355,9 +403,9 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
     if (st)
         atomicOr(&streams[s].status, st);
     if (last) {
-        streams[s].n_seg = i + 1 - streams[s].first_seg;
+        streams[s].n_seg = j - streams[s].first_seg;
         streams[s].consumed = r.end - s_begin;
-        streams[s].frames = seg_fbase[i + 1] - seg_fbase[streams[s].first_seg];
+        streams[s].frames = seg_fbase[j] - seg_fbase[streams[s].first_seg];
         (void)s_end;
     }
 }

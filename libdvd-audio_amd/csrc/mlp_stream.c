@@ -269,9 +269,31 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
     /* ---- keep what the next call needs: bytes from the last major sync on, the FIR history in
      *      front of that segment, and how many of its frames have been handed out */
     if (n_sync >= 2) {
-        dvda_mlp_segment_info si;
-        if (dvda_mlp_hip_segment_fir(d->ctx, n_sync - 2, d->fir, NULL) ||
-            dvda_mlp_hip_segment_info(d->ctx, n_sync - 1, &si, NULL))
+        /* device segment indices also count sync patterns found inside payload bytes
+           (DVDA_ST_FALSE_SYNC): the last two LIVE segments are the ones wanted */
+        dvda_mlp_segment_info si, sp;
+        uint32_t n_dev = 0, last_i, prev_i;
+        if (dvda_mlp_hip_segment_count(d->ctx, &n_dev, NULL) || n_dev < 2)
+            return 0;
+        last_i = n_dev - 1;
+        for (;;) {
+            if (dvda_mlp_hip_segment_info(d->ctx, last_i, &si, NULL))
+                return 0;
+            if (!(si.status & DVDA_ST_FALSE_SYNC) || last_i == 0)
+                break;
+            last_i--;
+        }
+        if (last_i == 0)
+            return 0;
+        prev_i = last_i - 1;
+        for (;;) {
+            if (dvda_mlp_hip_segment_info(d->ctx, prev_i, &sp, NULL))
+                return 0;
+            if (!(sp.status & DVDA_ST_FALSE_SYNC) || prev_i == 0)
+                break;
+            prev_i--;
+        }
+        if (dvda_mlp_hip_segment_fir(d->ctx, prev_i, d->fir, NULL))
             return 0;
         d->have_fir = 1;
         d->rows_before = si.pcm_frames;

@@ -203,3 +203,52 @@ def test_linearity_free_property_checksum_of_large_batch(pkg, oracle):
         assert st == 0 and infos1[i].status == 0 and infos2[i].status == 0
         assert int(pcm1[i].astype(np.int64).sum()) == int(want.astype(np.int64).sum())
         assert np.array_equal(pcm1[i], pcm2[i]) and np.array_equal(pcm1[i], want)
+
+
+def _inject_false_sync(stream, frame_index):
+    """Grows one access unit by 64 ignored tail bytes that look exactly like a major-sync access
+    unit header (the reference ignores everything behind the last substream, src/mlp.c:470-610)."""
+    b = stream
+    pos = 0
+    for _ in range(frame_index):
+        pos += 2 * (((int(b[pos]) & 0xF) << 8) | int(b[pos + 1]))
+    size = 2 * (((int(b[pos]) & 0xF) << 8) | int(b[pos + 1]))
+    fake = np.zeros(64, np.uint8)
+    fake[0:2] = [0x00, 0x40]                      # size field: 0x40 words = 128 bytes
+    fake[4:8] = [0xF8, 0x72, 0x6F, 0xBB]
+    fake[8:10] = [0x22, 0x11]
+    fake[11] = 12
+    fake[20] = 0x10                               # substream count 1
+    new_size = size + 64
+    out = np.concatenate([b[:pos], b[pos:pos + size], fake, b[pos + size:]]).astype(np.uint8)
+    out[pos] = (out[pos] & 0xF0) | ((new_size // 2) >> 8)
+    out[pos + 1] = (new_size // 2) & 0xFF
+    return out
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_false_sync_pattern_in_ignored_bytes_is_resolved(pkg, oracle, S):
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=40)
+    clean, frames = syn.stream(cfg, 1234)
+    chained_cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=40, profile=1,
+                               features=syn.SF["CHAINED"] | syn.SF["FIRRAND"], restart_interval=4)
+    chained, cframes = syn.stream(chained_cfg, 4321)
+    cases = [(_inject_false_sync(clean, 3), frames), (_inject_false_sync(clean, 39), frames),
+             (_inject_false_sync(chained, 10), cframes), (clean, frames)]
+    pcm, infos = hip.decode_streams([c[0] for c in cases], lanes_per_segment=2)
+    for (b, f), got, inf in zip(cases, pcm, infos):
+        want, r, st = oracle.decode(b, 6, f)
+        assert st == 0 and r == f
+        assert inf.status & ~hip.ST_BENIGN == 0, hex(inf.status)
+        assert inf.pcm_frames == f and np.array_equal(got, want)
+    # and through the streaming tier
+    dec = hip.MLPDecoder(2, 2, 1, 1, 12)
+    samples = [[] for _ in range(6)]
+    b = cases[2][0]
+    for off in range(0, len(b), 3001):
+        dec.decode_packet(np.ascontiguousarray(b[off:off + 3001]), samples)
+        assert dec.status & ~hip.ST_BENIGN == 0
+    dec.close()
+    want, r, st = oracle.decode(b, 6, cframes)
+    assert np.array_equal(np.asarray(samples, np.int32), want)
