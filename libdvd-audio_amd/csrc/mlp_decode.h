@@ -526,7 +526,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
                                       // fir_order<<19 | fir_shift<<23 | iir_shift<<27
     int32_t sho[NS];                  // signed huffman offset (src/mlp.c:1152-1176)
-    uint32_t mreg[2][5];              // coefficients of matrices 0 and 1 (int16 pairs)
+    uint32_t mreg[2][4];              // channel coefficients of matrices 0 and 1 (int16 pairs), zero
+                                      // beyond max_matrix_channel
     uint32_t mnoise[2] = {0, 0};      // their two noise coefficients (follow channel max_matrix_channel)
 #pragma unroll
     for (int k = 0; k < NS; k++) {
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int j = 0; j < 5; j++)
+        for (int j = 0; j < 4; j++)
             mreg[m][j] = 0;
     if (GENERAL && resume_fir) {
         // history left by the previous segment's lane in the fast pass
@@ -588,49 +589,38 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
         const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
         seed = (seed << 16) ^ shifted ^ (shifted << 5);
-        for (uint32_t m = 0; m < matrix_len; m++) {
-            uint32_t mc[5];
-            uint32_t nz;
-            if (m < 2) {
-#pragma unroll
-                for (int j = 0; j < 5; j++)
-                    mc[j] = m == 0 ? mreg[0][j] : mreg[1][j];
-                nz = m == 0 ? mnoise[0] : mnoise[1];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 5; j++)
-                    mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
-                // the two noise coefficients follow channel max_matrix_channel
-                int32_t cn0 = 0, cn1 = 0;
-#pragma unroll
-                for (int c = 1; c < 10; c++) {
-                    const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
-                    cn0 = ((uint32_t)c == max_mat_ch + 1) ? coef : cn0;
-                    cn1 = ((uint32_t)c == max_mat_ch + 2) ? coef : cn1;
-                }
-                nz = ((uint32_t)cn0 & 0xFFFFu) | ((uint32_t)cn1 << 16);
-            }
+        // one matrix: straight-line multiply-accumulate over all channels (coefficients past
+        // max_matrix_channel are stored as 0), result placed by select; `on` is per lane
+        auto one_matrix = [&](const uint32_t(&mc)[4], uint32_t nz, uint32_t m, bool on) {
             int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
-                if ((uint32_t)c <= max_mat_ch)
-                    acc += (int64_t)ch[c] * (int64_t)coef;
-            }
+            for (int c = 0; c < 6; c++)
+                acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]));
             if (__builtin_expect(wide_matrix, 0)) {       // channels 6 and 7: never on DVD-Audio layouts
 #pragma unroll
-                for (int c = 6; c < MAXCH; c++) {
-                    const int32_t coef = (c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]);
-                    if ((uint32_t)c <= max_mat_ch)
-                        acc += (int64_t)ch[c] * (int64_t)coef;
-                }
+                for (int c = 6; c < MAXCH; c++)
+                    acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]));
             }
             const uint32_t oc = nib(outch_pack, m);
             const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
                                          ((bypass_bits >> m) & 1u));
+            const uint32_t oce = on ? oc : 0xFFu;
 #pragma unroll
             for (int c = 0; c < MAXCH; c++)
-                ch[c] = ((uint32_t)c == oc) ? nv : ch[c];
+                ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
+        };
+        if (__any(matrix_len > 0))
+            one_matrix(mreg[0], mnoise[0], 0, matrix_len > 0);
+        if (__any(matrix_len > 1))
+            one_matrix(mreg[1], mnoise[1], 1, matrix_len > 1);
+        if (__builtin_expect(__any(matrix_len > 2), 0)) {
+            for (uint32_t m = 2; m < matrix_len; m++) {    // cold: matrices 2.. live in the workspace
+                uint32_t mc[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
+                one_matrix(mc, a.mat_ws[(size_t)(m * 5 + 4) * a.total_lanes + gl], m, true);
+            }
         }
 #pragma unroll
         for (int c = 0; c < MAXCH; c++)
@@ -828,19 +818,25 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                                         noise |= (uint32_t)v & 0xFFFFu;
                                     if (c == max_mat_ch + 2)
                                         noise |= (uint32_t)v << 16;
+                                    // kept per channel: positions past max_matrix_channel are stored as 0,
+                                    // so the row loop multiplies all channels unconditionally
+                                    const int32_t vc = c <= max_mat_ch ? v : 0;
                                     if (c & 1) {
-                                        const uint32_t word = pair | ((uint32_t)v << 16);
-                                        a.mat_ws[(size_t)(m * 5 + (c >> 1)) * a.total_lanes + gl] = word;
+                                        const uint32_t word = pair | ((uint32_t)vc << 16);
+                                        if (c < 8) {
+                                            a.mat_ws[(size_t)(m * 5 + (c >> 1)) * a.total_lanes + gl] = word;
 #pragma unroll
-                                        for (int mm = 0; mm < 2; mm++)
+                                            for (int mm = 0; mm < 2; mm++)
 #pragma unroll
-                                            for (int jj = 0; jj < 5; jj++)
-                                                if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1))
-                                                    mreg[mm][jj] = word;
+                                                for (int jj = 0; jj < 4; jj++)
+                                                    if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1))
+                                                        mreg[mm][jj] = word;
+                                        }
                                     } else {
-                                        pair = (uint32_t)v & 0xFFFFu;
+                                        pair = (uint32_t)vc & 0xFFFFu;
                                     }
                                 }
+                                a.mat_ws[(size_t)(m * 5 + 4) * a.total_lanes + gl] = noise;
                                 if (m == 0)
                                     mnoise[0] = noise;
                                 if (m == 1)
