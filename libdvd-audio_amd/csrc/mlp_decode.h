@@ -71,7 +71,15 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 #if defined(DVDA_EXP_NOSTORE)
 #define DVDA_STORE_V4(dst, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
 #else
-#define DVDA_STORE_V4(dst, a_, b_, c_, d_) (*reinterpret_cast<int4 *>(dst) = make_int4(a_, b_, c_, d_))
+// One 16-byte store instruction, opaque to the optimizer: left to itself the compiler merges this
+// store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
+// which doubles the store instructions and splits every half-sector write in two.
+typedef int dvda_v4i __attribute__((ext_vector_type(4)));
+#define DVDA_STORE_V4(dst, a_, b_, c_, d_)                                                          \
+    do {                                                                                            \
+        dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
+        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v4_) : "memory");           \
+    } while (0)
 #endif
 
 // status bits (mirror include/dvda_mlp_hip.h)
@@ -332,6 +340,22 @@ struct BitReader {
         ofs += n;
         while (ofs >= 32)
             advance();
+        return v;
+    }
+    // n in [0, 31], branch-free; the caller guarantees that the dword at `next` is resident
+    // (the row loop keeps 12 dwords ahead)
+    __device__ __forceinline__ uint32_t read_resident(uint32_t n)
+    {
+        const uint32_t top = peek32();
+        const uint32_t v = (top >> 1) >> (31u - n);                  // n == 0 -> 0
+        const uint32_t o = ofs + n;
+        const bool step = o >= 32u;
+        const uint32_t cand = ld(next);
+        hi = step ? lo : hi;
+        lo = step ? nx : lo;
+        nx = step ? cand : nx;
+        next += step ? 1u : 0u;
+        ofs = o & 31u;
         return v;
     }
     __device__ __forceinline__ int32_t read_signed(uint32_t n)
@@ -604,10 +628,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             const uint32_t oc = nib(outch_pack, m);
             const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
                                          ((bypass_bits >> m) & 1u));
-            const uint32_t oce = on ? oc : 0xFFu;
+            const uint32_t oce = on ? oc : 0xFFu;                // oc <= max_matrix_channel (checked)
 #pragma unroll
-            for (int c = 0; c < MAXCH; c++)
+            for (int c = 0; c < 6; c++)
                 ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
+            if (__builtin_expect(wide_matrix, 0)) {
+#pragma unroll
+                for (int c = 6; c < MAXCH; c++)
+                    ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
+            }
         };
         if (__any(matrix_len > 0))
             one_matrix(mreg[0], mnoise[0], 0, matrix_len > 0);
@@ -1085,11 +1114,19 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 
         if (active) {
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
+            // all of the row's bypassed LSBs (at most one per matrix) are cut from the window at once
+            // and dealt to their matrices in stream order -- straight-line, no per-bit read
             uint32_t bypass_bits = 0;
-            if (bypass_mask) {
-                for (uint32_t m = 0; m < matrix_len; m++)
-                    if ((bypass_mask >> m) & 1u)
-                        bypass_bits |= rd.read(1) << m;
+            if (__any(bypass_mask != 0)) {
+                const uint32_t cnt = (uint32_t)__popc(bypass_mask);          // <= MAXMAT
+                const uint32_t field = rd.read_resident(cnt);
+                uint32_t rank = 0;
+#pragma unroll
+                for (int m = 0; m < MAXMAT; m++) {
+                    const uint32_t bit = (bypass_mask >> m) & 1u;
+                    bypass_bits |= (bit & (field >> ((cnt - 1u - rank) & 31u))) << m;
+                    rank += bit;
+                }
             }
             int32_t val[NS];
             uint32_t bad_code = 0;
