@@ -75,10 +75,13 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 // store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
 // which doubles the store instructions and splits every half-sector write in two.
 typedef int dvda_v4i __attribute__((ext_vector_type(4)));
+#ifndef DVDA_STORE_MODS
+#define DVDA_STORE_MODS ""
+#endif
 #define DVDA_STORE_V4(dst, a_, b_, c_, d_)                                                          \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v4_) : "memory");           \
+        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_MODS ::"v"(dst), "v"(v4_) : "memory"); \
     } while (0)
 #endif
 
@@ -1102,7 +1105,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #endif
                         (!rd.crc_rem || (int32_t)(rd.fillpos + CHUNK_DWORDS - RING_DWORDS - rd.crc_pos) <= 0);
         uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+#if defined(DVDA_EXP_ALWAYSLOAD)
+        if (pf || active) {      // diagnostic: every lane issues the four loads every row
+#else
         if (pf) {
+#endif
             const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
             const uint4 *src = rd.gsrc + (c >> 2);
             p0 = src[0];
