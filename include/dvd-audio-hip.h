@@ -1,0 +1,89 @@
+/* dvd-audio-hip.h -- tier C of the HIP decoder: the disc-level API (SURVEY.md 8(b) "outer
+ * boundary", rows f-1 and f-4), exported by libdvd_audio_hip.so.
+ *
+ * The 27 entry points below have the names, argument meaning, 1-based numbering, NULL-on-failure
+ * and ownership rules of the reference's public header (reference include/dvd-audio.h:59-201),
+ * so a program written against that header -- utils/dvda2wav.c for one -- links against this
+ * library unchanged.  What differs is the inside: opening a track reader reads the track's AOB
+ * sectors once, uploads them, and runs ONE batch on the GPU
+ *
+ *     sector walk + payload gather   (reference src/packet.c:61-188, src/dvd-audio.c:1151-1248)
+ *     major-sync search, end-of-track rule            (src/dvd-audio.c:1167-1194, 1238-1421)
+ *     MLP decode (tier A of dvda_mlp_hip.h)  /  PCM un-swizzle      (src/mlp.c, src/pcm.c:99-193)
+ *
+ * and dvda_read() then hands out slices of the decoded track.  There is no CPU decode path: a
+ * track reader cannot be opened without a HIP device.  CPPM-protected discs are not handled
+ * (`device` is accepted and ignored; reference src/aob.c:109-127).
+ */
+#ifndef DVD_AUDIO_HIP_H
+#define DVD_AUDIO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVDA_HIP_PTS_PER_SECOND 90000
+
+typedef struct DVDA_s DVDA;
+typedef struct DVDA_Titleset_s DVDA_Titleset;
+typedef struct DVDA_Title_s DVDA_Title;
+typedef struct DVDA_Track_s DVDA_Track;
+typedef struct DVDA_Track_Reader_s DVDA_Track_Reader;
+
+typedef enum { DVDA_PCM, DVDA_MLP } dvda_codec_t;
+
+/* ---- disc: AUDIO_TS.IFO (reference src/dvd-audio.c:323-360, 896-930) */
+DVDA *dvda_open(const char *audio_ts_path, const char *device);
+void dvda_close(DVDA *dvda);
+unsigned dvda_titleset_count(const DVDA *dvda);
+
+/* ---- titleset: ATS_XX_0.IFO (src/dvd-audio.c:362-424, 932-1014) */
+DVDA_Titleset *dvda_open_titleset(DVDA *dvda, unsigned titleset);
+void dvda_close_titleset(DVDA_Titleset *titleset);
+unsigned dvda_titleset_number(const DVDA_Titleset *titleset);
+unsigned dvda_title_count(const DVDA_Titleset *titleset);
+
+/* ---- title: track table and the sector range of every track (src/dvd-audio.c:426-515) */
+DVDA_Title *dvda_open_title(DVDA_Titleset *titleset, unsigned title);
+void dvda_close_title(DVDA_Title *title);
+unsigned dvda_title_number(const DVDA_Title *title);
+unsigned dvda_track_count(const DVDA_Title *title);
+unsigned dvda_title_pts_length(const DVDA_Title *title);
+
+/* ---- track (src/dvd-audio.c:517-584) */
+DVDA_Track *dvda_open_track(DVDA_Title *title, unsigned track);
+void dvda_close_track(DVDA_Track *track);
+unsigned dvda_track_number(const DVDA_Track *track);
+unsigned dvda_track_pts_index(const DVDA_Track *track);
+unsigned dvda_track_pts_length(const DVDA_Track *track);
+unsigned dvda_track_first_sector(const DVDA_Track *track);
+unsigned dvda_track_last_sector(const DVDA_Track *track);
+
+/* ---- track reader (src/dvd-audio.c:586-794): the whole track is decoded when it is opened */
+DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *track);
+void dvda_close_track_reader(DVDA_Track_Reader *reader);
+dvda_codec_t dvda_codec(const DVDA_Track_Reader *reader);
+unsigned dvda_bits_per_sample(const DVDA_Track_Reader *reader);
+unsigned dvda_sample_rate(const DVDA_Track_Reader *reader);
+unsigned dvda_channel_count(const DVDA_Track_Reader *reader);
+unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *reader);
+/* interleaved int samples in RIFF-WAVE channel order; returns the PCM frames delivered, fewer
+ * than asked only at the end of the track, 0 afterwards */
+unsigned dvda_read(DVDA_Track_Reader *reader, unsigned pcm_frames, int buffer[]);
+
+/* ---- additions of this library (not in the reference API) */
+/* HIP device used by track readers opened afterwards (default 0) */
+void dvda_hip_set_device(int device);
+/* status word of the decode behind a reader: DVDA_ST_* bits of dvda_mlp_hip.h (0 = clean) */
+unsigned dvda_hip_reader_status(const DVDA_Track_Reader *reader);
+/* PCM frames the reader holds in total */
+unsigned long long dvda_hip_reader_total_frames(const DVDA_Track_Reader *reader);
+/* The rest of the track as the WAV payload dvda2wav would write for it (interleaved,
+ * little-endian, write_signed semantics, packed on the GPU): returns the byte count and a
+ * pointer valid until the reader is closed; the reader is at its end afterwards. */
+unsigned long long dvda_hip_reader_wav_payload(DVDA_Track_Reader *reader, const unsigned char **payload);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

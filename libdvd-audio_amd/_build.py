@@ -1,6 +1,7 @@
 """In-tree build of the native pieces (hipcc / gcc, no network, no JIT cache).
 
     libdvda_mlp_hip.so   HIP kernels + C ABI (include/dvda_mlp_hip.h), gfx950
+    libdvd_audio_hip.so  disc-level API (include/dvd-audio-hip.h), plain C on top of the above
     libmlp_synth.so      synthetic MLP stream generator (tooling for tests/bench)
 
 The oracle (oracle/Makefile) is built by __graft_entry__.build(), not here: it is
@@ -13,6 +14,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.path.join(HERE, "libdvda_mlp_hip.so")
 SYNTH_SO = os.path.join(HERE, "synth", "libmlp_synth.so")
+DISC_SO = os.path.join(HERE, "libdvd_audio_hip.so")
+DISC_SRCS = [os.path.join(HERE, "csrc", "dvda_disc.c"),
+             os.path.join(os.path.dirname(HERE), "include", "dvd-audio-hip.h"),
+             os.path.join(os.path.dirname(HERE), "include", "dvda_mlp_hip.h")]
 
 HIP_SRCS = [os.path.join(HERE, "csrc", f) for f in
             ("mlp_hip.hip", "mlp_stream.c", "mlp_decode.h", "mlp_index.h", "mlp_tables.h")]
@@ -55,6 +60,16 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     return target
 
 
+def build_disc(force=False):
+    """tier C (dvd-audio.h mirror): links against libdvda_mlp_hip.so next to it."""
+    if not force and not _stale(DISC_SO, DISC_SRCS + [HIP_SO]):
+        return DISC_SO
+    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-o", DISC_SO, DISC_SRCS[0], "-L" + HERE, "-ldvda_mlp_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-lm", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return DISC_SO
+
+
 def build_synth(force=False):
     if not force and not _stale(SYNTH_SO, SYNTH_SRCS):
         return SYNTH_SO
@@ -64,4 +79,4 @@ def build_synth(force=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force)
+    return build_hip(force, verbose), build_disc(force), build_synth(force)

@@ -1,0 +1,860 @@
+/* dvda_disc.c -- tier C of the HIP decoder (include/dvd-audio-hip.h): the disc-level API,
+ * host side, plain C.  Built into libdvd_audio_hip.so on top of libdvda_mlp_hip.so.
+ *
+ * Mirrors what reference src/dvd-audio.c + src/aob.c + src/packet.c + src/audio_ts.c do
+ * (SURVEY.md 8(b) outer boundary, rows f-1 and f-4), with the per-packet decode loop replaced
+ * by one GPU batch per track:
+ *
+ *   IFO tables          parsed on the host, field for field (src/dvd-audio.c:896-1014)
+ *   track sector range  dvda_open_title's rules (src/dvd-audio.c:426-492)
+ *   AOB files           ATS_XX_1..9.AOB taken as one sector sequence (src/aob.c:86-190)
+ *   codec probe         first 0xBD packet at/after the track's first sector (src/dvd-audio.c:586-655)
+ *   MLP track           sectors -> GPU gather of the MLP payload (dvda_mlp_hip_demux_sectors);
+ *                       stream start = first major sync found byte by byte (locate_mlp_parameters,
+ *                       src/dvd-audio.c:1327-1365); stream end = the first major sync at or after
+ *                       the first payload byte of a sector beyond the track's last sector
+ *                       (decode_mlp_audio + mlp_data_to_major_sync, src/dvd-audio.c:1167-1194,
+ *                       1367-1421); then tier A index + decode of that one stream
+ *   PCM track           sectors -> GPU un-swizzle (dvda_pcm_hip_decode_sectors); whole packets are
+ *                       delivered until lround(PTS length * rate / 90000) frames are covered
+ *                       (open_pcm_track_reader / decode_pcm_audio, src/dvd-audio.c:958-1084)
+ *   dvda_read           interleave out of the decoded track (src/dvd-audio.c:757-794)
+ *
+ * Streams the reference would abort on (assert) make dvda_open_track_reader return NULL here.
+ */
+#include <ctype.h>
+#include <dirent.h>
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include "../../include/dvd-audio-hip.h"
+#include "../../include/dvda_mlp_hip.h"
+
+#define SECTOR 2048u
+#define MAX_AOBS 9
+#define CODEC_PCM 0xA0u
+#define CODEC_MLP 0xA1u
+
+static int g_device = 0;
+
+void dvda_hip_set_device(int device) { g_device = device; }
+
+/* ------------------------------------------------------------------ records */
+struct ifo_title {
+    unsigned track_count, index_count, pts_length;
+    struct {
+        unsigned index_number, pts_index, pts_length;
+    } track[256];
+    struct {
+        unsigned first, last;
+    } index[256];
+};
+
+struct DVDA_s {
+    char *dir;
+    unsigned titlesets;
+};
+
+struct DVDA_Titleset_s {
+    char *dir;
+    unsigned number, title_count;
+    struct ifo_title *title;
+};
+
+struct track_span {
+    unsigned pts_index, pts_length, first, last;
+};
+
+struct DVDA_Title_s {
+    char *dir;
+    unsigned titleset, number, track_count, pts_length;
+    struct track_span t[256];
+};
+
+struct DVDA_Track_s {
+    char *dir;
+    unsigned titleset, title, number;
+    struct track_span s;
+};
+
+struct DVDA_Track_Reader_s {
+    dvda_codec_t codec;
+    unsigned bps_code[2], rate_code[2], assignment;
+    unsigned channels, status;
+    uint64_t frames, served, stride;
+    int32_t *pcm;              /* host, planar [channel][stride], RIFF-WAVE order */
+    int32_t *d_pcm;            /* device copy, kept for the GPU WAV packer */
+    uint8_t *wav;              /* host payload produced by dvda_hip_reader_wav_payload */
+};
+
+/* ------------------------------------------------------------------ files */
+static int same_name(const char *a, const char *b)
+{
+    for (; *a && *b; a++, b++)
+        if (toupper((unsigned char)*a) != toupper((unsigned char)*b))
+            return 0;
+    return *a == *b;
+}
+
+/* case-insensitive lookup inside the AUDIO_TS directory (src/audio_ts.c:37-73) */
+static char *find_file(const char *dir, const char *name)
+{
+    DIR *d = opendir(dir);
+    struct dirent *e;
+    char *path = NULL;
+    if (!d)
+        return NULL;
+    while ((e = readdir(d)) != NULL) {
+        if (same_name(name, e->d_name)) {
+            const size_t n = strlen(dir) + 1 + strlen(e->d_name) + 1;
+            path = malloc(n);
+            if (path)
+                snprintf(path, n, "%s/%s", dir, e->d_name);
+            break;
+        }
+    }
+    closedir(d);
+    return path;
+}
+
+static unsigned be16(const uint8_t *p) { return ((unsigned)p[0] << 8) | p[1]; }
+static unsigned be32(const uint8_t *p)
+{
+    return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3];
+}
+
+static uint8_t *slurp(const char *path, size_t *size)
+{
+    FILE *f = fopen(path, "rb");
+    uint8_t *buf = NULL;
+    long n;
+    if (!f)
+        return NULL;
+    if (fseek(f, 0, SEEK_END) == 0 && (n = ftell(f)) >= 0 && fseek(f, 0, SEEK_SET) == 0) {
+        buf = malloc((size_t)n + 1);
+        if (buf && fread(buf, 1, (size_t)n, f) != (size_t)n) {
+            free(buf);
+            buf = NULL;
+        }
+        *size = (size_t)n;
+    }
+    fclose(f);
+    return buf;
+}
+
+/* the titleset's AOB files as one run of sectors (src/aob.c:86-127, 177-216) */
+struct aob_set {
+    FILE *f[MAX_AOBS];
+    unsigned sectors[MAX_AOBS];
+    unsigned n, total;
+};
+
+static void aob_close_all(struct aob_set *a)
+{
+    for (unsigned i = 0; i < a->n; i++)
+        fclose(a->f[i]);
+    a->n = 0;
+}
+
+static void aob_open_all(struct aob_set *a, const char *dir, unsigned titleset)
+{
+    memset(a, 0, sizeof(*a));
+    for (unsigned k = 1; k <= MAX_AOBS; k++) {
+        char name[16];
+        char *path;
+        struct stat st;
+        snprintf(name, sizeof(name), "ATS_%2.2u_%1.1u.AOB", titleset % 100, k);
+        path = find_file(dir, name);
+        if (!path)
+            break;
+        if (stat(path, &st) != 0 || (a->f[a->n] = fopen(path, "rb")) == NULL) {
+            free(path);
+            break;
+        }
+        free(path);
+        a->sectors[a->n] = (unsigned)(st.st_size / SECTOR);
+        a->total += a->sectors[a->n];
+        a->n++;
+    }
+}
+
+/* reads sectors [first, first + count) into dst; returns the number read (short at the end) */
+static unsigned aob_read(struct aob_set *a, unsigned first, unsigned count, uint8_t *dst)
+{
+    unsigned done = 0, base = 0;
+    for (unsigned i = 0; i < a->n && done < count; i++) {
+        const unsigned lo = base, hi = base + a->sectors[i];
+        base = hi;
+        if (first + done >= hi)
+            continue;
+        const unsigned at = first + done - lo;
+        unsigned take = a->sectors[i] - at;
+        if (take > count - done)
+            take = count - done;
+        if (fseek(a->f[i], (long)at * (long)SECTOR, SEEK_SET) != 0)
+            break;
+        const size_t got = fread(dst + (size_t)done * SECTOR, SECTOR, take, a->f[i]);
+        done += (unsigned)got;
+        if (got != take)
+            break;
+    }
+    return done;
+}
+
+/* ------------------------------------------------------------------ disc / titleset / title / track */
+DVDA *dvda_open(const char *audio_ts_path, const char *device)
+{
+    (void)device;               /* CPPM is not handled */
+    if (!audio_ts_path)
+        return NULL;
+    char *ifo = find_file(audio_ts_path, "AUDIO_TS.IFO");
+    if (!ifo)
+        return NULL;
+    size_t n = 0;
+    uint8_t *b = slurp(ifo, &n);
+    free(ifo);
+    /* "DVDAUDIO-AMG", title set count in byte 63; the reference parses 104 bytes (src/dvd-audio.c:908-913) */
+    unsigned count = 0;
+    if (b && n >= 104 && memcmp(b, "DVDAUDIO-AMG", 12) == 0)
+        count = b[63];
+    free(b);
+    if (!count)
+        return NULL;
+    DVDA *d = calloc(1, sizeof(*d));
+    if (!d)
+        return NULL;
+    d->dir = strdup(audio_ts_path);
+    d->titlesets = count;
+    return d;
+}
+
+void dvda_close(DVDA *d)
+{
+    if (d) {
+        free(d->dir);
+        free(d);
+    }
+}
+
+unsigned dvda_titleset_count(const DVDA *d) { return d->titlesets; }
+
+/* one title table of ATS_XX_0.IFO (src/dvd-audio.c:975-1014); returns 0 when it leaves the file */
+static int parse_title(const uint8_t *b, size_t n, size_t table, struct ifo_title *t)
+{
+    if (table + 16 > n)
+        return 0;
+    t->track_count = b[table + 2];
+    t->index_count = b[table + 3];
+    t->pts_length = be32(b + table + 4);
+    const unsigned ptr_off = be16(b + table + 12);
+    size_t p = table + 16;
+    for (unsigned i = 0; i < t->track_count; i++, p += 20) {
+        if (p + 20 > n)
+            return 0;
+        t->track[i].index_number = b[p + 4];
+        t->track[i].pts_index = be32(b + p + 6);
+        t->track[i].pts_length = be32(b + p + 10);
+    }
+    p = table + ptr_off;
+    for (unsigned i = 0; i < t->index_count; i++, p += 12) {
+        if (p + 12 > n)
+            return 0;
+        t->index[i].first = be32(b + p + 4);
+        t->index[i].last = be32(b + p + 8);
+    }
+    return 1;
+}
+
+DVDA_Titleset *dvda_open_titleset(DVDA *d, unsigned titleset)
+{
+    char name[16];
+    snprintf(name, sizeof(name), "ATS_%2.2u_0.IFO", titleset > 99 ? 99u : titleset);
+    char *path = find_file(d->dir, name);
+    if (!path)
+        return NULL;
+    size_t n = 0;
+    uint8_t *b = slurp(path, &n);
+    free(path);
+    if (!b)
+        return NULL;
+    DVDA_Titleset *ts = NULL;
+    if (n >= SECTOR + 8 && memcmp(b, "DVDAUDIO-ATS", 12) == 0) {
+        ts = calloc(1, sizeof(*ts));
+        ts->number = titleset;
+        ts->title_count = be16(b + SECTOR);
+        ts->title = calloc(ts->title_count ? ts->title_count : 1, sizeof(*ts->title));
+        int ok = ts->title != NULL;
+        for (unsigned i = 0; ok && i < ts->title_count; i++) {
+            const size_t e = SECTOR + 8 + (size_t)8 * i;       /* title number 8u, 24p, table offset 32u */
+            ok = e + 8 <= n && parse_title(b, n, SECTOR + (size_t)be32(b + e + 4), &ts->title[i]);
+        }
+        if (!ok) {
+            free(ts->title);
+            free(ts);
+            ts = NULL;
+        } else {
+            ts->dir = strdup(d->dir);
+        }
+    }
+    free(b);
+    return ts;
+}
+
+void dvda_close_titleset(DVDA_Titleset *ts)
+{
+    if (ts) {
+        free(ts->dir);
+        free(ts->title);
+        free(ts);
+    }
+}
+
+unsigned dvda_titleset_number(const DVDA_Titleset *ts) { return ts->number; }
+unsigned dvda_title_count(const DVDA_Titleset *ts) { return ts->title_count; }
+
+static const unsigned *index_of(const struct ifo_title *t, unsigned track, int want_last)
+{
+    static const unsigned zero = 0;
+    const unsigned k = t->track[track].index_number;
+    if (k == 0 || k > 256)
+        return &zero;
+    return want_last ? &t->index[k - 1].last : &t->index[k - 1].first;
+}
+
+DVDA_Title *dvda_open_title(DVDA_Titleset *ts, unsigned title)
+{
+    if (title == 0 || title > ts->title_count)
+        return NULL;
+    const struct ifo_title *it = &ts->title[title - 1];
+    DVDA_Title *t = calloc(1, sizeof(*t));
+    if (!t)
+        return NULL;
+    t->dir = strdup(ts->dir);
+    t->titleset = ts->number;
+    t->number = title;
+    t->track_count = it->track_count;
+    t->pts_length = it->pts_length;
+    for (unsigned i = 0; i < it->track_count; i++) {
+        t->t[i].pts_index = it->track[i].pts_index;
+        t->t[i].pts_length = it->track[i].pts_length;
+        t->t[i].first = *index_of(it, i, 0);
+        const unsigned own_last = *index_of(it, i, 1);
+        /* a track runs up to the sector before the next track (of this or the next title);
+         * only the very last one ends where its own index says (src/dvd-audio.c:452-488) */
+        if (i + 1 < it->track_count) {
+            t->t[i].last = *index_of(it, i + 1, 0) - 1;
+        } else if (title < ts->title_count && ts->title[title].track_count) {
+            const unsigned next_first = *index_of(&ts->title[title], 0, 0) - 1;
+            t->t[i].last = next_first > own_last ? next_first : own_last;
+        } else {
+            t->t[i].last = own_last;
+        }
+    }
+    return t;
+}
+
+void dvda_close_title(DVDA_Title *t)
+{
+    if (t) {
+        free(t->dir);
+        free(t);
+    }
+}
+
+unsigned dvda_title_number(const DVDA_Title *t) { return t->number; }
+unsigned dvda_track_count(const DVDA_Title *t) { return t->track_count; }
+unsigned dvda_title_pts_length(const DVDA_Title *t) { return t->pts_length; }
+
+DVDA_Track *dvda_open_track(DVDA_Title *t, unsigned track)
+{
+    if (track == 0 || track > t->track_count)
+        return NULL;
+    DVDA_Track *k = calloc(1, sizeof(*k));
+    if (!k)
+        return NULL;
+    k->dir = strdup(t->dir);
+    k->titleset = t->titleset;
+    k->title = t->number;
+    k->number = track;
+    k->s = t->t[track - 1];
+    return k;
+}
+
+void dvda_close_track(DVDA_Track *k)
+{
+    if (k) {
+        free(k->dir);
+        free(k);
+    }
+}
+
+unsigned dvda_track_number(const DVDA_Track *k) { return k->number; }
+unsigned dvda_track_pts_index(const DVDA_Track *k) { return k->s.pts_index; }
+unsigned dvda_track_pts_length(const DVDA_Track *k) { return k->s.pts_length; }
+unsigned dvda_track_first_sector(const DVDA_Track *k) { return k->s.first; }
+unsigned dvda_track_last_sector(const DVDA_Track *k) { return k->s.last; }
+
+/* ------------------------------------------------------------------ code tables (src/dvd-audio.c:1423-1496) */
+static unsigned bits_of(unsigned code) { return code == 0 ? 16 : code == 1 ? 20 : code == 2 ? 24 : 0; }
+
+static unsigned rate_of(unsigned code)
+{
+    switch (code) {
+    case 0: return 48000;
+    case 1: return 96000;
+    case 2: return 192000;
+    case 8: return 44100;
+    case 9: return 88200;
+    case 10: return 176400;
+    default: return 0;
+    }
+}
+
+static unsigned channels_of(unsigned assignment)
+{
+    static const uint8_t n[21] = {1, 2, 3, 4, 3, 4, 5, 3, 4, 5, 4, 5, 6, 4, 5, 4, 5, 6, 5, 5, 6};
+    return assignment < 21 ? n[assignment] : 0;
+}
+
+/* ------------------------------------------------------------------ codec probe */
+/* First 0xBD packet of a sector: returns 1 and its codec id, pad_2 size and the bytes behind the
+ * 4-byte audio header; 0 = no audio packet in this sector; -1 = malformed (src/packet.c:61-188,
+ * src/dvd-audio.c:1238-1248). */
+static int first_audio_packet(const uint8_t *p, unsigned *codec, unsigned *pad2, const uint8_t **body,
+                              unsigned *body_len)
+{
+    if (p[0] != 0 || p[1] != 0 || p[2] != 1 || p[3] != 0xBA)
+        return -1;
+    if ((p[4] >> 6) != 1 || !(p[4] & 4) || !(p[6] & 4) || !(p[8] & 4) || !(p[9] & 1) || (p[12] & 3) != 3)
+        return -1;
+    unsigned pos = 14 + (p[13] & 7);
+    while (pos + 6 <= SECTOR) {
+        const unsigned id = p[pos + 3], len = be16(p + pos + 4);
+        if (p[pos] != 0 || p[pos + 1] != 0 || p[pos + 2] != 1 || pos + 6 + len > SECTOR)
+            return -1;
+        if (id == 0xBD) {
+            const uint8_t *q = p + pos + 6;
+            if (len < 3 || len < 7u + q[2])
+                return -1;
+            const unsigned pad1 = q[2];
+            *codec = q[3 + pad1];
+            *pad2 = q[6 + pad1];
+            *body = q + 7 + pad1;
+            *body_len = len - 7 - pad1;
+            return 1;
+        }
+        pos += 6 + len;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ device helpers */
+static int dev_alloc(void **p, size_t bytes)
+{
+    *p = NULL;
+    return hipMalloc(p, bytes ? bytes : 16) == hipSuccess;
+}
+
+/* offset of the first major-sync pattern (bytes +4..+7 = F8 72 6F BB) at or after `from` whose
+ * 8 bytes lie inside [0, size), or -1 (find_major_sync, src/dvd-audio.c:1250-1285) */
+static int64_t find_sync(const uint8_t *b, uint64_t from, uint64_t size)
+{
+    for (uint64_t p = from; p + 8 <= size; p++)
+        if (b[p + 4] == 0xF8 && b[p + 5] == 0x72 && b[p + 6] == 0x6F && b[p + 7] == 0xBB)
+            return (int64_t)p;
+    return -1;
+}
+
+static void reader_free(DVDA_Track_Reader *r)
+{
+    if (!r)
+        return;
+    free(r->pcm);
+    free(r->wav);
+    if (r->d_pcm)
+        (void)hipFree(r->d_pcm);
+    free(r);
+}
+
+/* ------------------------------------------------------------------ MLP track */
+static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
+{
+    DVDA_Track_Reader *r = NULL;
+    uint8_t *h_sec = NULL, *h_mlp = NULL, *d_sec = NULL, *d_mlp = NULL, *d_stream = NULL;
+    uint32_t *d_work = NULL, *h_base = NULL;
+    uint64_t *d_meta = NULL;
+    int32_t *d_pcm = NULL;
+    dvda_mlp_hip_ctx *ctx = NULL;
+    const unsigned first = k->s.first;
+    const unsigned in_track = k->s.last >= first ? k->s.last - first + 1 : 1;
+    unsigned extra = 8;
+    uint64_t total = 0, begin = 0, end = 0;
+
+    for (;;) {
+        /* sectors of the track plus a few behind it: the stream runs on to the next major sync */
+        unsigned want = in_track + extra;
+        if (first + want > aobs->total || first + want < first)
+            want = aobs->total - first;
+        free(h_sec);
+        free(h_mlp);
+        free(h_base);
+        h_sec = h_mlp = NULL;
+        h_base = NULL;
+        (void)hipFree(d_sec);
+        (void)hipFree(d_mlp);
+        (void)hipFree(d_work);
+        d_sec = d_mlp = NULL;
+        d_work = NULL;
+        h_sec = malloc((size_t)want * SECTOR);
+        if (!h_sec)
+            goto fail;
+        const unsigned got = aob_read(aobs, first, want, h_sec);
+        if (got == 0)
+            goto fail;
+        const size_t cap = (size_t)got * SECTOR;
+        if (!dev_alloc((void **)&d_sec, cap) || !dev_alloc((void **)&d_mlp, cap + 64) ||
+            !dev_alloc((void **)&d_work, dvda_pcm_hip_workspace_words(got) * sizeof(uint32_t)))
+            goto fail;
+        if (hipMemcpy(d_sec, h_sec, cap, hipMemcpyHostToDevice) != hipSuccess)
+            goto fail;
+        if (dvda_mlp_hip_demux_sectors(d_sec, got, d_mlp, cap, d_work, NULL) != DVDA_HIP_OK)
+            goto fail;
+        uint32_t bad = 0;
+        if (dvda_pcm_hip_result(d_work, got, &total, &bad, NULL) != DVDA_HIP_OK)
+            goto fail;
+        /* workspace words [got, 2*got]: payload offset of every sector, then the total */
+        h_base = malloc(((size_t)got + 1) * sizeof(uint32_t));
+        h_mlp = malloc(total + 8);
+        if (!h_base || !h_mlp)
+            goto fail;
+        if (hipMemcpy(h_base, d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_mlp, d_mlp, total, hipMemcpyDeviceToHost) != hipSuccess)
+            goto fail;
+        const int64_t s0 = find_sync(h_mlp, 0, total);
+        if (s0 < 0) {
+            if (got < want || first + got >= aobs->total)
+                goto fail;                       /* no major sync anywhere: the reference asserts */
+            extra *= 4;
+            continue;
+        }
+        begin = (uint64_t)s0;
+        if (got <= in_track) {
+            end = total;                         /* the titleset ends with this track */
+            break;
+        }
+        const uint64_t boundary = h_base[in_track];
+        const int64_t s1 = find_sync(h_mlp, boundary > begin ? boundary : begin, total);
+        if (s1 >= 0) {
+            end = (uint64_t)s1;
+            break;
+        }
+        if (first + got >= aobs->total) {
+            /* packets behind the track but no further sync: the reference gives up 7 bytes
+             * short of the data it has (find_major_sync needs 8) */
+            end = total - boundary >= 8 ? total - 7 : boundary;
+            break;
+        }
+        extra *= 4;
+    }
+    if (end <= begin)
+        goto fail;
+
+    {
+        const uint64_t len = end - begin;
+        const uint64_t padded = (len + 15) & ~(uint64_t)15;
+        uint64_t meta[4] = {0, len, 0, 0};
+        dvda_mlp_stream_info info;
+        uint32_t segs = (uint32_t)(len / 2048 + 256), found = 0;
+        if (!dev_alloc((void **)&d_stream, padded + 64) || !dev_alloc((void **)&d_meta, sizeof(meta)))
+            goto fail;
+        if (hipMemset(d_stream, 0, padded + 64) != hipSuccess ||
+            hipMemcpy(d_stream, d_mlp + begin, len, hipMemcpyDeviceToDevice) != hipSuccess ||
+            hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
+            goto fail;
+        (void)hipFree(d_sec);
+        (void)hipFree(d_mlp);
+        d_sec = d_mlp = NULL;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if (dvda_mlp_hip_create(&ctx, g_device, 1, segs) != DVDA_HIP_OK)
+                goto fail;
+            if (dvda_mlp_hip_index(ctx, d_stream, padded, d_meta + 0, d_meta + 1, 1, NULL) != DVDA_HIP_OK)
+                goto fail;
+            const int rc = dvda_mlp_hip_segment_count(ctx, &found, NULL);
+            if (rc == DVDA_HIP_OK)
+                break;
+            if (rc != DVDA_HIP_ECAPACITY || attempt)
+                goto fail;
+            dvda_mlp_hip_destroy(ctx);
+            ctx = NULL;
+            segs = found + 16;
+        }
+        if (dvda_mlp_hip_stream_info(ctx, &info, 1, NULL) != DVDA_HIP_OK || info.channels == 0)
+            goto fail;
+        const unsigned rate = rate_of(info.group0_rate);
+        const uint64_t per_au = rate == 48000 || rate == 44100 ? 40 : rate == 96000 || rate == 88200 ? 80 : 160;
+        uint64_t stride = info.mlp_frames * per_au;
+        stride = (stride + 3) & ~(uint64_t)3;
+        if (stride == 0)
+            stride = 4;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            meta[3] = stride;
+            if (!dev_alloc((void **)&d_pcm, stride * info.channels * sizeof(int32_t)) ||
+                hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
+                goto fail;
+            if (dvda_mlp_hip_decode(ctx, d_pcm, d_meta + 2, d_meta + 3, NULL) != DVDA_HIP_OK ||
+                dvda_mlp_hip_stream_info(ctx, &info, 1, NULL) != DVDA_HIP_OK)
+                goto fail;
+            if (!(info.status & DVDA_ST_OVERFLOW))
+                break;
+            /* access units longer than the standard length: pcm_frames is the size needed */
+            if (attempt)
+                goto fail;
+            (void)hipFree(d_pcm);
+            d_pcm = NULL;
+            stride = (info.pcm_frames + 3) & ~(uint64_t)3;
+        }
+        if (info.status & ~(uint32_t)DVDA_ST_BENIGN)
+            goto fail;                       /* the reference assert()s on such a stream */
+        r = calloc(1, sizeof(*r));
+        if (!r)
+            goto fail;
+        r->codec = DVDA_MLP;
+        r->bps_code[0] = info.group0_bps;
+        r->bps_code[1] = info.group1_bps;
+        r->rate_code[0] = info.group0_rate;
+        r->rate_code[1] = info.group1_rate;
+        r->assignment = info.assignment;
+        r->channels = channels_of(info.assignment);
+        r->status = info.status;
+        r->frames = info.pcm_frames;
+        r->stride = stride;
+        if (r->channels == 0 || r->channels != info.channels)
+            goto fail;
+        r->pcm = malloc(stride * r->channels * sizeof(int32_t));
+        if (!r->pcm || hipMemcpy(r->pcm, d_pcm, stride * r->channels * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+            goto fail;
+        r->d_pcm = d_pcm;
+        d_pcm = NULL;
+    }
+    goto done;
+fail:
+    reader_free(r);
+    r = NULL;
+done:
+    if (ctx)
+        dvda_mlp_hip_destroy(ctx);
+    free(h_sec);
+    free(h_mlp);
+    free(h_base);
+    (void)hipFree(d_sec);
+    (void)hipFree(d_mlp);
+    (void)hipFree(d_work);
+    (void)hipFree(d_stream);
+    (void)hipFree(d_meta);
+    (void)hipFree(d_pcm);
+    return r;
+}
+
+/* ------------------------------------------------------------------ PCM track */
+static DVDA_Track_Reader *open_pcm(struct aob_set *aobs, const DVDA_Track *k, const uint8_t *params)
+{
+    /* 9-byte parameter block: first_audio_frame 16u, 8p, bps 4u 4u, rate 4u 4u, 8p, assignment 8u,
+     * 8p, crc 8u (src/pcm.c:80-96) */
+    DVDA_Track_Reader *r = calloc(1, sizeof(*r));
+    uint8_t *h_sec = NULL, *d_sec = NULL;
+    uint32_t *d_work = NULL, *h_base = NULL;
+    int32_t *d_pcm = NULL;
+    if (!r)
+        return NULL;
+    r->codec = DVDA_PCM;
+    r->bps_code[0] = params[3] >> 4;
+    r->bps_code[1] = params[3] & 15;
+    r->rate_code[0] = params[4] >> 4;
+    r->rate_code[1] = params[4] & 15;
+    r->assignment = params[6];
+    r->channels = channels_of(r->assignment);
+    const unsigned bits = bits_of(r->bps_code[0]), rate = rate_of(r->rate_code[0]);
+    if (!r->channels || (bits != 16 && bits != 24) || !rate)
+        goto fail;
+    const uint64_t want_frames = (uint64_t)lround((double)k->s.pts_length * (double)rate / DVDA_HIP_PTS_PER_SECOND);
+    const unsigned first = k->s.first;
+    unsigned count = k->s.last >= first ? k->s.last - first + 1 : 1;
+    for (;;) {
+        if (first + count > aobs->total || first + count < first)
+            count = aobs->total - first;
+        free(h_sec);
+        free(h_base);
+        (void)hipFree(d_sec);
+        (void)hipFree(d_work);
+        (void)hipFree(d_pcm);
+        h_sec = NULL;
+        h_base = NULL;
+        d_sec = NULL;
+        d_work = NULL;
+        d_pcm = NULL;
+        h_sec = malloc((size_t)count * SECTOR);
+        if (!h_sec)
+            goto fail;
+        const unsigned got = aob_read(aobs, first, count, h_sec);
+        if (!got)
+            goto fail;
+        /* a sector holds at most 2013 payload bytes: upper bound of the PCM frames */
+        uint64_t stride = (uint64_t)got * (2013 / (r->channels * (bits / 8) * 2)) * 2;
+        stride = (stride + 3) & ~(uint64_t)3;
+        if (!dev_alloc((void **)&d_sec, (size_t)got * SECTOR) ||
+            !dev_alloc((void **)&d_work, dvda_pcm_hip_workspace_words(got) * sizeof(uint32_t)) ||
+            !dev_alloc((void **)&d_pcm, stride * r->channels * sizeof(int32_t)))
+            goto fail;
+        if (hipMemcpy(d_sec, h_sec, (size_t)got * SECTOR, hipMemcpyHostToDevice) != hipSuccess)
+            goto fail;
+        if (dvda_pcm_hip_decode_sectors(d_sec, got, bits, r->channels, d_pcm, stride, d_work, NULL) != DVDA_HIP_OK)
+            goto fail;
+        uint64_t total = 0;
+        uint32_t bad = 0;
+        if (dvda_pcm_hip_result(d_work, got, &total, &bad, NULL) != DVDA_HIP_OK)
+            goto fail;
+        h_base = malloc(((size_t)got + 1) * sizeof(uint32_t));
+        if (!h_base ||
+            hipMemcpy(h_base, d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+            goto fail;
+        /* whole packets are delivered until the track's length is covered */
+        uint64_t deliver = total;
+        int covered = 0;
+        for (unsigned s = 0; s < got; s++) {
+            if (h_base[s + 1] >= want_frames) {
+                deliver = h_base[s + 1];
+                covered = 1;
+                break;
+            }
+        }
+        if (!covered && got == count && first + got < aobs->total) {
+            count *= 2;                          /* the track spills over its sector range */
+            continue;
+        }
+        if (want_frames == 0)
+            deliver = h_base[1] < total ? h_base[1] : total;   /* the opening packet is decoded regardless */
+        r->frames = deliver;
+        r->stride = stride;
+        r->pcm = malloc(stride * r->channels * sizeof(int32_t));
+        if (!r->pcm || hipMemcpy(r->pcm, d_pcm, stride * r->channels * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+            goto fail;
+        r->d_pcm = d_pcm;
+        d_pcm = NULL;
+        break;
+    }
+    goto done;
+fail:
+    reader_free(r);
+    r = NULL;
+done:
+    free(h_sec);
+    free(h_base);
+    (void)hipFree(d_sec);
+    (void)hipFree(d_work);
+    (void)hipFree(d_pcm);
+    return r;
+}
+
+/* ------------------------------------------------------------------ track reader */
+DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *k)
+{
+    struct aob_set aobs;
+    DVDA_Track_Reader *r = NULL;
+    uint8_t sec[SECTOR];
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= g_device) {
+        fprintf(stderr, "libdvd_audio_hip: no HIP device %d (the decode path is GPU-only)\n", g_device);
+        return NULL;
+    }
+    if (hipSetDevice(g_device) != hipSuccess)
+        return NULL;
+    aob_open_all(&aobs, k->dir, k->titleset);
+    if (aobs.n == 0 || k->s.first >= aobs.total)
+        goto out;
+    /* the first audio packet at or after the track's first sector names the codec */
+    for (unsigned s = k->s.first; s < aobs.total; s++) {
+        unsigned codec = 0, pad2 = 0, body_len = 0;
+        const uint8_t *body = NULL;
+        if (aob_read(&aobs, s, 1, sec) != 1)
+            break;
+        const int rc = first_audio_packet(sec, &codec, &pad2, &body, &body_len);
+        if (rc < 0)
+            break;
+        if (rc == 0)
+            continue;
+        if (codec == CODEC_MLP) {
+            r = open_mlp(&aobs, k);
+        } else if (codec == CODEC_PCM && body_len >= 9 && pad2 >= 9) {
+            r = open_pcm(&aobs, k, body);
+        }
+        break;
+    }
+out:
+    aob_close_all(&aobs);
+    return r;
+}
+
+void dvda_close_track_reader(DVDA_Track_Reader *r) { reader_free(r); }
+
+dvda_codec_t dvda_codec(const DVDA_Track_Reader *r) { return r->codec; }
+unsigned dvda_bits_per_sample(const DVDA_Track_Reader *r) { return bits_of(r->bps_code[0]); }
+unsigned dvda_sample_rate(const DVDA_Track_Reader *r) { return rate_of(r->rate_code[0]); }
+unsigned dvda_channel_count(const DVDA_Track_Reader *r) { return channels_of(r->assignment); }
+unsigned dvda_hip_reader_status(const DVDA_Track_Reader *r) { return r->status; }
+unsigned long long dvda_hip_reader_total_frames(const DVDA_Track_Reader *r) { return r->frames; }
+
+unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *r)
+{
+    /* speaker bits per channel assignment (src/dvd-audio.c:693-755) */
+    enum { FL = 0x1, FR = 0x2, FC = 0x4, LF = 0x8, BL = 0x10, BR = 0x20, BC = 0x100 };
+    static const unsigned mask[21] = {
+        FC, FL | FR, FL | FR | BC, FL | FR | BL | BR, FL | FR | LF, FL | FR | LF | BC, FL | FR | LF | BL | BR,
+        FL | FR | FC, FL | FR | FC | BC, FL | FR | FC | BL | BR, FL | FR | FC | LF, FL | FR | FC | LF | BC,
+        FL | FR | FC | LF | BL | BR, FL | FR | FC | BC, FL | FR | FC | BL | BR, FL | FR | FC | LF,
+        FL | FR | FC | LF | BC, FL | FR | FC | LF | BL | BR, FL | FR | BL | BR | LF, FL | FR | BL | BR | FC,
+        FL | FR | BL | BR | FC | LF};
+    return r->assignment < 21 ? mask[r->assignment] : 0;
+}
+
+unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
+{
+    const uint64_t left = r->frames - r->served;
+    const unsigned n = left < pcm_frames ? (unsigned)left : pcm_frames;
+    for (unsigned c = 0; c < r->channels; c++) {
+        const int32_t *src = r->pcm + (size_t)c * r->stride + r->served;
+        for (unsigned i = 0; i < n; i++)
+            buffer[(size_t)i * r->channels + c] = src[i];
+    }
+    r->served += n;
+    return n;
+}
+
+unsigned long long dvda_hip_reader_wav_payload(DVDA_Track_Reader *r, const unsigned char **payload)
+{
+    const unsigned bits = bits_of(r->bps_code[0]);
+    const uint64_t left = r->frames - r->served;
+    const uint64_t bytes = left * r->channels * (bits / 8);
+    uint8_t *d_out = NULL;
+    *payload = NULL;
+    if ((bits != 16 && bits != 24) || left == 0)
+        return 0;
+    free(r->wav);
+    r->wav = malloc(bytes);
+    if (!r->wav || !dev_alloc((void **)&d_out, bytes))
+        return 0;
+    /* planes start at r->served inside each channel: pass the shifted base, same stride */
+    if (dvda_mlp_hip_pack_wav(r->d_pcm + r->served, r->stride, r->channels, left, bits, d_out, NULL) != DVDA_HIP_OK ||
+        hipMemcpy(r->wav, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipFree(d_out);
+        return 0;
+    }
+    (void)hipFree(d_out);
+    r->served = r->frames;
+    *payload = r->wav;
+    return bytes;
+}

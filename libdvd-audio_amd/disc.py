@@ -137,41 +137,58 @@ def pcm_track_sectors(samples, bps_code, rate_code, assignment):
 
 
 def write_disc(root, tracks):
-    """tracks: list of dicts {"sectors": [bytes...], "pcm_frames": n, "rate_code": r}.
+    """tracks: list of dicts {"sectors": [bytes...], "pcm_frames": n, "rate_code": r}: one title.
     Returns the AUDIO_TS path."""
+    return write_disc_titles(root, [tracks])
+
+
+def split_tracks(sectors, cuts, pcm_frames, rate_code):
+    """One continuous run of sectors cut into consecutive tracks at the sector indices `cuts`
+    (tracks of a real title share one MLP stream: a track's last frames usually sit in the first
+    sector of the next one).  pcm_frames: per-track PCM frame counts (PTS lengths; only raw-PCM
+    tracks use them)."""
+    edges = [0] + list(cuts) + [len(sectors)]
+    return [{"sectors": sectors[a:b], "pcm_frames": f, "rate_code": rate_code}
+            for a, b, f in zip(edges[:-1], edges[1:], pcm_frames)]
+
+
+def write_disc_titles(root, titles, titlesets=1, titleset=1):
+    """titles: list of titles, each a list of track dicts (see write_disc); all of them go into
+    title set `titleset` (ATS_XX_0.IFO + ATS_XX_1.AOB) in order.  Returns the AUDIO_TS path."""
     ats = os.path.join(root, "AUDIO_TS")
     os.makedirs(ats, exist_ok=True)
     amg = bytearray(SECTOR)
     amg[0:12] = b"DVDAUDIO-AMG"
-    amg[63] = 1
+    amg[63] = titlesets
     open(os.path.join(ats, "AUDIO_TS.IFO"), "wb").write(amg)
 
-    n = len(tracks)
-    first = []
-    pos = 0
-    for t in tracks:
-        first.append(pos)
-        pos += len(t["sectors"])
-    ifo = bytearray(2 * SECTOR)
+    ifo = bytearray(4 * SECTOR)
     ifo[0:12] = b"DVDAUDIO-ATS"
     base = SECTOR
-    struct.pack_into(">HHI", ifo, base, 1, 0, 0)                 # title_count
+    struct.pack_into(">HHI", ifo, base, len(titles), 0, 0)       # title_count
     table_off = 0x100
-    struct.pack_into(">BBHI", ifo, base + 8, 1, 0, 0, table_off)  # title 1 -> table
-    t0 = base + table_off
-    pts = [int(round(t["pcm_frames"] * 90000.0 / RATES[t["rate_code"]])) for t in tracks]
-    sector_ptr_off = 16 + 20 * n
-    struct.pack_into(">HBBIIHH", ifo, t0, 0, n, n, sum(pts), 0, sector_ptr_off, 0)
-    acc = 0
-    for i in range(n):
-        struct.pack_into(">IBBII", ifo, t0 + 16 + 20 * i, 0, i + 1, 0, acc, pts[i])
-        acc += pts[i]
-    for i in range(n):
-        last = first[i] + len(tracks[i]["sectors"]) - 1
-        struct.pack_into(">III", ifo, t0 + sector_ptr_off + 12 * i, i + 1, first[i], last)
-    open(os.path.join(ats, "ATS_01_0.IFO"), "wb").write(ifo)
-    with open(os.path.join(ats, "ATS_01_1.AOB"), "wb") as f:
-        for t in tracks:
-            for s in t["sectors"]:
-                f.write(s)
+    pos = 0
+    for ti, tracks in enumerate(titles):
+        n = len(tracks)
+        struct.pack_into(">BBHI", ifo, base + 8 + 8 * ti, ti + 1, 0, 0, table_off)
+        t0 = base + table_off
+        pts = [int(round(t["pcm_frames"] * 90000.0 / RATES[t["rate_code"]])) for t in tracks]
+        sector_ptr_off = 16 + 20 * n
+        struct.pack_into(">HBBIIHH", ifo, t0, 0, n, n, sum(pts), 0, sector_ptr_off, 0)
+        acc = 0
+        for i in range(n):
+            struct.pack_into(">IBBII", ifo, t0 + 16 + 20 * i, 0, i + 1, 0, acc, pts[i])
+            acc += pts[i]
+        for i in range(n):
+            first = pos
+            pos += len(tracks[i]["sectors"])
+            struct.pack_into(">III", ifo, t0 + sector_ptr_off + 12 * i, i + 1, first, pos - 1)
+        table_off += (sector_ptr_off + 12 * n + 15) & ~15
+    assert base + table_off <= len(ifo)
+    open(os.path.join(ats, "ATS_%02d_0.IFO" % titleset), "wb").write(ifo)
+    with open(os.path.join(ats, "ATS_%02d_1.AOB" % titleset), "wb") as f:
+        for tracks in titles:
+            for t in tracks:
+                for sec in t["sectors"]:
+                    f.write(sec)
     return ats

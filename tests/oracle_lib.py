@@ -46,6 +46,17 @@ class Oracle:
             raise RuntimeError("oracle output capacity too small")
         return out[:, :r].copy(), int(r), int(st.value)
 
+    def wav_pack(self, planar, bits):
+        """planar int32 [channels, frames] -> the WAV payload bytes dvda2wav writes (oracle/pcm_oracle.c)"""
+        planar = np.ascontiguousarray(planar, np.int32)
+        ch, frames = planar.shape
+        self.lib.wav_oracle_pack.restype = ctypes.c_long
+        self.lib.wav_oracle_pack.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_size_t,
+                                             ctypes.c_uint, ctypes.c_void_p]
+        out = np.zeros(ch * frames * 3 + 8, np.uint8)
+        n = self.lib.wav_oracle_pack(planar.ctypes.data, frames, ch, frames, bits, out.ctypes.data)
+        return out[:n].tobytes()
+
 
 class Reference:
     """The real reference decoder; exists only where oracle/_ref has been built."""

@@ -1,0 +1,115 @@
+"""Disc-level API (include/dvd-audio-hip.h, libdvd_audio_hip.so): SURVEY 8(b) outer boundary,
+rows f-1 (demux + end-of-track rule) and f-4 (IFO walk, several title sets).
+
+CPU part: the library loads without a GPU, exports the reference's 27 entry points, walks the IFO
+tables like the reference (track sector ranges per src/dvd-audio.c:426-492) and refuses to open a
+track reader without a device.  GPU part: every track read through dvda_read() / the GPU WAV
+packer against the oracle."""
+import ctypes
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _titles(pkg, seeds=(3, 4)):
+    syn, disc = pkg.synth, pkg.disc
+    titles, streams = [], []
+    b, f = syn.stream(syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=96), seeds[0])
+    secs = disc.mlp_track_sectors(b)
+    titles.append(disc.split_tracks(secs, [len(secs) // 3, 2 * len(secs) // 3 + 1], [f // 3, f // 3, f - 2 * (f // 3)], 1))
+    streams.append((b, f, 12))
+    b, f = syn.stream(syn.make_cfg(assignment=1, rate_code=0, n_substreams=1, n_aus=80), seeds[1])
+    secs = disc.mlp_track_sectors(b)
+    titles.append(disc.split_tracks(secs, [len(secs) // 2], [f // 2, f - f // 2], 0))
+    streams.append((b, f, 1))
+    return titles, streams
+
+
+def test_header_and_library_export_the_reference_api(pkg):
+    text = open(os.path.join(ROOT, "include", "dvd-audio-hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(dvda_\w+)\s*\(", text)))
+    assert len([n for n in declared if not n.startswith("dvda_hip_")]) == 27
+    assert set(declared) == set(pkg.discdec.EXPORTS)
+    lib = pkg.discdec.lib()
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+
+
+def test_ifo_walk_and_track_sector_ranges(pkg):
+    disc = pkg.disc
+    with tempfile.TemporaryDirectory() as tmp:
+        titles, _ = _titles(pkg)
+        ats = disc.write_disc_titles(tmp, titles)
+        lay = pkg.discdec.layout(ats)
+        assert [(t, k) for t, k, *_ in lay] == [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2)]
+        pos = 0
+        for (ti, ki, pts_i, pts_l, first, last), trk in zip(lay, [t for tt in titles for t in tt]):
+            n = len(trk["sectors"])
+            assert (first, last) == (pos, pos + n - 1)          # contiguous tracks: last = next first - 1
+            assert pts_l == int(round(trk["pcm_frames"] * 90000.0 / disc.RATES[trk["rate_code"]]))
+            pos += n
+        # case-insensitive file lookup (src/audio_ts.c:37-73)
+        os.rename(os.path.join(ats, "ATS_01_0.IFO"), os.path.join(ats, "ats_01_0.ifo"))
+        assert len(pkg.discdec.layout(ats)) == 5
+        # not a disc
+        with pytest.raises(IOError):
+            pkg.discdec.layout(tmp)
+
+
+def test_no_cpu_fallback_for_track_readers(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with tempfile.TemporaryDirectory() as tmp:
+        titles, _ = _titles(pkg)
+        ats = pkg.disc.write_disc_titles(tmp, titles)
+        with pytest.raises(RuntimeError):
+            pkg.discdec.read_track(ats, 1, 1, 1)
+
+
+@pytest.mark.gpu
+def test_tracks_of_a_title_partition_the_stream(pkg, oracle):
+    """The tracks of a title are cut out of ONE MLP stream at sector boundaries: each track runs from
+    its first major sync to the first major sync behind its last sector, so together they give back
+    the whole stream's PCM, access unit for access unit -- also in title set 2."""
+    syn, disc = pkg.synth, pkg.disc
+    for titleset in (1, 2):
+        with tempfile.TemporaryDirectory() as tmp:
+            titles, streams = _titles(pkg, seeds=(5 + titleset, 9 + titleset))
+            ats = disc.write_disc_titles(tmp, titles, titlesets=2, titleset=titleset)
+            for ti, (tracks, (b, f, asg)) in enumerate(zip(titles, streams), 1):
+                nch = syn.channels(asg)
+                want, r, st = oracle.decode(b, nch, f)
+                assert st == 0 and r == f
+                got = []
+                for ki in range(1, len(tracks) + 1):
+                    info = pkg.discdec.read_track(ats, titleset, ti, ki, chunk=1000)
+                    assert info["codec"] == "MLP" and info["channels"] == nch and info["bits"] == 24
+                    assert info["status"] & ~pkg.hipdec.ST_BENIGN == 0
+                    assert info["frames"] == len(info["pcm"]) and info["frames"] % 40 == 0
+                    got.append(info["pcm"])
+                assert all(len(g) for g in got)
+                assert np.array_equal(np.concatenate(got).T, want)
+
+
+@pytest.mark.gpu
+def test_pcm_tracks_and_gpu_wav_payload(pkg, oracle):
+    disc = pkg.disc
+    rng = np.random.RandomState(21)
+    pcm = rng.randint(-(1 << 23), 1 << 23, size=(2004, 6))
+    with tempfile.TemporaryDirectory() as tmp:
+        secs = disc.pcm_track_sectors(pcm, 2, 1, 12)
+        per = (2048 - 14 - 6 - 7 - 9) // 36 * 2
+        ats = disc.write_disc_titles(tmp, [disc.split_tracks(secs, [4], [4 * per, len(pcm) - 4 * per], 1)])
+        a = pkg.discdec.read_track(ats, 1, 1, 1)
+        b = pkg.discdec.read_track(ats, 1, 1, 2)
+        assert a["codec"] == "PCM" and a["bits"] == 24 and a["rate"] == 96000 and a["mask"] == 0x3F
+        assert np.array_equal(np.concatenate([a["pcm"], b["pcm"]]), pcm)
+        w = pkg.discdec.read_track(ats, 1, 1, 1, wav=True)
+        assert w["payload"] == oracle.wav_pack(a["pcm"].T, 24)

@@ -94,3 +94,58 @@ def test_dvda2wav_links_unchanged_and_matches(pkg, oracle):
         for a, b, pcm in zip(ref, hip, want):
             assert open(a, "rb").read() == open(b, "rb").read(), os.path.basename(a)
             assert np.array_equal(_wav_pcm(b, pcm.shape[0], 24), pcm)
+
+
+NATIVE_TOOL = os.path.join(ROOT, "oracle", "_ref", "dvda2wav_native")
+
+
+def _mixed_disc(pkg, tmp):
+    """Title 1: ONE 6-ch MLP stream cut into three tracks at sector boundaries (a track's last
+    frames sit in the next track's first sector: the end-of-track rule); title 2: a 2-substream
+    stream in two tracks; title 3: 16-bit stereo PCM in two tracks; title 4: 24-bit 6-ch PCM."""
+    syn, disc = pkg.synth, pkg.disc
+    titles = []
+    b, f = syn.stream(syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=96), 3)
+    secs = disc.mlp_track_sectors(b)
+    titles.append(disc.split_tracks(secs, [len(secs) // 3, 2 * len(secs) // 3 + 1], [f // 3, f // 3, f - 2 * (f // 3)], 1))
+    b, f = syn.stream(syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=64), 4)
+    secs = disc.mlp_track_sectors(b)
+    titles.append(disc.split_tracks(secs, [len(secs) // 2], [f // 2, f - f // 2], 1))
+    rng = np.random.RandomState(11)
+    pcm = rng.randint(-32768, 32768, size=(3000, 2))
+    secs = disc.pcm_track_sectors(pcm, 0, 0, 1)
+    per = 2008 // 4
+    titles.append(disc.split_tracks(secs, [3], [3 * per, len(pcm) - 3 * per], 0))
+    pcm6 = rng.randint(-(1 << 23), 1 << 23, size=(1000, 6))
+    titles.append(disc.split_tracks(disc.pcm_track_sectors(pcm6, 2, 1, 12), [], [len(pcm6)], 1))
+    return disc.write_disc_titles(tmp, titles)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(REF_TOOL) and os.path.exists(NATIVE_TOOL)),
+                    reason="reference tools not built (dev container only)")
+def test_disc_library_replaces_libdvd_audio_under_reference_dvda2wav(pkg):
+    """SURVEY 8(b) outer boundary, rows f-1/f-4: the reference's utils/dvda2wav.c linked against
+    libdvd_audio_hip.so (IFO walk, sector demux, end-of-track rule and decode all ours, on the
+    GPU) writes the same files as the all-reference build."""
+    with tempfile.TemporaryDirectory() as tmp:
+        ats = _mixed_disc(pkg, tmp)
+        ref = _run(REF_TOOL, ats, os.path.join(tmp, "ref"))
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "libdvd-audio_amd") + ":/opt/rocm/lib:" +
+                   os.environ.get("LD_LIBRARY_PATH", ""))
+        out = os.path.join(tmp, "native")
+        os.makedirs(out)
+        r = subprocess.run([NATIVE_TOOL, "-A", ats, "-d", out], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+        got = sorted(os.path.join(out, f) for f in os.listdir(out))
+        assert [os.path.basename(p) for p in got] == [os.path.basename(p) for p in ref]
+        assert len(ref) == 8
+        for a, b in zip(ref, got):
+            assert open(a, "rb").read() == open(b, "rb").read(), os.path.basename(a)
+        # single title / single track selection takes the same path
+        one = os.path.join(tmp, "one")
+        os.makedirs(one)
+        r = subprocess.run([NATIVE_TOOL, "-A", ats, "-T", "1", "-t", "2", "-d", one], capture_output=True,
+                           text=True, timeout=900, env=env)
+        assert r.returncode == 0 and os.listdir(one) == ["track-01-02.wav"]
+        assert open(os.path.join(one, "track-01-02.wav"), "rb").read() == open(ref[1], "rb").read()
