@@ -1104,7 +1104,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS) &&
 #endif
                         (!rd.crc_rem || (int32_t)(rd.fillpos + CHUNK_DWORDS - RING_DWORDS - rd.crc_pos) <= 0);
-        uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+        // deliberately not initialised: only read under the same `pf`.  (Zero-filling them made the
+        // compiler wait for every outstanding memory operation -- the previous row's PCM stores
+        // included -- before it could overwrite the registers.)
+        uint4 p0, p1, p2, p3;
+        bool flush = false;               // this row completes a staged group of OUT_ROWS frames
+        uint64_t flush_row = 0;
 #if defined(DVDA_EXP_ALWAYSLOAD)
         if (pf || active) {      // diagnostic: every lane issues the four loads every row
 #else
@@ -1263,26 +1268,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     } else if (row < row_limit) {
                         rows_written++;
                         if (ph == OUT_ROWS - 1) {
-#pragma unroll
-                            for (int c = 0; c < 6; c++) {
-                                if ((uint32_t)c < nch_out) {
-                                    const uint32_t wc = nib(wavepk, c);
-                                    int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + (row - (OUT_ROWS - 1));
-                                    int32_t o[OUT_ROWS];
-#pragma unroll
-                                    for (int i = 0; i < OUT_ROWS; i++)
-                                        o[i] = T[c][i][GENERAL ? 0 : lane];
-                                    if (vec_ok) {
-#pragma unroll
-                                        for (int i = 0; i < OUT_ROWS; i += 4)
-                                            DVDA_STORE_V4(dst + i, o[i], o[i + 1], o[i + 2], o[i + 3]);
-                                    } else {
-#pragma unroll
-                                        for (int i = 0; i < OUT_ROWS; i++)
-                                            dst[i] = o[i];
-                                    }
-                                }
-                            }
+                            flush = true;          // stored after the ring commit below
+                            flush_row = row - (OUT_ROWS - 1);
                         }
                     }
                 }
@@ -1351,6 +1338,32 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         if (pf) {
             ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3);
             rd.filled();
+        }
+        // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
+        //      older memory operation, so stores issued before it would be waited for as well; issued
+        //      here they have a whole row to drain before the next wait
+        if (!GENERAL && flush) {
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                if ((uint32_t)c < nch_out) {
+                    const uint32_t wc = nib(wavepk, c);
+                    int32_t *dst = a.pcm + out_base + (uint64_t)wc * out_stride + flush_row;
+                    int32_t o[OUT_ROWS];
+#pragma unroll
+                    for (int i = 0; i < OUT_ROWS; i++)
+                        o[i] = T[c][i][GENERAL ? 0 : lane];
+                    if (vec_ok) {
+#pragma unroll
+                        for (int i = 0; i < OUT_ROWS; i += 4)
+                            DVDA_STORE_V4(dst + i, o[i], o[i + 1], o[i + 2], o[i + 3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < OUT_ROWS; i++)
+                            dst[i] = o[i];
+                    }
+                }
+            }
         }
         DVDA_STAMP(4);
     }
