@@ -57,6 +57,25 @@ __device__ __forceinline__ bool sync_frame_at(const uint8_t *b, uint64_t p, uint
     return count == 1 || count == 2;
 }
 
+// The first 8 bytes of the frame at even offset p, byte k in bits 8k..8k+7 (four aligned 16-bit loads
+// that leave together), and the major-sync test of sync_frame_at() on such a preloaded header.
+__device__ __forceinline__ uint64_t ld_hdr8(const uint8_t *b, uint64_t p)
+{
+    const uint16_t *h = reinterpret_cast<const uint16_t *>(b + p);
+    return (uint64_t)h[0] | ((uint64_t)h[1] << 16) | ((uint64_t)h[2] << 32) | ((uint64_t)h[3] << 48);
+}
+
+__device__ __forceinline__ bool sync_frame_hdr(const uint8_t *b, uint64_t p, uint64_t limit, uint64_t hdr)
+{
+    if (p + 32 > limit)
+        return false;
+    const uint32_t size = 2u * ((((uint32_t)hdr & 0x0Fu) << 8) | (((uint32_t)hdr >> 8) & 0xFFu));
+    if (size < 32 || (uint32_t)(hdr >> 32) != 0xBB6F72F8u)
+        return false;
+    const uint32_t count = ld_u8(b, p + 20) >> 4;
+    return count == 1 || count == 2;
+}
+
 // Pass 1: one mask byte per 16-byte chunk (bit j = candidate at chunk*16 + 2j),
 // plus the number of candidates per 64 KiB tile.
 __global__ __launch_bounds__(IDX_THREADS) void k_sync_mask(const uint8_t *__restrict__ bytes,
@@ -193,26 +212,43 @@ __global__ __launch_bounds__(IDX_THREADS) void k_sync_scatter(const uint8_t *__r
                                                               uint64_t *__restrict__ cand_off,
                                                               uint32_t max_cand)
 {
-    __shared__ uint32_t s_scan[IDX_THREADS];
+    __shared__ uint32_t s_wave[IDX_THREADS / 64];
     const uint64_t n_chunks = (total_bytes + 15) >> 4;
     const uint64_t first = (uint64_t)blockIdx.x * IDX_TILE_CHUNKS +
                            (uint64_t)threadIdx.x * IDX_CHUNKS_PER_THREAD;
+    static_assert(IDX_CHUNKS_PER_THREAD == 16, "one 16-byte load of mask bytes per thread");
     uint8_t m[IDX_CHUNKS_PER_THREAD];
     uint32_t cnt = 0;
+    if (first + IDX_CHUNKS_PER_THREAD <= n_chunks) {
+        // the mask array is 16-byte aligned and `first` a multiple of 16: one coalesced load
+        const uint4 q = *reinterpret_cast<const uint4 *>(masks + first);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int k = 0; k < IDX_CHUNKS_PER_THREAD; k++) {
-        m[k] = (first + k < n_chunks) ? masks[first + k] : 0;
-        cnt += __popc((uint32_t)m[k]);
+        for (int k = 0; k < IDX_CHUNKS_PER_THREAD; k++)
+            m[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        cnt = __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
+    } else {
+#pragma unroll
+        for (int k = 0; k < IDX_CHUNKS_PER_THREAD; k++) {
+            m[k] = (first + k < n_chunks) ? masks[first + k] : 0;
+            cnt += __popc((uint32_t)m[k]);
+        }
     }
-    s_scan[threadIdx.x] = cnt;
+    // inclusive scan inside the wave, then over the block's waves
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o, 64);
+        if ((int)(threadIdx.x & 63) >= o)
+            inc += v;
+    }
+    if ((threadIdx.x & 63) == 63)
+        s_wave[threadIdx.x >> 6] = inc;
     __syncthreads();
-    for (int o = 1; o < IDX_THREADS; o <<= 1) {
-        uint32_t v = threadIdx.x >= (uint32_t)o ? s_scan[threadIdx.x - o] : 0;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t at = tile_base[blockIdx.x] + s_scan[threadIdx.x] - cnt;
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+        before += s_wave[w];
+    uint32_t at = tile_base[blockIdx.x] + before + inc - cnt;
     if (cnt == 0)
         return;
 #pragma unroll
@@ -281,13 +317,16 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
                  ((ld_u8(bytes, off + 9) >> 4) << 8) | ((ld_u8(bytes, off + 9) & 0xFu) << 12) |
                  ((ld_u8(bytes, off + 11) & 0x1Fu) << 16) | ((ld_u8(bytes, off + 20) >> 4) << 24);
         uint32_t n = 0;
+        // one memory round trip per frame: the 8 header bytes of the frame at p (size field and
+        // the place a major sync would sit) are fetched together and carried into the next step
+        uint64_t hdr = ld_hdr8(bytes, p);
         for (;;) {
             if (p + 4 > s_end) {
                 if (p != s_end)
                     r.flags |= 1u << 21; // DVDA_ST_TRUNCATED
                 break;
             }
-            const uint32_t size = 2u * (((ld_u8(bytes, p) & 0x0Fu) << 8) | ld_u8(bytes, p + 1));
+            const uint32_t size = 2u * ((((uint32_t)hdr & 0x0Fu) << 8) | (((uint32_t)hdr >> 8) & 0xFFu));
             if (size < 4) {
                 r.flags |= 1u << 4; // DVDA_ST_EOF: the reference stalls on such a header
                 break;
@@ -298,7 +337,8 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
             }
             p += size;
             n++;
-            if (sync_frame_at(bytes, p, s_end))
+            hdr = ld_hdr8(bytes, p);          // the buffer is readable 64 bytes past its end
+            if (sync_frame_hdr(bytes, p, s_end, hdr))
                 break;
         }
         r.nframes = n;
