@@ -1397,11 +1397,14 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
                                                   const uint32_t *__restrict__ seg_fbase,
                                                   const uint32_t *__restrict__ seg_status,
                                                   const uint32_t *__restrict__ seg_rows,
-                                                  StreamRec *__restrict__ streams, uint32_t n_streams)
+                                                  StreamRec *__restrict__ streams, uint32_t n_streams,
+                                                  const uint32_t *__restrict__ only_if)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams)
         return;
+    if (only_if && *only_if == 0)
+        return;                 // nothing was deferred: the sums of the fast pass stand
     StreamRec r = streams[s];
     if (r.first_seg == 0xFFFFFFFFu) {
         r.status |= 1u << 0;

@@ -345,7 +345,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     c->ev_used += 2;
     const dim3 fgrid((c->n_streams + 255) / 256);
     hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status,
-                       c->d_seg_rows, c->d_streams, c->n_streams);
+                       c->d_seg_rows, c->d_streams, c->n_streams, (const uint32_t *)nullptr);
     // general pass, twice: the second run picks up streams whose non-standard timing only
     // showed inside a chained run.  Lanes without deferred work exit at once.
     for (int pass = 0; pass < 2; pass++) {
@@ -355,7 +355,8 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         else
             hipLaunchKernelGGL((k_decode<6, false, true>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase,
-                           c->d_seg_status, c->d_seg_rows, c->d_streams, c->n_streams);
+                           c->d_seg_status, c->d_seg_rows, c->d_streams, c->n_streams,
+                           (const uint32_t *)a.deferred);
     }
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
