@@ -51,7 +51,8 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     subprocess.run(["gcc", "-O2", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                     "-c", "-o", obj_c, HIP_SRCS[1]], check=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-           "-o", obj_hip, HIP_SRCS[0]] + ["-D" + d for d in defines]
+           "-o", obj_hip, HIP_SRCS[0]] + ["-D" + d for d in defines if not d.startswith("-")] + \
+          [d for d in defines if d.startswith("-")]          # diagnostic builds may pass raw flags
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
@@ -70,6 +71,21 @@ def build_disc(force=False):
     return DISC_SO
 
 
+TOOL = os.path.join(os.path.dirname(HERE), "build", "dvda2wav_hip")
+TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "dvda2wav_hip.c")
+
+
+def build_tool(force=False):
+    """dvda2wav_hip: the command-line extractor on top of libdvd_audio_hip.so."""
+    if not force and not _stale(TOOL, [TOOL_SRC, DISC_SO, DISC_SRCS[1]]):
+        return TOOL
+    os.makedirs(os.path.dirname(TOOL), exist_ok=True)
+    subprocess.run(["gcc", "-O2", "-Wall", "-o", TOOL, TOOL_SRC, "-I" + os.path.join(os.path.dirname(HERE), "include"),
+                    "-L" + HERE, "-ldvd_audio_hip", "-ldvda_mlp_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,$ORIGIN/../libdvd-audio_amd", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return TOOL
+
+
 def build_synth(force=False):
     if not force and not _stale(SYNTH_SO, SYNTH_SRCS):
         return SYNTH_SO
@@ -79,4 +95,4 @@ def build_synth(force=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_disc(force), build_synth(force)
+    return build_hip(force, verbose), build_disc(force), build_tool(force), build_synth(force)

@@ -149,3 +149,18 @@ def test_disc_library_replaces_libdvd_audio_under_reference_dvda2wav(pkg):
                            text=True, timeout=900, env=env)
         assert r.returncode == 0 and os.listdir(one) == ["track-01-02.wav"]
         assert open(os.path.join(one, "track-01-02.wav"), "rb").read() == open(ref[1], "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_TOOL), reason="reference tools not built (dev container only)")
+def test_gpu_extractor_writes_the_reference_files(pkg):
+    """tools/dvda2wav_hip.c: the whole chain on the GPU (IFO walk, demux, decode, write_signed packing),
+    only the header and fwrite() on the host -- same files as the reference's dvda2wav."""
+    tool = pkg._build.build_tool()
+    with tempfile.TemporaryDirectory() as tmp:
+        ats = _mixed_disc(pkg, tmp)
+        ref = _run(REF_TOOL, ats, os.path.join(tmp, "ref"))
+        got = _run(tool, ats, os.path.join(tmp, "gpu"))
+        assert [os.path.basename(p) for p in got] == [os.path.basename(p) for p in ref] and len(ref) == 8
+        for a, b in zip(ref, got):
+            assert open(a, "rb").read() == open(b, "rb").read(), os.path.basename(a)

@@ -1,0 +1,155 @@
+/* dvda2wav_hip -- extracts the tracks of a DVD-Audio disc to WAV files on the GPU.
+ *
+ * Same command line and the same output files (names, 68-byte WAVE_FORMAT_EXTENSIBLE header,
+ * data bytes) as the reference's utility (reference utils/dvda2wav.c:57-186, 257-397), built on
+ * libdvd_audio_hip.so only: IFO walk, sector demux, MLP decode / PCM un-swizzle and the
+ * write_signed packing of the data chunk all run through include/dvd-audio-hip.h; this file does
+ * argument parsing, the header and fwrite().
+ *
+ *   cc -O2 -o dvda2wav_hip tools/dvda2wav_hip.c -Iinclude -Llibdvd-audio_amd -ldvd_audio_hip \
+ *      -ldvda_mlp_hip -Wl,-rpath,'$ORIGIN/../libdvd-audio_amd'
+ */
+#include <getopt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dvd-audio-hip.h"
+
+static void put16(uint8_t *p, unsigned v) { p[0] = v & 0xFF; p[1] = (v >> 8) & 0xFF; }
+static void put32(uint8_t *p, unsigned v) { put16(p, v & 0xFFFF); put16(p + 2, v >> 16); }
+
+/* RIFF/WAVE_FORMAT_EXTENSIBLE header as the reference writes it (utils/dvda2wav.c:352-397):
+ * note that its RIFF size field counts the 12 + 8 + 40 + 8 header bytes themselves */
+static void wave_header(uint8_t h[68], unsigned rate, unsigned channels, unsigned mask, unsigned bits,
+                        unsigned frames)
+{
+    static const uint8_t guid[16] = {1, 0, 0, 0, 0, 0, 16, 0, 128, 0, 0, 170, 0, 56, 155, 113};
+    const unsigned bytes = bits / 8, data = bytes * channels * frames;
+    memcpy(h, "RIFF", 4);
+    put32(h + 4, 12 + 40 + 8 + data + (data % 2));
+    memcpy(h + 8, "WAVEfmt ", 8);
+    put32(h + 16, 40);
+    put16(h + 20, 0xFFFE);
+    put16(h + 22, channels);
+    put32(h + 24, rate);
+    put32(h + 28, rate * channels * bytes);
+    put16(h + 32, channels * bytes);
+    put16(h + 34, bits);
+    put16(h + 36, 22);
+    put16(h + 38, bits);
+    put32(h + 40, mask);
+    memcpy(h + 44, guid, 16);
+    memcpy(h + 60, "data", 4);
+    put32(h + 64, data);
+}
+
+static int extract(DVDA_Title *title, unsigned track_num, const char *dir)
+{
+    DVDA_Track *track = dvda_open_track(title, track_num);
+    if (!track) {
+        fprintf(stderr, "*** Error: unable to open track %u\n", track_num);
+        return 0;
+    }
+    DVDA_Track_Reader *r = dvda_open_track_reader(track);
+    if (!r) {
+        fprintf(stderr, "*** Error: unable to open track %u for reading\n", track_num);
+        dvda_close_track(track);
+        return 0;
+    }
+    char path[4096];
+    const size_t n = strlen(dir);
+    snprintf(path, sizeof(path), "%s%strack-%2.2u-%2.2u.wav", dir, n && dir[n - 1] == '/' ? "" : "/",
+             dvda_title_number(title), dvda_track_number(track));
+    dvda_close_track(track);
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        fprintf(stderr, "*** Error: unable to open \"%s\" for writing\n", path);
+        dvda_close_track_reader(r);
+        return 0;
+    }
+    const unsigned channels = dvda_channel_count(r), bits = dvda_bits_per_sample(r), rate = dvda_sample_rate(r);
+    printf("* Extracting %s track  %u channels  %u Hz  %u bps\n", dvda_codec(r) == DVDA_MLP ? "MLP" : "PCM",
+           channels, rate, bits);
+    const unsigned long long frames = dvda_hip_reader_total_frames(r);
+    const unsigned char *payload = NULL;
+    const unsigned long long bytes = dvda_hip_reader_wav_payload(r, &payload);
+    uint8_t h[68];
+    wave_header(h, rate, channels, dvda_riff_wave_channel_mask(r), bits, (unsigned)frames);
+    int ok = fwrite(h, 1, sizeof(h), f) == sizeof(h) && (bytes == 0 || fwrite(payload, 1, bytes, f) == bytes);
+    ok = fclose(f) == 0 && ok;
+    if (ok && bytes == frames * channels * (bits / 8))
+        printf("* Wrote: \"%s\"\n", path);
+    else
+        fprintf(stderr, "*** Error: writing \"%s\"\n", path);
+    dvda_close_track_reader(r);
+    return ok;
+}
+
+static void usage(const char *prog)
+{
+    printf("*** Usage : %s -A [AUDIO_TS] [OPTIONS]\n"
+           "Options:\n"
+           "  -h, --help                show this help message and exit\n"
+           "  -A PATH, --audio_ts=PATH  path to disc's AUDIO_TS directory\n"
+           "  -S SET, --titleset=SET    title set number (default 1)\n"
+           "  -T TITLE, --title=TITLE   title number to extract (default: all)\n"
+           "  -t TRACK, --track=TRACK   track number to extract (default: all)\n"
+           "  -d DIR, --dir=DIR         output directory (default: the working directory)\n"
+           "  -g N, --gpu=N             HIP device (default 0)\n", prog);
+}
+
+int main(int argc, char *argv[])
+{
+    static struct option longopts[] = {{"audio_ts", required_argument, 0, 'A'}, {"cdrom", required_argument, 0, 'c'},
+                                       {"titleset", required_argument, 0, 'S'}, {"title", required_argument, 0, 'T'},
+                                       {"track", required_argument, 0, 't'},    {"dir", required_argument, 0, 'd'},
+                                       {"gpu", required_argument, 0, 'g'},      {"help", no_argument, 0, 'h'},
+                                       {0, 0, 0, 0}};
+    const char *audio_ts = NULL, *dir = ".", *cdrom = NULL;
+    unsigned titleset_num = 1, title_num = 0, track_num = 0;
+    int c;
+    while ((c = getopt_long(argc, argv, "A:c:S:T:t:d:g:h", longopts, NULL)) != -1) {
+        switch (c) {
+        case 'A': audio_ts = optarg; break;
+        case 'c': cdrom = optarg; break;
+        case 'S': titleset_num = (unsigned)strtoul(optarg, NULL, 10); break;
+        case 'T': title_num = (unsigned)strtoul(optarg, NULL, 10); break;
+        case 't': track_num = (unsigned)strtoul(optarg, NULL, 10); break;
+        case 'd': dir = optarg; break;
+        case 'g': dvda_hip_set_device(atoi(optarg)); break;
+        case 'h': usage(argv[0]); return 0;
+        default: return 1;
+        }
+    }
+    if (!audio_ts) {
+        usage(argv[0]);
+        return 0;
+    }
+    DVDA *dvda = dvda_open(audio_ts, cdrom);
+    DVDA_Titleset *ts = dvda ? dvda_open_titleset(dvda, titleset_num) : NULL;
+    if (!ts) {
+        fprintf(stderr, "*** Error: \"%s\" does not appear to be a valid AUDIO_TS path\n", audio_ts);
+        if (dvda)
+            dvda_close(dvda);
+        return 1;
+    }
+    int rc = 0;
+    const unsigned t_lo = title_num ? title_num : 1, t_hi = title_num ? title_num : dvda_title_count(ts);
+    for (unsigned t = t_lo; t <= t_hi && !rc; t++) {
+        DVDA_Title *title = dvda_open_title(ts, t);
+        if (!title) {
+            fprintf(stderr, "*** Error: unable to open title %u\n", t);
+            rc = 1;
+            break;
+        }
+        const unsigned k_lo = track_num ? track_num : 1, k_hi = track_num ? track_num : dvda_track_count(title);
+        for (unsigned k = k_lo; k <= k_hi; k++)
+            extract(title, k, dir);
+        dvda_close_title(title);
+    }
+    dvda_close_titleset(ts);
+    dvda_close(dvda);
+    return rc;
+}
