@@ -470,6 +470,32 @@ static int64_t find_sync(const uint8_t *b, uint64_t from, uint64_t size)
     return -1;
 }
 
+/* the same search over device memory: windows of the payload are copied back until the pattern
+ * shows up (each window overlaps the previous one by 7 bytes) */
+static int64_t find_sync_dev(const uint8_t *d_bytes, uint64_t from, uint64_t size)
+{
+    enum { WINDOW = 1 << 16 };
+    uint8_t *w = malloc(WINDOW);
+    int64_t at = -1;
+    if (!w)
+        return -1;
+    while (from + 8 <= size) {
+        const uint64_t n = size - from < WINDOW ? size - from : WINDOW;
+        if (hipMemcpy(w, d_bytes + from, n, hipMemcpyDeviceToHost) != hipSuccess)
+            break;
+        const int64_t p = find_sync(w, 0, n);
+        if (p >= 0) {
+            at = (int64_t)from + p;
+            break;
+        }
+        if (n < WINDOW)
+            break;
+        from += n - 7;
+    }
+    free(w);
+    return at;
+}
+
 static void reader_free(DVDA_Track_Reader *r)
 {
     if (!r)
@@ -485,7 +511,7 @@ static void reader_free(DVDA_Track_Reader *r)
 static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
 {
     DVDA_Track_Reader *r = NULL;
-    uint8_t *h_sec = NULL, *h_mlp = NULL, *d_sec = NULL, *d_mlp = NULL, *d_stream = NULL;
+    uint8_t *h_sec = NULL, *d_sec = NULL, *d_mlp = NULL, *d_stream = NULL;
     uint32_t *d_work = NULL, *h_base = NULL;
     uint64_t *d_meta = NULL;
     int32_t *d_pcm = NULL;
@@ -501,9 +527,8 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         if (first + want > aobs->total || first + want < first)
             want = aobs->total - first;
         free(h_sec);
-        free(h_mlp);
         free(h_base);
-        h_sec = h_mlp = NULL;
+        h_sec = NULL;
         h_base = NULL;
         (void)hipFree(d_sec);
         (void)hipFree(d_mlp);
@@ -529,13 +554,11 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
             goto fail;
         /* workspace words [got, 2*got]: payload offset of every sector, then the total */
         h_base = malloc(((size_t)got + 1) * sizeof(uint32_t));
-        h_mlp = malloc(total + 8);
-        if (!h_base || !h_mlp)
+        if (!h_base)
             goto fail;
-        if (hipMemcpy(h_base, d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(h_mlp, d_mlp, total, hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipMemcpy(h_base, d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
             goto fail;
-        const int64_t s0 = find_sync(h_mlp, 0, total);
+        const int64_t s0 = find_sync_dev(d_mlp, 0, total);
         if (s0 < 0) {
             if (got < want || first + got >= aobs->total)
                 goto fail;                       /* no major sync anywhere: the reference asserts */
@@ -548,7 +571,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
             break;
         }
         const uint64_t boundary = h_base[in_track];
-        const int64_t s1 = find_sync(h_mlp, boundary > begin ? boundary : begin, total);
+        const int64_t s1 = find_sync_dev(d_mlp, boundary > begin ? boundary : begin, total);
         if (s1 >= 0) {
             end = (uint64_t)s1;
             break;
@@ -635,10 +658,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         r->stride = stride;
         if (r->channels == 0 || r->channels != info.channels)
             goto fail;
-        r->pcm = malloc(stride * r->channels * sizeof(int32_t));
-        if (!r->pcm || hipMemcpy(r->pcm, d_pcm, stride * r->channels * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
-            goto fail;
-        r->d_pcm = d_pcm;
+        r->d_pcm = d_pcm;              /* the host copy is made by the first dvda_read() */
         d_pcm = NULL;
     }
     goto done;
@@ -649,7 +669,6 @@ done:
     if (ctx)
         dvda_mlp_hip_destroy(ctx);
     free(h_sec);
-    free(h_mlp);
     free(h_base);
     (void)hipFree(d_sec);
     (void)hipFree(d_mlp);
@@ -740,9 +759,6 @@ static DVDA_Track_Reader *open_pcm(struct aob_set *aobs, const DVDA_Track *k, co
             deliver = h_base[1] < total ? h_base[1] : total;   /* the opening packet is decoded regardless */
         r->frames = deliver;
         r->stride = stride;
-        r->pcm = malloc(stride * r->channels * sizeof(int32_t));
-        if (!r->pcm || hipMemcpy(r->pcm, d_pcm, stride * r->channels * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
-            goto fail;
         r->d_pcm = d_pcm;
         d_pcm = NULL;
         break;
@@ -823,6 +839,16 @@ unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *r)
 
 unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
 {
+    if (!r->pcm) {
+        /* planar PCM of the whole track, fetched once */
+        const size_t bytes = r->stride * r->channels * sizeof(int32_t);
+        r->pcm = malloc(bytes ? bytes : 1);
+        if (!r->pcm || hipMemcpy(r->pcm, r->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            free(r->pcm);
+            r->pcm = NULL;
+            return 0;
+        }
+    }
     const uint64_t left = r->frames - r->served;
     const unsigned n = left < pcm_frames ? (unsigned)left : pcm_frames;
     for (unsigned c = 0; c < r->channels; c++) {
