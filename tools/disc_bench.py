@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""tools/disc_bench.py [--tracks N] [--aus A] -- end-to-end extraction of a synthetic disc:
+build/dvda2wav_hip (disc tier, everything on the GPU but file I/O) beside the reference's own
+dvda2wav where oracle/_ref holds it.  Prints one JSON line with wall-clock seconds and
+Msamples/s for each, and checks that the files are identical.  Diagnostic, not bench.py."""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import libdvd_audio_amd as pkg  # noqa: E402
+
+
+def digest(d):
+    out = {}
+    for f in sorted(os.listdir(d)):
+        h = hashlib.sha256()
+        with open(os.path.join(d, f), "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 22), b""):
+                h.update(blk)
+        out[f] = h.hexdigest()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=8)
+    ap.add_argument("--aus", type=int, default=16384)
+    ap.add_argument("--tmp", default=None)
+    a = ap.parse_args()
+    syn, disc = pkg.synth, pkg.disc
+    tool = pkg._build.build_tool()
+    ref = os.path.join(ROOT, "oracle", "_ref", "dvda2wav_ref")
+    with tempfile.TemporaryDirectory(dir=a.tmp) as tmp:
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=a.aus)
+        tracks, samples = [], 0
+        for t in range(a.tracks):
+            b, f = syn.stream(cfg, 100 + t)
+            tracks.append({"sectors": disc.mlp_track_sectors(b), "pcm_frames": f, "rate_code": 1})
+            samples += f * 6
+        ats = disc.write_disc_titles(tmp, [tracks])
+        aob = os.path.getsize(os.path.join(ats, "ATS_01_1.AOB"))
+        res = {"tracks": a.tracks, "samples": samples, "aob_bytes": aob}
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "libdvd-audio_amd") + ":/opt/rocm/lib:" +
+                   os.environ.get("LD_LIBRARY_PATH", ""))
+        outs = {}
+        for name, exe in (("gpu", tool), ("reference", ref)):
+            if not os.path.exists(exe):
+                continue
+            out = os.path.join(tmp, name)
+            os.makedirs(out)
+            for rep in range(2 if name == "gpu" else 1):          # second GPU run: page cache + driver warm
+                t0 = time.time()
+                r = subprocess.run([exe, "-A", ats, "-d", out], capture_output=True, text=True, env=env)
+                dt = time.time() - t0
+                assert r.returncode == 0, r.stderr[-2000:]
+            res[name + "_seconds"] = round(dt, 3)
+            res[name + "_msamples_per_s"] = round(samples / dt / 1e6, 1)
+            outs[name] = digest(out)
+        if len(outs) == 2:
+            res["identical_files"] = outs["gpu"] == outs["reference"]
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
