@@ -252,3 +252,47 @@ def test_false_sync_pattern_in_ignored_bytes_is_resolved(pkg, oracle, S):
     dec.close()
     want, r, st = oracle.decode(b, 6, cframes)
     assert np.array_equal(np.asarray(samples, np.int32), want)
+
+
+@pytest.mark.gpu
+def test_mixed_corpus_192k_mlp_and_raw_pcm_titles_on_concurrent_streams(pkg, oracle):
+    """BASELINE configs[4] in small: 6-ch/192 kHz MLP titles and 6-ch/24-bit raw-PCM AOB titles are
+    decoded at the same time, each kind from its own host thread on its own HIP stream (every
+    C-ABI entry point takes the stream); both must match their oracles."""
+    import threading
+    import torch
+    syn, disc = pkg.synth, pkg.disc
+    cfg = syn.make_cfg(assignment=12, rate_code=2, n_aus=96)
+    titles = [syn.stream(cfg, 700 + i) for i in range(4)]
+    rng = np.random.RandomState(77)
+    pcm_titles = [rng.randint(-(1 << 23), 1 << 23, size=(2000 + 200 * i, 6)) for i in range(3)]
+    pcm_sectors = [np.frombuffer(b"".join(disc.pcm_track_sectors(p, 2, 2, 12)), np.uint8).copy() for p in pcm_titles]
+    got, errors = {}, []
+
+    def run_mlp():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                got["mlp"] = pkg.hipdec.decode_streams([b for b, _ in titles], lanes_per_segment=1)
+        except Exception as e:          # surfaced in the main thread
+            errors.append(e)
+
+    def run_pcm():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                got["pcm"] = [pkg.hipdec.pcm_decode_sectors(s, 24, 6) for s in pcm_sectors]
+        except Exception as e:
+            errors.append(e)
+
+    ts = [threading.Thread(target=run_mlp), threading.Thread(target=run_pcm)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    pcm, infos = got["mlp"]
+    for (b, f), p, inf in zip(titles, pcm, infos):
+        want, r, st = oracle.decode(b, 6, f)
+        assert st == 0 and r == f == p.shape[1] and f == 96 * 160
+        assert inf.status & ~pkg.hipdec.ST_BENIGN == 0 and np.array_equal(p, want)
+    for src, (out, bad) in zip(pcm_titles, got["pcm"]):
+        assert bad == 0 and np.array_equal(out, src.T)
