@@ -654,10 +654,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 one_matrix(mc, a.mat_ws[(size_t)(m * 5 + 4) * a.total_lanes + gl], m, true);
             }
         }
+        // output shifts are rare (all zero on most streams): one wave-uniform test skips them
+        if (__any(oshift_pack != 0)) {
 #pragma unroll
-        for (int c = 0; c < MAXCH; c++)
-            if ((uint32_t)c <= max_mat_ch)
-                ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
+            for (int c = 0; c < MAXCH; c++)
+                if ((uint32_t)c <= max_mat_ch)
+                    ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
+        }
     };
 
 #if defined(DVDA_EXP_STAMP)
@@ -1141,7 +1144,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 }
             }
             int32_t val[NS];
-            uint32_t bad_code = 0;
+            uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
+            const bool wave_iir = __any(iir_any != 0); // IIR taps anywhere in the wave (rare)
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
@@ -1160,7 +1164,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 const uint32_t e = huff_decode(cb ? cb : 1u, top >> 23);
                 const uint32_t msb = cb ? (e & 0xFFu) : 0u;
                 const uint32_t len = cb ? (e >> 8) : 0u;
-                bad_code |= (msb == 0xFFu) ? 1u : 0u;
+                msb_or |= msb;                            // valid values are < 0x20
                 const uint32_t o2 = rd.ofs + len;
                 const uint32_t top2 = (uint32_t)((win << o2) >> 32);
                 const uint32_t lsbv = (top2 >> 1) >> (31u - lb);          // lb == 0 -> 0
@@ -1185,9 +1189,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 acc0 += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
                 acc1 += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
                 int64_t acc = acc0 + acc1;
-                const bool iir_on = in && ((iir_any >> k) & 1u);
-                if (__builtin_expect(iir_on, 0))
-                    acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
+                bool iir_on = false;
+                if (__builtin_expect(wave_iir, 0)) {
+                    iir_on = in && ((iir_any >> k) & 1u);
+                    if (iir_on)
+                        acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
+                }
                 const int32_t ssum = (int32_t)(acc >> shift);
                 const int32_t value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
                 // history moves only for channels this lane really carries
@@ -1195,12 +1202,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 for (int j = 7; j > 0; j--)
                     st[k][j] = in ? st[k][j - 1] : st[k][j];
                 st[k][0] = in ? value : st[k][0];
-                if (__builtin_expect(iir_on, 0))
-                    iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
-                             (int32_t)((uint32_t)value - (uint32_t)ssum));
+                if (__builtin_expect(wave_iir, 0)) {
+                    if (iir_on)
+                        iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
+                                 (int32_t)((uint32_t)value - (uint32_t)ssum));
+                }
                 val[k] = in ? value : 0;
             }
-            if (__builtin_expect(bad_code != 0, 0)) {
+            if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {
                 status |= ST_HUFFMAN;
                 active = false;
             }
