@@ -529,6 +529,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             }
         }
     }
+    // fast pass: rows this lane may still write (see the row loop)
+    uint32_t room = 0;
+    {
+        const uint64_t edge = out_stride < row_limit ? out_stride : row_limit;
+        if (edge > row0)
+            room = edge - row0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(edge - row0);
+    }
     const bool vec_ok = (((out_base | out_stride) & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0);   // 16-byte aligned rows
 
@@ -1102,11 +1109,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         const int32_t ahead_now = (int32_t)(rd.fillpos - rd.next);
 #if defined(DVDA_LINE_PREFETCH)
         const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS) &&
-                        ((rd.fillpos & CHUNK_DWORDS) || ahead_now <= RING_DWORDS / 2) &&
+                        ((rd.fillpos & CHUNK_DWORDS) || ahead_now <= RING_DWORDS / 2);
 #else
-        const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS) &&
+        const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS);
 #endif
-                        (!rd.crc_rem || (int32_t)(rd.fillpos + CHUNK_DWORDS - RING_DWORDS - rd.crc_pos) <= 0);
+        // (the chunk this overwrites has been hashed: crc_catchup() above ran up to `next`, and
+        //  ahead_now <= 16 puts `next` past it)
         // deliberately not initialised: only read under the same `pf`.  (Zero-filling them made the
         // compiler wait for every outstanding memory operation -- the previous row's PCM stores
         // included -- before it could overwrite the registers.)
@@ -1135,12 +1143,17 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             if (__any(bypass_mask != 0)) {
                 const uint32_t cnt = (uint32_t)__popc(bypass_mask);          // <= MAXMAT
                 const uint32_t field = rd.read_resident(cnt);
-                uint32_t rank = 0;
+                // matrices 0 and 1 (the ones every real stream uses) directly, the rest in a cold loop
+                const uint32_t b0 = bypass_mask & 1u, b1 = (bypass_mask >> 1) & 1u;
+                bypass_bits = (b0 & (field >> ((cnt - 1u) & 31u))) | ((b1 & (field >> ((cnt - 1u - b0) & 31u))) << 1);
+                if (__builtin_expect(__any((bypass_mask >> 2) != 0), 0)) {
+                    uint32_t rank = b0 + b1;
 #pragma unroll
-                for (int m = 0; m < MAXMAT; m++) {
-                    const uint32_t bit = (bypass_mask >> m) & 1u;
-                    bypass_bits |= (bit & (field >> ((cnt - 1u - rank) & 31u))) << m;
-                    rank += bit;
+                    for (int m = 2; m < MAXMAT; m++) {
+                        const uint32_t bit = (bypass_mask >> m) & 1u;
+                        bypass_bits |= (bit & (field >> ((cnt - 1u - rank) & 31u))) << m;
+                        rank += bit;
+                    }
                 }
             }
             int32_t val[NS];
@@ -1271,10 +1284,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         T[c][ph][GENERAL ? 0 : lane] = ch[c];
                     // ---- RIFF order (src/mlp.c:527-533): every OUT_ROWS-th frame each channel's staged
                     //      frames leave as 16-byte stores that together cover whole 32-byte sectors
-                    if (row >= out_stride) {
-                        status |= ST_OVERFLOW;
-                        active = false;
-                    } else if (row < row_limit) {
+                    // `room` rows are left before the segment's standard length or the output
+                    // capacity is reached: one 32-bit test per row, the 64-bit ones only at the edge
+                    if (__builtin_expect(room == 0, 0)) {
+                        if (row >= out_stride) {
+                            status |= ST_OVERFLOW;
+                            active = false;
+                        }
+                    } else {
                         rows_written++;
                         if (ph == OUT_ROWS - 1) {
                             flush = true;          // stored after the ring commit below
@@ -1285,9 +1302,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             }
             row++;
             rows_done++;
-            if (row > row_limit) {
-                status |= ST_TIMING;       // more PCM frames than the standard access-unit length
-                active = false;
+            if (GENERAL) {
+                if (row > row_limit) {
+                    status |= ST_TIMING;
+                    active = false;
+                }
+            } else if (__builtin_expect(room == 0, 0)) {
+                if (row > row_limit) {
+                    status |= ST_TIMING;   // more PCM frames than the standard access-unit length
+                    active = false;
+                }
+            } else {
+                room--;
             }
             frame_rows++;
             rows_left--;
