@@ -146,10 +146,15 @@ __device__ __forceinline__ int32_t huff_center(uint32_t codebook, uint32_t lb)
 // Ring layout: [dword index mod RING_DWORDS][lane].  A lane's dword d sits at
 // (d mod RING_DWORDS) * 64 + lane, so whatever position each lane reads, lane l always hits
 // bank l mod 32: ring reads and writes are conflict-free and an address costs two instructions.
+// One extra plane behind the ring mirrors plane 0, so "dword d and dword d + 1" is always
+// "address and address + one plane": the row loop fetches its two look-ahead dwords with a single
+// two-address LDS read and one address computation.  `first_plane`: the chunk starts at plane 0.
 __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, const uint4 &b, const uint4 &c,
-                                             const uint4 &d)
+                                             const uint4 &d, bool first_plane)
 {
     // dst = slot of the chunk's first dword; the chunk is 16-dword aligned, so no wrap inside it
+    if (first_plane)
+        dst[RING_DWORDS * 64] = a.x;
     dst[0 * 64] = a.x;  dst[1 * 64] = a.y;  dst[2 * 64] = a.z;  dst[3 * 64] = a.w;
     dst[4 * 64] = b.x;  dst[5 * 64] = b.y;  dst[6 * 64] = b.z;  dst[7 * 64] = b.w;
     dst[8 * 64] = c.x;  dst[9 * 64] = c.y;  dst[10 * 64] = c.z; dst[11 * 64] = c.w;
@@ -160,10 +165,10 @@ __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, cons
 // Synchronous fill of one 64-byte chunk into a lane's ring slots (used after
 // seeks and inside long headers; the row loop prefetches instead).
 // dst: this lane's 16-byte slot in the chunk's first plane; planes are 64 slots apart.
-__device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint32_t *dst)
+__device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint32_t *dst, bool first_plane)
 {
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-    ring_store16(dst, a, b, c, d);
+    ring_store16(dst, a, b, c, d, first_plane);
 }
 
 // Byte-wise ends of the parity/CRC check (src/mlp.c:1397-1398 and 690-706).
@@ -275,7 +280,7 @@ struct BitReader {
         if (crc_rem && (int32_t)(fillpos + CHUNK_DWORDS - RING_DWORDS - crc_pos) > 0)
             crc_catchup(fillpos);
         const uint32_t c = fillpos < max_chunk ? fillpos : max_chunk;
-        ring_fill_sync(gsrc + (c >> 2), slot(fillpos));
+        ring_fill_sync(gsrc + (c >> 2), slot(fillpos), (fillpos & (RING_DWORDS - 1)) == 0);
         filled();
     }
     __device__ __forceinline__ void ensure(uint32_t n)           // n dwords resident at/after next
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     if (GENERAL && *a.deferred == 0)
         return;                                                   // nothing was deferred: whole grid exits
     __shared__ uint8_t s_crc[4 * 256];
-    __shared__ uint32_t s_ring[DEC_WAVES][RING_DWORDS][64];
+    __shared__ uint32_t s_ring[DEC_WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
     __shared__ int32_t s_out[GENERAL ? 1 : DEC_WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
     __shared__ int32_t s_xch[PAIRED ? DEC_WAVES : 1][MAXCH][PAIRED ? 64 : 1];
 
@@ -1171,7 +1176,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 const uint32_t pkk = in ? pk[k] : 0u;
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
-                const uint32_t cand1 = rd.ld(rd.next), cand2 = rd.ld(rd.next + 1);
+                // the two dwords behind the window: one address, one two-address LDS read (mirror plane)
+                const uint32_t *look = rd.slot(rd.next);
+                const uint32_t cand1 = __builtin_bswap32(look[0]), cand2 = __builtin_bswap32(look[64]);
                 const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
                 const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
                 const uint32_t e = huff_decode(cb ? cb : 1u, top >> 23);
@@ -1371,7 +1378,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 
         // ---- the prefetched chunk lands in the ring
         if (pf) {
-            ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3);
+            ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3, (rd.fillpos & (RING_DWORDS - 1)) == 0);
             rd.filled();
         }
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
