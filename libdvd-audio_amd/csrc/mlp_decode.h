@@ -1294,7 +1294,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     // `room` rows are left before the segment's standard length or the output
                     // capacity is reached: one 32-bit test per row, the 64-bit ones only at the edge
                     if (__builtin_expect(room == 0, 0)) {
-                        if (row >= out_stride) {
+                        // past the segment's standard length it is a timing matter (flagged below, the
+                        // general pass then places the rows where they really go), not a capacity one
+                        if (row >= out_stride && row < row_limit) {
                             status |= ST_OVERFLOW;
                             active = false;
                         }
@@ -1456,7 +1458,9 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
         r.consumed = 0;
     } else {
         uint64_t rows = 0;
-        uint32_t st = r.status;
+        // decode-time bits are rebuilt from the segments every time (the general pass clears what it
+        // repairs); only what the index found stays
+        uint32_t st = r.status & ~(0x3FCu | ST_DEFERRED | ST_OVERFLOW | ST_CAPACITY | ST_GENERAL);
         for (uint32_t i = r.first_seg; i < r.first_seg + r.n_seg; i++) {
             rows += seg_rows[i];
             st |= seg_status[i];

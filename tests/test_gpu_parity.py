@@ -337,3 +337,21 @@ def test_garbage_and_bit_flips_never_hang_and_never_pass_silently(pkg, oracle):
             # least agree on everything the oracle produced before stopping
             assert p.shape[1] >= r and np.array_equal(p[:, :r], want)
     assert clean >= 4
+
+
+@pytest.mark.gpu
+def test_long_last_access_unit_is_timing_not_overflow(pkg, oracle):
+    """Found by tools/soak.py: when the last segment's access unit is longer than the standard 40/80/160
+    frames, the fast pass runs past both its standard length and the output capacity at the same row.
+    That is a timing matter (the general pass re-places the rows), so the stream must end without
+    DVDA_ST_OVERFLOW although the total fits the capacity derived from the standard length."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=17, rate_code=2, n_substreams=2, n_aus=15, profile=1, features=syn.SF_ALL,
+                       restart_interval=2)
+    b, f = syn.stream(cfg, 10303)
+    want, r, st = oracle.decode(b, 6, f)
+    assert st == 0 and r == f
+    pcm, infos = hip.decode_streams([b], lanes_per_segment=2)
+    assert infos[0].status & hip.ST["TIMING"]
+    assert infos[0].status & ~hip.ST_BENIGN == 0
+    assert np.array_equal(pcm[0], want)
