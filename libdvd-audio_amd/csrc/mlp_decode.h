@@ -1190,9 +1190,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 const uint32_t lsbv = (top2 >> 1) >> (31u - lb);          // lb == 0 -> 0
                 const uint32_t o3 = o2 + lb;                              // <= 31 + 9 + 24 = 64
                 const uint32_t adv = o3 >> 5;                             // 0, 1 or 2 dwords consumed
-                const uint32_t nh = adv == 0 ? rd.hi : (adv == 1 ? rd.lo : rd.nx);
-                const uint32_t nl = adv == 0 ? rd.lo : (adv == 1 ? rd.nx : cand1);
-                const uint32_t nn = adv == 0 ? rd.nx : (adv == 1 ? cand1 : cand2);
+                // a symbol rarely spans two whole dwords (ofs + code + LSBs >= 64): the one-dword step is
+                // the straight path, the second step sits behind a wave-uniform test
+                const bool step = adv != 0;
+                uint32_t nh = step ? rd.lo : rd.hi;
+                uint32_t nl = step ? rd.nx : rd.lo;
+                uint32_t nn = step ? cand1 : rd.nx;
+                if (__builtin_expect(__any(adv == 2), 0)) {
+                    const bool two = adv == 2;
+                    nh = two ? rd.nx : nh;
+                    nl = two ? cand1 : nl;
+                    nn = two ? cand2 : nn;
+                }
                 rd.hi = nh;
                 rd.lo = nl;
                 rd.nx = nn;
