@@ -1198,6 +1198,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 uint32_t nn = step ? cand1 : rd.nx;
                 if (__builtin_expect(__any(adv == 2), 0)) {
                     const bool two = adv == 2;
+#if defined(DVDA_EXP_COUNT)
+                    if (two && in && a.dbg)
+                        atomicAdd(&a.dbg[8], 1ull);      // diagnostic: how often the rare path really runs
+#endif
                     nh = two ? rd.nx : nh;
                     nl = two ? cand1 : nl;
                     nn = two ? cand2 : nn;

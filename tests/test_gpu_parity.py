@@ -355,3 +355,20 @@ def test_long_last_access_unit_is_timing_not_overflow(pkg, oracle):
     assert infos[0].status & hip.ST["TIMING"]
     assert infos[0].status & ~hip.ST_BENIGN == 0
     assert np.array_equal(pcm[0], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codebook", [1, 2, 3])
+def test_widest_symbols_step_the_bit_window_by_two_dwords(pkg, oracle, codebook):
+    """A 9-bit code followed by 24 LSBs starting at bit 31 of the window consumes two whole dwords --
+    the row loop's rare second window step (wave-uniform gate).  The generator reaches it with a
+    code book and huffman_lsbs = 24 (a DVDA_EXP_COUNT build counted 22 such steps in 24 of these
+    streams); every stream must stay bit-exact."""
+    syn = pkg.synth
+    cases = []
+    for seed in range(6):
+        cfg = syn.make_cfg(assignment=[12, 1, 9][seed % 3], rate_code=seed % 3, n_substreams=1 + seed % 2, n_aus=24,
+                           profile=seed % 2, features=(syn.SF_FAST & ~syn.SF["MIXBOOKS"]) if seed % 2 else 0,
+                           restart_interval=1 + seed, codebook=codebook, huffman_lsbs=24)
+        cases.append((cfg, 31000 + 10 * codebook + seed))
+    _check(pkg, oracle, cases, lanes=2)
