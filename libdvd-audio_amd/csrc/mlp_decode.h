@@ -623,7 +623,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
     //      ch[0..7] in MLP channel order, shifted in place
     auto rematrix = [&](int32_t(&ch)[MAXCH], uint32_t bypass_bits) {
-        const bool wide_matrix = __any(max_mat_ch >= 6);       // wave-uniform
         const uint32_t shifted = (seed >> 7) & 0xFFFFu;
         const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
         const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
@@ -635,11 +634,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
             for (int c = 0; c < 6; c++)
                 acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]));
-            if (__builtin_expect(wide_matrix, 0)) {       // channels 6 and 7: never on DVD-Audio layouts
-#pragma unroll
-                for (int c = 6; c < MAXCH; c++)
-                    acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]));
-            }
             const uint32_t oc = nib(outch_pack, m);
             const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
                                          ((bypass_bits >> m) & 1u));
@@ -647,11 +641,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
             for (int c = 0; c < 6; c++)
                 ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
-            if (__builtin_expect(wide_matrix, 0)) {
-#pragma unroll
-                for (int c = 6; c < MAXCH; c++)
-                    ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
-            }
         };
         if (__any(matrix_len > 0))
             one_matrix(mreg[0], mnoise[0], 0, matrix_len > 0);
@@ -801,9 +790,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         if (h0 != (0x18F5u << 1) || max_ch < min_ch || max_mat_ch < max_ch) {
                             ok = false;
                             err = ST_RESTART;
-                        } else if (max_mat_ch >= MAXCH || max_ch - min_ch >= (uint32_t)NS) {
+                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= (uint32_t)NS) {
                             ok = false;
-                            err = ST_ENVELOPE;                     // reference arrays hold 8 channels
+                            // DVD-Audio layouts stop at 6 channels (src/mlp.c:416-438 has 6 columns,
+                            // src/dvd-audio.c:1459-1496 counts at most 6); matrix channels 6 and 7 are
+                            // reported, not decoded
+                            err = ST_ENVELOPE;
                         } else {
                             for (uint32_t c = 0; c <= max_mat_ch; c++)
                                 if (rd.read(6) > max_mat_ch) {
