@@ -133,7 +133,8 @@ int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *ctx, uint32_t *n_segments, void
 int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *launches);
 
 /* Number of lanes the decode kernels use per segment: 1 when every stream of the batch is known
- * to carry a single substream (faster), 2 (default) otherwise. */
+ * to carry a single substream starting at channel 0 (faster; anything else in the batch is
+ * reported as DVDA_ST_ENVELOPE), 2 (default) otherwise. */
 int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
 
 /* Per-segment results of the last decode (blocks on `stream`). */

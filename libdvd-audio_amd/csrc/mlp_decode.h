@@ -74,6 +74,12 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 // One 16-byte store instruction, opaque to the optimizer: left to itself the compiler merges this
 // store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
 // which doubles the store instructions and splits every half-sector write in two.
+// coverage counters of the rarely taken paths (DVDA_EXP_COUNT builds, tools/coverage_run.py)
+#if defined(DVDA_EXP_COUNT)
+#define DVDA_COV(i) do { if (a.dbg) atomicAdd(&a.dbg[(i)], 1ull); } while (0)
+#else
+#define DVDA_COV(i) ((void)0)
+#endif
 typedef int dvda_v4i __attribute__((ext_vector_type(4)));
 #ifndef DVDA_STORE_MODS
 #define DVDA_STORE_MODS ""
@@ -648,6 +654,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             one_matrix(mreg[1], mnoise[1], 1, matrix_len > 1);
         if (__builtin_expect(__any(matrix_len > 2), 0)) {
             for (uint32_t m = 2; m < matrix_len; m++) {    // cold: matrices 2.. live in the workspace
+                DVDA_COV(9);
                 uint32_t mc[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -790,11 +797,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         if (h0 != (0x18F5u << 1) || max_ch < min_ch || max_mat_ch < max_ch) {
                             ok = false;
                             err = ST_RESTART;
-                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= (uint32_t)NS) {
+                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= (uint32_t)NS || (!PAIRED && min_ch != 0)) {
                             ok = false;
                             // DVD-Audio layouts stop at 6 channels (src/mlp.c:416-438 has 6 columns,
                             // src/dvd-audio.c:1459-1496 counts at most 6); matrix channels 6 and 7 are
-                            // reported, not decoded
+                            // reported, not decoded; so is a lone substream that does not start at
+                            // channel 0 in a one-lane launch (the reference then leaves channel 0 empty)
                             err = ST_ENVELOPE;
                         } else {
                             for (uint32_t c = 0; c <= max_mat_ch; c++)
@@ -1098,6 +1106,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         // (cold top-up), hash what the parser has passed, and fetch the next 64-byte chunk now
         // so that it lands in the ring while this row is being decoded.
         if (active) {
+            if ((int32_t)(rd.fillpos - rd.next) < 12)
+                DVDA_COV(14);                // synchronous ring top-up inside the row loop
             rd.ensure(12);
             rd.crc_catchup(rd.next);
         }
@@ -1144,6 +1154,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 const uint32_t b0 = bypass_mask & 1u, b1 = (bypass_mask >> 1) & 1u;
                 bypass_bits = (b0 & (field >> ((cnt - 1u) & 31u))) | ((b1 & (field >> ((cnt - 1u - b0) & 31u))) << 1);
                 if (__builtin_expect(__any((bypass_mask >> 2) != 0), 0)) {
+                    if (bypass_mask >> 2)
+                        DVDA_COV(10);            // bypassed LSBs of matrices 2..5
                     uint32_t rank = b0 + b1;
 #pragma unroll
                     for (int m = 2; m < MAXMAT; m++) {
@@ -1190,10 +1202,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 uint32_t nn = step ? cand1 : rd.nx;
                 if (__builtin_expect(__any(adv == 2), 0)) {
                     const bool two = adv == 2;
-#if defined(DVDA_EXP_COUNT)
-                    if (two && in && a.dbg)
-                        atomicAdd(&a.dbg[8], 1ull);      // diagnostic: how often the rare path really runs
-#endif
+                    if (two && in)
+                        DVDA_COV(8);                 // two-dword window step
                     nh = two ? rd.nx : nh;
                     nl = two ? cand1 : nl;
                     nn = two ? cand2 : nn;
@@ -1217,6 +1227,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 bool iir_on = false;
                 if (__builtin_expect(wave_iir, 0)) {
                     iir_on = in && ((iir_any >> k) & 1u);
+                    if (iir_on)
+                        DVDA_COV(11);                // IIR taps
                     if (iir_on)
                         acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
                 }
@@ -1256,19 +1268,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
                 for (int c = 0; c < MAXCH; c++)
                     ch[c] = X[c][slot0];
-            } else if (min_ch == 0) {
+            } else {
+                // one lane per segment: the single substream starts at channel 0 (checked at the
+                // restart header)
 #pragma unroll
                 for (int c = 0; c < MAXCH; c++)
                     ch[c] = c < NS ? val[c < NS ? c : 0] : 0;
-            } else {
-                // single substream whose first channel is not 0: place by select
-#pragma unroll
-                for (int c = 0; c < MAXCH; c++) {
-                    ch[c] = 0;
-#pragma unroll
-                    for (int k = 0; k < NS; k++)
-                        ch[c] = (min_ch + k == (uint32_t)c && (uint32_t)k < nslots) ? val[k] : ch[c];
-                }
             }
 
             if (is_last_sub) {
@@ -1410,6 +1415,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 #pragma unroll
                         for (int i = 0; i < OUT_ROWS; i++)
                             dst[i] = o[i];
+                        DVDA_COV(13);                // unaligned output: scalar stores
                     }
                 }
             }
