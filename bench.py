@@ -233,7 +233,7 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
-        if not args.no_cpu and world >= 1:
+        if not args.no_cpu and world == 1:       # the CPU baseline is timed at N=1 only
             ns = args.streams
             sample = [flat[int(offs[i]):int(offs[i] + sizes[i])] for i in range(ns)]
             out["cpu_baseline"] = cpu_baseline(syn, sample, [int(f) for f in frames[:ns]], nch,
