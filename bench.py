@@ -87,9 +87,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Plumbing check on a 1-GPU box only (never what the driver measures): DVDA_BENCH_ONE_GPU=1 puts
+    # every rank on cuda:0 and DVDA_BENCH_BACKEND=gloo exchanges the summary on the host, because RCCL
+    # refuses two ranks on one device.
+    backend = os.environ.get("DVDA_BENCH_BACKEND", "nccl")
+    if os.environ.get("DVDA_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the decode path is HIP-only)")
     torch.cuda.set_device(local_rank)
@@ -181,7 +187,8 @@ def main():
     # ---- whole-job aggregate: the path's one collective is this summary (RCCL all-reduce of a
     #      few words over xGMI; nothing on the data path is exchanged)
     checksum = int(d_pcm.to(torch.int64).sum().item()) if args.verify else 0
-    summ = pkg.shard.reduce_summary(dist if world > 1 else None, dev, rows_total, samples_per_step,
+    summ = pkg.shard.reduce_summary(dist if world > 1 else None, dev if backend == "nccl" else torch.device("cpu"),
+                                    rows_total, samples_per_step,
                                     comp_bytes, 0, checksum, elapsed)
     elapsed_max = summ["seconds"]
     job_samples = float(summ["samples"])
