@@ -643,7 +643,10 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             const uint32_t oc = nib(outch_pack, m);
             const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
                                          ((bypass_bits >> m) & 1u));
-            const uint32_t oce = on ? oc : 0xFFu;                // oc <= max_matrix_channel (checked)
+            // `on` is folded into the channel number (0xFF matches nothing) and the value is fenced, or
+            // the compiler turns it back into "compare, and with the mask, wait state, select" per channel
+            uint32_t oce = on ? oc : 0xFFu;                      // oc <= max_matrix_channel (checked)
+            asm volatile("" : "+v"(oce));
 #pragma unroll
             for (int c = 0; c < 6; c++)
                 ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
