@@ -162,7 +162,11 @@ const char *dvda_mlp_hip_version(void);
  * extension) do packet by packet, for n_sectors 2048-byte sectors resident in HBM at once.
  * Output: planar int32, channel c at d_pcm[c * stride + frame] -- the order the reference
  * appends into `samples`.  Only whole 2-frame chunks of a packet are decoded (src/pcm.c:149).
- * d_work: device scratch of dvda_pcm_hip_workspace_words(n_sectors) uint32 words. */
+ * d_work: device scratch of dvda_pcm_hip_workspace_words(n_sectors) uint32 words.  After the call
+ * it holds, per sector, what the sector contributed and where it starts in the output:
+ *   d_work[s]                 PCM frames (or MLP payload bytes, for the demux call) of sector s
+ *   d_work[n_sectors + s]     their exclusive prefix sum; d_work[2 * n_sectors] = the total
+ * (the disc tier reads the prefix to cut a track at a sector boundary). */
 size_t dvda_pcm_hip_workspace_words(uint32_t n_sectors);
 int dvda_pcm_hip_decode_sectors(const uint8_t *d_sectors, uint32_t n_sectors, unsigned bits_per_sample,
                                 unsigned channels, int32_t *d_pcm, uint64_t stride, uint32_t *d_work,
