@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verify", type=int, default=8, help="titles checked against the oracle")
+    ap.add_argument("--substreams", type=int, default=1, choices=(1, 2),
+                    help="1 = the BASELINE metric; 2 = the recipe's 2-substream variant (ch 0-1 | ch 2-5), "
+                         "decoded with two lanes per segment")
     ap.add_argument("--assignment", type=int, default=12,
                     help="channel assignment of the synthetic titles (12 = 6-ch, the BASELINE metric; "
                          "1 = 2-ch for configs[1] exploration)")
@@ -107,7 +110,7 @@ def main():
     assignment, rate_code = args.assignment, 1
     nch = syn.channels(assignment)
     rpa = syn.rows_per_au(rate_code)
-    cfg = syn.make_cfg(assignment=assignment, rate_code=rate_code, n_substreams=1, n_aus=args.aus)
+    cfg = syn.make_cfg(assignment=assignment, rate_code=rate_code, n_substreams=args.substreams, n_aus=args.aus)
 
     # ---- synthetic titles: unique set generated on the host cores, replicated on the device
     t_gen = time.perf_counter()
@@ -138,7 +141,7 @@ def main():
     d_stride = torch.from_numpy(all_frames).to(dev)
     d_pcm = torch.empty(samples_per_step, dtype=torch.int32, device=dev)
 
-    ctx = hip.Context(local_rank, n_streams, n_segments, lanes_per_segment=1)
+    ctx = hip.Context(local_rank, n_streams, n_segments, lanes_per_segment=args.substreams)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -224,6 +227,7 @@ def main():
             "config": {
                 "workload": "BASELINE configs[2]: synthetic 6ch/96kHz/24bit MLP, 2 matrices + 8-tap FIR, "
                             "codebook 1, CRC on, restart every 8 AUs",
+                "substreams": args.substreams,
                 "titles_per_gpu": n_streams, "unique_titles_per_gpu": args.streams,
                 "access_units_per_title": args.aus, "segments_per_gpu": n_segments,
                 "samples_per_step_per_gpu": samples_per_step,
