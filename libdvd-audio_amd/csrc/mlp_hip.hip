@@ -599,9 +599,32 @@ extern "C" int dvda_mlp_hip_pack_wav(const int32_t *d_pcm, uint64_t stride, unsi
         return DVDA_HIP_EINVAL;
     if (frames == 0)
         return DVDA_HIP_OK;
-    const uint64_t blocks = (frames + wav::FRAMES - 1) / wav::FRAMES;
-    hipLaunchKernelGGL(wav::k_pack_wav, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, d_pcm, stride,
-                       channels, frames, bits_per_sample, d_out);
+    hipStream_t st = (hipStream_t)stream_;
+    // whole 1024-frame blocks take the register-packing kernel when the planes and the output are
+    // dword / 16-byte aligned; the tail (and unaligned buffers) the generic one
+    uint64_t done = 0;
+    const bool fast_ok = ((uintptr_t)d_pcm & 15) == 0 && (stride & 3) == 0 && ((uintptr_t)d_out & 3) == 0;
+    const uint64_t nfast = fast_ok ? frames / wav::FAST_FRAMES : 0;
+    if (nfast) {
+        const dim3 g((unsigned)nfast), b(256);
+#define DVDA_PACK_CASE(CH, BITS)                                                                        \
+    case (CH) * 100 + (BITS):                                                                           \
+        hipLaunchKernelGGL((wav::k_pack_wav_fast<CH, BITS>), g, b, 0, st, d_pcm, stride, nfast, d_out); \
+        break;
+        switch (channels * 100 + bits_per_sample) {
+            DVDA_PACK_CASE(1, 16) DVDA_PACK_CASE(2, 16) DVDA_PACK_CASE(3, 16) DVDA_PACK_CASE(4, 16)
+            DVDA_PACK_CASE(5, 16) DVDA_PACK_CASE(6, 16) DVDA_PACK_CASE(1, 24) DVDA_PACK_CASE(2, 24)
+            DVDA_PACK_CASE(3, 24) DVDA_PACK_CASE(4, 24) DVDA_PACK_CASE(5, 24) DVDA_PACK_CASE(6, 24)
+        }
+#undef DVDA_PACK_CASE
+        done = nfast * wav::FAST_FRAMES;
+    }
+    if (done < frames) {
+        const uint64_t rest = frames - done;
+        const uint64_t blocks = (rest + wav::FRAMES - 1) / wav::FRAMES;
+        hipLaunchKernelGGL(wav::k_pack_wav, dim3((unsigned)blocks), dim3(256), 0, st, d_pcm + done, stride, channels,
+                           rest, bits_per_sample, d_out + done * channels * (bits_per_sample / 8));
+    }
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
 }

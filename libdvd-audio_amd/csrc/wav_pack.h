@@ -52,4 +52,53 @@ __global__ __launch_bounds__(256) void k_pack_wav(const int32_t *__restrict__ pc
         o[k] = (uint8_t)byte_at(k);
 }
 
+// Fast path (dword-aligned planes and output, whole 1024-frame blocks): one thread takes 4 PCM frames
+// of every channel with one 16-byte load per channel, packs its 4 * CH samples frame-major into
+// CH * BITS / 8 dwords in registers (four 24-bit samples -> three dwords, two 16-bit samples -> one),
+// and the block's dwords leave through LDS so that consecutive lanes store consecutive dwords.
+constexpr int FAST_FRAMES = 1024;
+
+template <int CH, int BITS>
+__global__ __launch_bounds__(256) void k_pack_wav_fast(const int32_t *__restrict__ pcm, uint64_t stride,
+                                                       uint64_t n_blocks, uint8_t *__restrict__ out)
+{
+    constexpr int NB = BITS / 8;
+    constexpr int ND = CH * NB;                       // dwords per thread (4 frames)
+    constexpr uint32_t LOW = (1u << (BITS - 1)) - 1u, SIGN = 1u << (BITS - 1);
+    __shared__ uint32_t s_d[256 * ND];
+    const uint64_t f0 = (uint64_t)blockIdx.x * FAST_FRAMES + 4u * threadIdx.x;
+    uint32_t v[4 * CH];                                // frame-major: v[f * CH + c]
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int4 q = *reinterpret_cast<const int4 *>(pcm + (uint64_t)c * stride + f0);
+        const int32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+            v[f * CH + c] = ((uint32_t)x[f] & LOW) | (x[f] < 0 ? SIGN : 0u);      // write_signed
+    }
+    uint32_t d[ND];
+    if (BITS == 24) {
+#pragma unroll
+        for (int g = 0; g < CH; g++) {                 // samples 4g .. 4g+3 -> dwords 3g .. 3g+2
+            const uint32_t s0 = v[4 * g], s1 = v[4 * g + 1], s2 = v[4 * g + 2], s3 = v[4 * g + 3];
+            d[3 * g] = s0 | (s1 << 24);
+            d[3 * g + 1] = (s1 >> 8) | (s2 << 16);
+            d[3 * g + 2] = (s2 >> 16) | (s3 << 8);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 2 * CH; g++)
+            d[g] = v[2 * g] | (v[2 * g + 1] << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < ND; j++)
+        s_d[threadIdx.x * ND + j] = d[j];
+    __syncthreads();
+    uint32_t *o = reinterpret_cast<uint32_t *>(out) + (uint64_t)blockIdx.x * (256 * ND);
+#pragma unroll
+    for (int j = 0; j < ND; j++)
+        o[j * 256 + threadIdx.x] = s_d[j * 256 + threadIdx.x];
+    (void)n_blocks;
+}
+
 } // namespace wav

@@ -150,7 +150,8 @@ def test_wav_pack_oracle_equals_reference_writer(bits, ch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits", [16, 24])
-@pytest.mark.parametrize("ch,frames", [(1, 1), (2, 255), (3, 256), (5, 1000), (6, 4099)])
+@pytest.mark.parametrize("ch,frames", [(1, 1), (2, 255), (3, 256), (5, 1000), (6, 4099), (1, 5000), (2, 2048),
+                                       (3, 3333), (4, 10240), (5, 7777), (6, 1024)])
 def test_gpu_wav_pack_matches_oracle(pkg, bits, ch, frames):
     lib = _wav_oracle()
     s = _wide_samples(ch, max(frames, 4), frames)[:, :frames].copy()
