@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_mlp_gather(const uint8_t *__restrict__ 
                                                     const uint32_t *__restrict__ sec_base,
                                                     uint8_t *__restrict__ out, uint64_t out_cap)
 {
-    __shared__ uint4 s_sec[4][SECTOR / 16];
+    __shared__ uint4 s_sec[4][SECTOR / 16 + 1];          // + one vector: the funnel shift reads one dword ahead
     __shared__ uint32_t s_pk[4][2 * MAX_PACKETS + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x * 4 + wv;
@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256) void k_mlp_gather(const uint8_t *__restrict__ 
         const uint4 *src = reinterpret_cast<const uint4 *>(sectors + (size_t)s * SECTOR);
         s_sec[wv][lane] = src[lane];
         s_sec[wv][lane + 64] = src[lane + 64];
+        if (lane == 0)
+            s_sec[wv][SECTOR / 16] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     const uint8_t *p = reinterpret_cast<const uint8_t *>(&s_sec[wv][0]);
@@ -234,10 +236,13 @@ __global__ __launch_bounds__(256) void k_mlp_gather(const uint8_t *__restrict__ 
             out[dst + lane] = p[off + lane];
         const uint32_t body = (len - head) >> 2;
         uint32_t *o32 = reinterpret_cast<uint32_t *>(out + dst + head);
+        // the source is byte-aligned inside the sector: two aligned LDS dwords and a funnel shift per
+        // output dword instead of four byte reads
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p) + ((off + head) >> 2);
+        const uint32_t sh = (off + head) & 3u;
         for (uint32_t i = lane; i < body; i += 64) {
-            const uint8_t *c = p + off + head + 4 * i;
             if (dst + head + 4 * i + 4 <= out_cap)
-                o32[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+                o32[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
         }
         const uint32_t done = head + 4 * body;
         if ((uint32_t)lane < len - done && dst + done + lane < out_cap)
