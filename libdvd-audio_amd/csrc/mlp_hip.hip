@@ -536,8 +536,19 @@ extern "C" int dvda_pcm_hip_decode_sectors(const uint8_t *d_sectors, uint32_t n_
         hipLaunchKernelGGL(k_scan_add, dim3(blocks), dim3(1024), 0, st, sec_base, tmp, blocks, n_sectors,
                            (const uint32_t *)nullptr, n_sectors);
     }
-    hipLaunchKernelGGL(pcm::k_pcm_unswizzle, dim3((n_sectors + 3) / 4), dim3(256), 0, st, d_sectors, n_sectors,
-                       bits_per_sample == 24 ? 1u : 0u, channels, sec_base, d_pcm, stride);
+    {
+        const dim3 g((n_sectors + 3) / 4), b(256);
+#define DVDA_PCM_CASE(CH, NB)                                                                                  \
+    case (CH) * 10 + (NB):                                                                                     \
+        hipLaunchKernelGGL((pcm::k_pcm_unswizzle_t<CH, NB>), g, b, 0, st, d_sectors, n_sectors, sec_base, d_pcm, stride); \
+        break;
+        switch (channels * 10 + bits_per_sample / 8) {
+            DVDA_PCM_CASE(1, 2) DVDA_PCM_CASE(2, 2) DVDA_PCM_CASE(3, 2) DVDA_PCM_CASE(4, 2) DVDA_PCM_CASE(5, 2)
+            DVDA_PCM_CASE(6, 2) DVDA_PCM_CASE(1, 3) DVDA_PCM_CASE(2, 3) DVDA_PCM_CASE(3, 3) DVDA_PCM_CASE(4, 3)
+            DVDA_PCM_CASE(5, 3) DVDA_PCM_CASE(6, 3)
+        }
+#undef DVDA_PCM_CASE
+    }
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
 }

@@ -8,9 +8,10 @@
 //                   packets, counts the PCM frames the sector holds (whole chunks only, as
 //                   src/pcm.c:149 does) and records a malformed sector instead of stopping.
 //   (exclusive scan of the per-sector frame counts = each sector's first output frame)
-//   k_pcm_unswizzle one wavefront per sector: the sector is staged in LDS with 16-byte loads,
-//                   each lane un-swizzles one 2-frame chunk (inverse of AOB_BYTE_SWAP) and stores
-//                   8 bytes per channel, so a wavefront writes contiguous runs per channel.
+//   k_pcm_unswizzle_t<CH, NB>  one wavefront per sector: the sector is staged in LDS with 16-byte
+//                   loads, each lane un-swizzles one 2-frame chunk (inverse of AOB_BYTE_SWAP, byte
+//                   permutes with compile-time selectors) and stores 8 bytes per channel, so a
+//                   wavefront writes contiguous runs per channel.
 //
 // Pure byte shuffling: bound by HBM (reads 2048 B, writes <= 2.6 KB per sector).
 #pragma once
@@ -53,14 +54,21 @@ constexpr SwapTables make_tables()
     return t;
 }
 
-__device__ const SwapTables d_tables = make_tables();
-
 constexpr uint32_t SECTOR = 2048;
 constexpr int MAX_PACKETS = 8;           // audio packets per sector the kernels handle (1 in practice)
 
 // Walks the PES packets of one sector.  Calls f(payload_offset, payload_len) for every PCM audio
 // packet (payload = bytes behind the parameter block).  Returns false on a malformed sector.
-template <typename F> __device__ __forceinline__ bool walk_sector(const uint8_t *p, F f, uint32_t want_codec = 0xA0)
+// first bytes of a sector from LDS, the rest (the packet headers near its end) from global memory:
+// the scan kernels stage 48 bytes per sector with coalescable 16-byte loads instead of reading the
+// pack / PES / audio headers byte by byte from HBM
+struct SectorView {
+    const uint8_t *head;     // LDS copy of bytes [0, 48)
+    const uint8_t *all;      // the sector in global memory
+    __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return i < 48u ? head[i] : all[i]; }
+};
+
+template <typename P, typename F> __device__ __forceinline__ bool walk_sector(const P p, F f, uint32_t want_codec = 0xA0)
 {
     if (p[0] != 0 || p[1] != 0 || p[2] != 1 || p[3] != 0xBA)
         return false;
@@ -72,13 +80,13 @@ template <typename F> __device__ __forceinline__ bool walk_sector(const uint8_t 
         if (p[pos] != 0 || p[pos + 1] != 0 || p[pos + 2] != 1 || pos + 6 + plen > SECTOR)
             return false;
         if (id == 0xBD) {                              // AUDIO_STREAM_ID, src/packet.c:119-136
-            const uint8_t *q = p + pos + 6;
+            const uint32_t q = pos + 6;
             if (plen < 7)
                 return false;
-            const uint32_t pad1 = q[2];
+            const uint32_t pad1 = p[q + 2];
             if (plen < 7 + pad1)
                 return false;
-            const uint32_t codec = q[3 + pad1], pad2 = q[6 + pad1];
+            const uint32_t codec = p[q + 3 + pad1], pad2 = p[q + 6 + pad1];
             const uint32_t hdr = 7 + pad1 + pad2;      // the 9-byte parameter block sits inside pad_2
             // PCM: the 9-byte parameter block is part of pad_2; MLP: pad_2 is plain padding
             if (codec != want_codec || (want_codec == 0xA0 && pad2 < 9) || hdr > plen)
@@ -94,12 +102,17 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const uint8_t *__restrict__ se
                                                   uint32_t chunk_size, uint32_t *__restrict__ sec_frames,
                                                   uint32_t *__restrict__ n_bad)
 {
+    __shared__ uint4 s_head[256][3];
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sectors)
         return;
+    const uint8_t *g = sectors + (size_t)s * SECTOR;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        s_head[threadIdx.x][i] = reinterpret_cast<const uint4 *>(g)[i];
+    const SectorView view = {reinterpret_cast<const uint8_t *>(&s_head[threadIdx.x][0]), g};
     uint32_t frames = 0;
-    const bool ok = walk_sector(sectors + (size_t)s * SECTOR,
-                                [&](uint32_t, uint32_t len) { frames += 2 * (len / chunk_size); });
+    const bool ok = walk_sector(view, [&](uint32_t, uint32_t len) { frames += 2 * (len / chunk_size); });
     if (!ok) {
         frames = 0;
         atomicAdd(n_bad, 1u);
@@ -107,25 +120,28 @@ __global__ __launch_bounds__(256) void k_pcm_scan(const uint8_t *__restrict__ se
     sec_frames[s] = frames;
 }
 
-// one wavefront per sector, 4 sectors per 256-thread block
-__global__ __launch_bounds__(256) void k_pcm_unswizzle(const uint8_t *__restrict__ sectors, uint32_t n_sectors,
-                                                       uint32_t bps_index, uint32_t channels,
-                                                       const uint32_t *__restrict__ sec_base,
-                                                       int32_t *__restrict__ out, uint64_t stride)
+// One wavefront per sector, 4 sectors per 256-thread block, the layout known at compile time (one
+// instantiation per channel count and sample width): a lane pulls its whole chunk out of LDS as aligned dwords (one funnel shift each,
+// the chunk starts at any byte), and every sample is two byte-permutes with constant selectors
+// instead of one LDS byte read plus a table read per byte.
+template <int CH, int NB>
+__global__ __launch_bounds__(256) void k_pcm_unswizzle_t(const uint8_t *__restrict__ sectors, uint32_t n_sectors,
+                                                         const uint32_t *__restrict__ sec_base,
+                                                         int32_t *__restrict__ out, uint64_t stride)
 {
-    __shared__ uint4 s_sec[4][SECTOR / 16];
+    constexpr int CS = 2 * CH * NB;                 // bytes per 2-frame chunk
+    constexpr int ND = (CS + 3) / 4;                // dwords that hold a chunk
+    constexpr SwapTables T = make_tables();
+    __shared__ uint4 s_sec[4][SECTOR / 16 + 1];     // + one vector: the funnel shift reads one dword ahead
     __shared__ uint32_t s_pk[4][2 * MAX_PACKETS + 1];
-    __shared__ uint8_t s_inv[36];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x * 4 + wv;
-    const uint32_t nb = bps_index ? 3u : 2u;
-    const uint32_t chunk_size = nb * channels * 2;
-    if (threadIdx.x < 36)
-        s_inv[threadIdx.x] = d_tables.inv[bps_index][channels - 1][threadIdx.x];
     if (s < n_sectors) {
         const uint4 *src = reinterpret_cast<const uint4 *>(sectors + (size_t)s * SECTOR);
         s_sec[wv][lane] = src[lane];
         s_sec[wv][lane + 64] = src[lane + 64];
+        if (lane == 0)
+            s_sec[wv][SECTOR / 16] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     const uint8_t *p = reinterpret_cast<const uint8_t *>(&s_sec[wv][0]);
@@ -147,20 +163,35 @@ __global__ __launch_bounds__(256) void k_pcm_unswizzle(const uint8_t *__restrict
     const bool vec_ok = ((stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
     for (uint32_t k = 0; k < s_pk[wv][0]; k++) {
         const uint32_t off = s_pk[wv][1 + 2 * k], len = s_pk[wv][2 + 2 * k];
-        const uint32_t chunks = len / chunk_size;
+        const uint32_t chunks = len / CS;
         for (uint32_t t = lane; t < chunks; t += 64) {
-            const uint8_t *c = p + off + t * chunk_size;
-            // sample j of the chunk (frame j / channels, channel j % channels), little-endian bytes
-            // j*nb .. j*nb+nb-1 of the un-swizzled block
-            for (uint32_t ch = 0; ch < channels; ch++) {
+            const uint32_t bo = off + t * CS;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(p) + (bo >> 2);
+            const uint32_t sh = bo & 3u;
+            uint32_t d[ND];
+#pragma unroll
+            for (int i = 0; i < ND; i++)
+                d[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);     // chunk byte 4i.. in d[i]
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) {
                 int32_t v[2];
 #pragma unroll
                 for (int fr = 0; fr < 2; fr++) {
-                    const uint32_t j = fr * channels + ch;
-                    uint32_t u = 0;
-                    for (uint32_t b = 0; b < nb; b++)
-                        u |= (uint32_t)c[s_inv[j * nb + b]] << (8 * b);
-                    v[fr] = nb == 2 ? (int32_t)(int16_t)u : ((int32_t)(u << 8) >> 8);   // src/pcm.c:172-193
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int j = fr * CH + ch;
+                    // little-endian byte b of sample j sits at chunk byte T.inv[..][j * NB + b]
+                    const int p0 = T.inv[NB - 2][CH - 1][j * NB + 0], p1 = T.inv[NB - 2][CH - 1][j * NB + 1];
+                    const uint32_t sel01 = (uint32_t)(p0 & 3) | ((uint32_t)(4 + (p1 & 3)) << 8) | 0x0C0C0000u;
+                    uint32_t u = __builtin_amdgcn_perm(d[p1 >> 2], d[p0 >> 2], sel01);
+                    if (NB == 3) {
+                        const int p2 = T.inv[NB - 2][CH - 1][j * NB + (NB == 3 ? 2 : 0)];
+                        const uint32_t sel2 = 0x0C000100u | ((uint32_t)(4 + (p2 & 3)) << 16);
+                        u = __builtin_amdgcn_perm(d[p2 >> 2], u, sel2);
+                        v[fr] = (int32_t)(u << 8) >> 8;                     // src/pcm.c:172-193
+                    } else {
+                        v[fr] = (int32_t)(int16_t)u;
+                    }
                 }
                 int32_t *dst = out + (uint64_t)ch * stride + frame0 + 2 * t;
                 if (vec_ok && (((frame0 + 2 * t) & 1) == 0))
@@ -183,11 +214,17 @@ __global__ __launch_bounds__(256) void k_mlp_sector_scan(const uint8_t *__restri
                                                          uint32_t *__restrict__ sec_bytes,
                                                          uint32_t *__restrict__ n_bad)
 {
+    __shared__ uint4 s_head[256][3];
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sectors)
         return;
+    const uint8_t *g = sectors + (size_t)s * SECTOR;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        s_head[threadIdx.x][i] = reinterpret_cast<const uint4 *>(g)[i];
+    const SectorView view = {reinterpret_cast<const uint8_t *>(&s_head[threadIdx.x][0]), g};
     uint32_t bytes = 0;
-    const bool ok = walk_sector(sectors + (size_t)s * SECTOR, [&](uint32_t, uint32_t len) { bytes += len; }, 0xA1);
+    const bool ok = walk_sector(view, [&](uint32_t, uint32_t len) { bytes += len; }, 0xA1);
     if (!ok) {
         bytes = 0;
         atomicAdd(n_bad, 1u);
