@@ -265,8 +265,10 @@ static int parse_matrices(bits_t *b, substream_t *s, unsigned *envelope)
     unsigned m, c;
     s->matrix_len = rd(b, 4);
     if (s->matrix_len > MAX_MATRICES) {
-        /* the reference does not check and overruns its array */
+        /* the reference does not check and overruns its array; the restatement reports it and
+           keeps a state it can go on with (the decoder is fed further packets in the tests) */
         *envelope = 1;
+        s->matrix_len = 0;
         return 0;
     }
     for (m = 0; m < s->matrix_len; m++) {
@@ -418,8 +420,14 @@ static int parse_decoding_params(bits_t *b, substream_t *s, int header, unsigned
             else if (header)
                 cp->huffman_offset = 0;
             cp->codebook = rd(b, 2);
-            if ((cp->huffman_lsbs = rd(b, 5)) > 24)
-                return 0;
+            {
+                /* the reference stores the value and then fails; a later block would shift by it
+                   (undefined there): the restatement fails without keeping it */
+                const unsigned lsbs = rd(b, 5);
+                if (lsbs > 24)
+                    return 0;
+                cp->huffman_lsbs = lsbs;
+            }
         } else if (header) {
             cp->fir.shift = 0;
             cp->fir.order = 0;
@@ -643,6 +651,11 @@ static void rematrix(mlp_oracle *d, substream_t *s)
                 d->status |= MLP_ORA_ERR_ENVELOPE; /* reads an empty channel there */
         if (mp->bypassed_len < rows)
             d->status |= MLP_ORA_ERR_ENVELOPE;     /* reads stale bypass bits there */
+        if (mp->out_channel >= MAX_CHANNELS) {     /* matrix kept from a wider restart header: the
+                                                      reference writes past framelist[8] there */
+            d->status |= MLP_ORA_ERR_ENVELOPE;
+            continue;
+        }
         for (i = 0; i < rows; i++) {
             int64_t sum = 0;
             for (c = 0; c <= s->max_matrix_ch; c++)
