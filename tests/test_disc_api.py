@@ -113,3 +113,29 @@ def test_pcm_tracks_and_gpu_wav_payload(pkg, oracle):
         assert np.array_equal(np.concatenate([a["pcm"], b["pcm"]]), pcm)
         w = pkg.discdec.read_track(ats, 1, 1, 1, wav=True)
         assert w["payload"] == oracle.wav_pack(a["pcm"].T, 24)
+
+
+REF_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_ref")
+NATIVE_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_native")
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_INFO) and os.path.exists(NATIVE_INFO)),
+                    reason="reference tools not built (dev container only)")
+def test_reference_debug_info_utility_prints_the_same_table(pkg):
+    """The reference's utils/dvda-debug-info.c linked against libdvd_audio_hip.so prints, byte for
+    byte, what the all-reference build prints (title / track / PTS / sector table).  No decoder is
+    involved, so this runs on the CPU."""
+    import subprocess
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "libdvd-audio_amd") + ":/opt/rocm/lib:" +
+               os.environ.get("LD_LIBRARY_PATH", ""))
+    with tempfile.TemporaryDirectory() as tmp:
+        titles, _ = _titles(pkg)
+        rng = np.random.RandomState(3)
+        pcm = rng.randint(-32768, 32768, size=(3000, 2))
+        secs = pkg.disc.pcm_track_sectors(pcm, 0, 0, 1)
+        titles.append(pkg.disc.split_tracks(secs, [2, 4], [1004, 1004, 992], 0))
+        ats = pkg.disc.write_disc_titles(tmp, titles)
+        a = subprocess.run([REF_INFO, "-A", ats], capture_output=True, text=True, timeout=120)
+        b = subprocess.run([NATIVE_INFO, "-A", ats], capture_output=True, text=True, timeout=120, env=env)
+        assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+        assert a.stdout == b.stdout and "Title  Track" in a.stdout and a.stdout.count("\n") >= 10
