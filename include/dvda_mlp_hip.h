@@ -156,6 +156,11 @@ int dvda_mlp_hip_set_initial_fir(dvda_mlp_hip_ctx *ctx, const int32_t *d_init_fi
 
 const char *dvda_mlp_hip_version(void);
 
+/* Self-test: runs the kernels' arithmetic code-book decode on the device for every (book 0..3,
+ * 9-bit peek) and returns host_out[book * 512 + peek] = value | length << 8 (value 0xFF = invalid
+ * code; book 0 = no code = 0).  The tables it must equal are reference src/mlp_codebook{1,2,3}.json. */
+int dvda_mlp_hip_selftest_huff(int device, uint32_t *host_out);
+
 /* ------------------------------------------------------------------ PCM tier */
 /* Raw-PCM AOB tracks: what reference src/dvd-audio.c:1016-1084 (decode_pcm_audio),
  * src/packet.c:61-188 (pack header / PES walk) and src/pcm.c:99-193 (AOB byte un-swizzle, sign

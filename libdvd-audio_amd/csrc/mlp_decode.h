@@ -384,23 +384,24 @@ struct BitReader {
     }
 };
 
-// Arithmetic, branch-free decode of the three code books (mlp_tables.h: huff_entry):
-// returns value | length << 8, value 0xFF for the two invalid codes.  cb in 1..3.
+// Arithmetic, branch-free decode of the three code books (mlp_tables.h: huff_entry) from a 9-bit
+// peek t: returns value | length << 8, value 0xFF for the two invalid codes of a book, and 0 (no
+// bits, value 0) for "book" 0 = no code.  Checked exhaustively against the table by
+// dvda_mlp_hip_selftest_huff (tests/test_gpu_parity.py).
 __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 {
-    // "1" + (3 - cb) bits -> 7 + bits, length 4 - cb
-    const uint32_t sub = 3u - cb;
-    const uint32_t bits = (t >> (8u - sub)) & ((1u << sub) - 1u);
-    const uint32_t a = (7u + bits) | ((sub + 1u) << 8);
+    // "1" + (3 - cb) bits -> 7 + bits, length 4 - cb: the bits are the top of the low byte
+    const uint32_t a = (((t & 0xFFu) >> (5u + cb)) + 7u) | ((4u - cb) << 8);
     // "0"^z "1" (z = 2..8) -> 8 - z ; "01" "0"^k "1" -> base + k : both are z' = leading zeros of
     // the low 7 bits, length z' + 3
     const uint32_t r = t & 0x7Fu;
     const uint32_t z = (uint32_t)__clz((int)r) - 25u;        // 7 if r == 0
-    const uint32_t base = cb == 1u ? 11u : (cb == 2u ? 9u : 8u);
+    const uint32_t base = (0x08090B08u >> (8u * cb)) & 0xFFu; // 11, 9, 8 for books 1, 2, 3
     uint32_t val = (t & 0x80u) ? base + z : 6u - z;
     val = z > 6u ? 0xFFu : val;
     const uint32_t b = val | (((z > 6u ? 6u : z) + 3u) << 8);
-    return (t & 0x100u) ? a : b;
+    const uint32_t e = (t & 0x100u) ? a : b;
+    return cb ? e : 0u;
 }
 
 // ----------------------------------------------------------------------------
@@ -1188,9 +1189,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 const uint32_t cand1 = __builtin_bswap32(look[0]), cand2 = __builtin_bswap32(look[64]);
                 const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
                 const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
-                const uint32_t e = huff_decode(cb ? cb : 1u, top >> 23);
-                const uint32_t msb = cb ? (e & 0xFFu) : 0u;
-                const uint32_t len = cb ? (e >> 8) : 0u;
+                const uint32_t e = huff_decode(cb, top >> 23);
+                const uint32_t msb = e & 0xFFu;
+                const uint32_t len = e >> 8;
                 msb_or |= msb;                            // valid values are < 0x20
                 const uint32_t o2 = rd.ofs + len;
                 const uint32_t top2 = (uint32_t)((win << o2) >> 32);
@@ -1485,6 +1486,14 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
     }
     (void)seg;
     streams[s] = r;
+}
+
+// every (book, 9-bit peek) through the device decode (dvda_mlp_hip_selftest_huff)
+__global__ void k_selftest_huff(uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * 512)
+        out[i] = huff_decode(i >> 9, i & 511u);
 }
 
 } // namespace mlp

@@ -447,6 +447,20 @@ extern "C" int dvda_mlp_hip_debug_counters(dvda_mlp_hip_ctx *c, unsigned long lo
     return DVDA_HIP_OK;
 }
 
+// host_out[book * 512 + peek9] = value | length << 8 as the row loop's arithmetic code-book decode sees it
+extern "C" int dvda_mlp_hip_selftest_huff(int device, uint32_t *host_out)
+{
+    if (!host_out)
+        return DVDA_HIP_EINVAL;
+    uint32_t *d = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc((void **)&d, 4 * 512 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_selftest_huff, dim3(8), dim3(256), 0, 0, d);
+    const hipError_t e = hipMemcpy(host_out, d, 4 * 512 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return e == hipSuccess ? DVDA_HIP_OK : DVDA_HIP_ENODEV;
+}
+
 extern "C" int dvda_mlp_hip_set_initial_fir(dvda_mlp_hip_ctx *c, const int32_t *d_init_fir)
 {
     if (!c)

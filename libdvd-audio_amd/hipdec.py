@@ -37,7 +37,7 @@ _lib = None
 
 EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
            "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
-           "dvda_mlp_hip_version", "dvda_mlp_hip_set_lanes_per_segment", "dvda_mlp_hip_segment_info",
+           "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_set_lanes_per_segment", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
            "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",

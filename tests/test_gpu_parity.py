@@ -372,3 +372,25 @@ def test_widest_symbols_step_the_bit_window_by_two_dwords(pkg, oracle, codebook)
                            restart_interval=1 + seed, codebook=codebook, huffman_lsbs=24)
         cases.append((cfg, 31000 + 10 * codebook + seed))
     _check(pkg, oracle, cases, lanes=2)
+
+
+@pytest.mark.gpu
+def test_device_code_book_decode_equals_the_tables_exhaustively(pkg, oracle):
+    """The row loop decodes the three code books arithmetically (no table).  Every (book, 9-bit peek)
+    is run through that device function and compared with the oracle's tables (= reference
+    src/mlp_codebook{1,2,3}.json); book 0 (no code) must read as value 0, length 0."""
+    import ctypes
+    L = pkg.hipdec.lib()
+    out = (ctypes.c_uint32 * (4 * 512))()
+    L.dvda_mlp_hip_selftest_huff.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    assert L.dvda_mlp_hip_selftest_huff(0, out) == 0
+    got = np.array(list(out), np.uint32).reshape(4, 512)
+    assert not got[0].any()
+    ol = oracle.lib
+    for book in (1, 2, 3):
+        for peek in range(512):
+            want = ol.mlp_oracle_test_huff(book, peek)
+            if (want & 0xFF) == 0xFF:
+                assert (int(got[book, peek]) & 0xFF) == 0xFF, (book, peek)
+            else:
+                assert int(got[book, peek]) == want, (book, peek, hex(int(got[book, peek])), hex(want))
