@@ -394,8 +394,8 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
     const uint32_t a = (((t & 0xFFu) >> (5u + cb)) + 7u) | ((4u - cb) << 8);
     // "0"^z "1" (z = 2..8) -> 8 - z ; "01" "0"^k "1" -> base + k : both are z' = leading zeros of
     // the low 7 bits, length z' + 3
-    const uint32_t r = t & 0x7Fu;
-    const uint32_t z = (uint32_t)__clz((int)r) - 25u;        // 7 if r == 0
+    // (the low 7 bits moved to the top of a word with a sentinel 1 behind them: clz is 0..7 at once)
+    const uint32_t z = (uint32_t)__clz((int)((t << 25) | 0x01000000u));   // 7 if the low 7 bits are 0
     const uint32_t base = (0x08090B08u >> (8u * cb)) & 0xFFu; // 11, 9, 8 for books 1, 2, 3
     uint32_t val = (t & 0x80u) ? base + z : 6u - z;
     val = z > 6u ? 0xFFu : val;
