@@ -11,14 +11,15 @@
 // loops; only header parses diverge.
 //
 // Memory behaviour (what the v1 profile asked for, profiles/r01_v1_pmc_summary.txt):
-//   * compressed bytes reach a lane through a private 256-byte LDS ring filled by
-//     whole 64-byte chunks, prefetched one row ahead of use, so every input line
-//     is fetched from HBM once and no global load sits on the serial parse chain;
-//     the CRC-8/parity check rides on the ring consumption (each dword passes once)
+//   * compressed bytes reach a lane through a private 128-byte LDS ring filled by
+//     whole 64-byte chunks, prefetched one row ahead of use, so no global load sits on
+//     the serial parse chain; the CRC-8/parity check rides on the ring consumption
+//     (each dword passes once)
 //   * residuals, FIR history/coefficients, codebook parameters and the first two
 //     matrices live in VGPRs; nothing between the ring and the PCM store touches
 //     memory (cold state only: IIR taps, matrices 3..6 in a workspace)
-//   * PCM leaves as 16-byte stores (4 frames x 1 channel per lane)
+//   * PCM leaves as 16-byte stores (4 frames x 1 channel per lane, staged in an LDS tile),
+//     issued after the ring commit so that no s_waitcnt counts them
 //   * Huffman codes are decoded arithmetically (the three books share one
 //     structure, mlp_tables.h) -- no table, no LDS latency on the parse chain
 //
@@ -30,7 +31,7 @@
 // shift once per FRAME with the parameters left by the frame's LAST block; this
 // kernel applies them per row with the parameters in force, which is identical
 // unless a later block of the same frame changes matrix-class parameters -- that
-// case is detected and reported as DVDA_ST_MIDFRAME (never silently decoded).
+// case is detected (DVDA_ST_MIDFRAME) and decoded frame-buffered by the general pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
