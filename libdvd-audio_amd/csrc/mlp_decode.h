@@ -649,9 +649,20 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             // the compiler turns it back into "compare, and with the mask, wait state, select" per channel
             uint32_t oce = on ? oc : 0xFFu;                      // oc <= max_matrix_channel (checked)
             asm volatile("" : "+v"(oce));
+            // six compares first, six selects after: back to back, every select would wait two states
+            // for its compare (the assembler pads them with s_nop)
+            uint64_t hit[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++)
-                ch[c] = ((uint32_t)c == oce) ? nv : ch[c];
+            for (int c = 0; c < 6; c++) {
+                hit[c] = __builtin_amdgcn_ballot_w64((uint32_t)c == oce);
+                asm volatile("" : "+s"(hit[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                int32_t keep = ch[c];
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(keep) : "v"(nv), "s"(hit[c]));
+                ch[c] = keep;
+            }
         };
         if (__any(matrix_len > 0))
             one_matrix(mreg[0], mnoise[0], 0, matrix_len > 0);
@@ -1201,10 +1212,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 const uint32_t adv = o3 >> 5;                             // 0, 1 or 2 dwords consumed
                 // a symbol rarely spans two whole dwords (ofs + code + LSBs >= 64): the one-dword step is
                 // the straight path, the second step sits behind a wave-uniform test
-                const bool step = adv != 0;
-                uint32_t nh = step ? rd.lo : rd.hi;
-                uint32_t nl = step ? rd.nx : rd.lo;
-                uint32_t nn = step ? cand1 : rd.nx;
+                // (the compare is issued here and the selects a few instructions later: back to back the
+                //  first select waits two states for it)
+                uint64_t step = __builtin_amdgcn_ballot_w64(adv != 0);
+                asm volatile("" : "+s"(step));
+                const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
+                uint32_t nh = rd.hi, nl = rd.lo, nn = rd.nx;
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(nh) : "v"(rd.lo), "s"(step));
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(nl) : "v"(rd.nx), "s"(step));
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(nn) : "v"(cand1), "s"(step));
                 if (__builtin_expect(__any(adv == 2), 0)) {
                     const bool two = adv == 2;
                     if (two && in)
@@ -1218,7 +1234,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 rd.nx = nn;
                 rd.next += adv;
                 rd.ofs = o3 & 31u;
-                const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
                 // ---- FIR/IIR reconstruction (src/mlp.c:1278-1300)
                 int64_t acc0 = (int64_t)lo16(cf[k][0]) * (int64_t)st[k][0];
                 int64_t acc1 = (int64_t)hi16(cf[k][0]) * (int64_t)st[k][1];
