@@ -650,7 +650,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
             uint32_t oce = on ? oc : 0xFFu;                      // oc <= max_matrix_channel (checked)
             asm volatile("" : "+v"(oce));
             // six compares first, six selects after: back to back, every select would wait two states
-            // for its compare (the assembler pads them with s_nop)
+            // for its compare (gfx940+: VALU writes an SGPR -> VALU reads it, no hardware interlock;
+            // the compiler pads its own pairs with s_nop).  Inline asm is NOT padded by the compiler:
+            // tools/hazard_check.py (run by tests/test_cabi.py on every build) verifies the distance.
             uint64_t hit[6];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 // a symbol rarely spans two whole dwords (ofs + code + LSBs >= 64): the one-dword step is
                 // the straight path, the second step sits behind a wave-uniform test
                 // (the compare is issued here and the selects a few instructions later: back to back the
-                //  first select waits two states for it)
+                //  first select waits two states for it; distance verified by tools/hazard_check.py)
                 uint64_t step = __builtin_amdgcn_ballot_w64(adv != 0);
                 asm volatile("" : "+s"(step));
                 const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);

@@ -61,3 +61,16 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
                 text = open(os.path.join(base, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "libmlp_oracle" not in text and "libdvda_ref" not in text, f
+
+
+def test_inline_asm_selects_keep_the_sgpr_hazard_distance():
+    """The decode kernels hold a few v_cndmask selects as inline asm so that their compares can be
+    issued ahead of them; LLVM does not pad inline asm for the gfx940+ 'VALU writes SGPR -> VALU
+    reads SGPR' hazard (2 wait states, no hardware interlock).  tools/hazard_check.py compiles the
+    kernels to assembly and verifies the distance for every such select."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hazard_check.py")], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "hazard violations: 0" in r.stdout

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""tools/hazard_check.py [file.s] -- static check of the inline-asm selects in the decode kernels.
+
+gfx940+ needs two wait states between a VALU instruction that writes an SGPR (v_cmp ... s[a:b]) and a
+VALU instruction that reads it; the hardware does not interlock and LLVM's hazard recogniser pads
+compiler-generated pairs with s_nop -- but it does not look into inline asm.  csrc/mlp_decode.h places
+a few v_cndmask_b32_e64 selects as inline asm precisely so that their compares can be issued well
+ahead (no padding).  This script compiles csrc/mlp_hip.hip to assembly (or reads the given .s) and
+verifies, for every such select in every kernel, that at least two wait states separate it from the
+definition of its mask in the same basic block.  tests/test_cabi.py runs it on every build."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def check(path):
+    L = open(path).read().split('\n')
+    viol, checked, unknown = [], 0, 0
+    for i, l in enumerate(L):
+        t = l.strip()
+        if not t.startswith('v_cndmask_b32_e64'):
+            continue
+        if 'ASMSTART' not in L[i - 1] and not (L[i - 1].strip().startswith('s_nop') and 'ASMSTART' in L[i - 2]):
+            continue                                   # compiler-generated: padded by the compiler
+        m = re.search(r'(s\[\d+:\d+\])\s*$', t)
+        if not m:
+            continue
+        sg, ws, k, found = m.group(1), 0, i - 1, None
+        while k >= 0:
+            p = L[k].strip()
+            if not p or p.startswith(';') or (p.startswith('.') and not p.endswith(':')):
+                k -= 1
+                continue
+            if p.endswith(':'):
+                found = ('label', p)
+                break
+            mm = re.match(r'^(\S+)\s+(\S+?),', p)
+            if mm and mm.group(2) == sg:
+                found = ('def', p)
+                break
+            n = re.match(r'^s_nop\s+(\d+)', p)
+            ws += (int(n.group(1)) + 1) if n else 1
+            k -= 1
+        checked += 1
+        if found is None or found[0] == 'label':
+            unknown += 1
+        elif found[1].startswith('v_') and ws < 2:
+            viol.append((i + 1, ws, found[1], t))
+    return checked, unknown, viol
+
+
+def main():
+    if len(sys.argv) > 1:
+        path = sys.argv[1]
+    else:
+        out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+        hipcc = "/opt/rocm/bin/hipcc"
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(ROOT, "libdvd-audio_amd", "csrc", "mlp_hip.hip")], check=True,
+                       stderr=subprocess.DEVNULL)
+        path = out
+    checked, unknown, viol = check(path)
+    print("inline-asm selects: %d, mask defined in another block: %d, hazard violations: %d" % (checked, unknown, len(viol)))
+    for v in viol[:10]:
+        print("  line %d: %d wait state(s) after `%s` before `%s`" % v)
+    return 1 if (viol or unknown or checked == 0) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
