@@ -50,6 +50,27 @@ def check(path):
             unknown += 1
         elif found[1].startswith('v_') and ws < 2:
             viol.append((i + 1, ws, found[1], t))
+    # asm PCM stores (global_store_dwordx4 ..., v[x:y], off): GFX9 wants one wait state between a VALU
+    # write of store data wider than 64 bits and the store
+    for i, l in enumerate(L):
+        t = l.strip()
+        if not t.startswith('global_store_dwordx4') or 'ASMSTART' not in L[i - 1]:
+            continue
+        m = re.search(r'v\[(\d+):(\d+)\], off', t)
+        if not m:
+            continue
+        lo, hi = int(m.group(1)), int(m.group(2))
+        k = i - 2
+        while k >= 0 and (not L[k].strip() or L[k].strip().startswith(';')):
+            k -= 1
+        p = L[k].strip()
+        checked += 1
+        mm = re.match(r'^(v_\S+)\s+v\[?(\d+)(?::(\d+))?\]?', p)
+        if mm:
+            a = int(mm.group(2))
+            b = int(mm.group(3)) if mm.group(3) else a
+            if not (b < lo or a > hi):
+                viol.append((i + 1, 0, p, t))
     return checked, unknown, viol
 
 
