@@ -42,6 +42,8 @@ namespace mlp {
 
 constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
+// fast pass over two-substream streams: one wave per (64 segments, substream); see k_decode
+constexpr int WS_THREADS = 256;
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
 #ifndef DVDA_RING_PLANES
@@ -416,23 +418,40 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 //   stream whose access units do not have the standard length -- decodes the whole stream in
 //   order with a running output position.
 template <int NS, bool PAIRED, bool GENERAL>
-__global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
+__global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     if (GENERAL && *a.deferred == 0)
         return;                                                   // nothing was deferred: whole grid exits
     __shared__ uint8_t s_crc[4 * 256];
-    __shared__ uint32_t s_ring[DEC_WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
-    __shared__ int32_t s_out[GENERAL ? 1 : DEC_WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
-    __shared__ int32_t s_xch[PAIRED ? DEC_WAVES : 1][MAXCH][PAIRED ? 64 : 1];
+    // fast pass over two-substream streams: a wave carries ONE substream of 64 segments (the short
+    // substream's wave then runs only its own two slots and no rematrix); the two waves of a group
+    // trade a row's channels through s_xw[row parity], one block barrier per row: wave w of a block
+    // is substream w & 1 of segment group w >> 1.  (Measured on the 2-substream bench shape: 100 ->
+    // 114 Gsamples/s over the lane-pair layout, which ran every wave through the long substream's
+    // slots and the rematrix; 2-, 4- and 8-wave blocks and the order of the roles were tried, 4 waves
+    // = two blocks per CU mixes short and long waves on the SIMDs best.)
+    constexpr bool WSPEC = PAIRED && !GENERAL;
+    constexpr int THREADS = WSPEC ? WS_THREADS : DEC_THREADS;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int GROUPS = WSPEC ? WAVES / 2 : 1;
+    __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
+    __shared__ int32_t s_out[GENERAL ? 1 : WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
+    __shared__ int32_t s_xch[(PAIRED && GENERAL) ? WAVES : 1][MAXCH][(PAIRED && GENERAL) ? 64 : 1];
+    __shared__ int32_t s_xw[WSPEC ? 2 : 1][GROUPS][MAXCH][WSPEC ? 64 : 1];
+    __shared__ uint32_t s_alive[2][WAVES];
 
-    for (int i = threadIdx.x; i < 4 * 256; i += DEC_THREADS)
+    for (int i = threadIdx.x; i < 4 * 256; i += THREADS)
         s_crc[i] = d_crc.t[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const uint32_t gl = blockIdx.x * DEC_THREADS + threadIdx.x;
+    // workspace lane = segment * L + substream in every layout
+    const uint32_t ws_grp = (uint32_t)wv >> 1;
+    const uint32_t ws_sub = (uint32_t)wv & 1u;
+    const uint32_t gl = WSPEC ? ((blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane) * 2u + ws_sub
+                              : blockIdx.x * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
@@ -693,6 +712,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = clock64();
 #endif
+    uint32_t rows_iter = 0;            // two-wave layout: parity of the exchange buffer
     for (;;) {
         DVDA_STAMP(5);
         // =================================================== header phase
@@ -1115,8 +1135,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 }
             }
         }
-        if (!__any(active))
-            break;
+        if (!WSPEC && !__any(active))
+            break;                     // (two-wave layout: the block leaves together, at the exchange)
         DVDA_STAMP(0);
 
         // ====================================================== row phase
@@ -1160,11 +1180,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         }
         DVDA_STAMP(1);
 
-        if (active) {
+        uint32_t bypass_bits = 0;
+        int32_t val[WSPEC ? 1 : NS];
+        const uint32_t par = rows_iter & 1u;           // two-wave layout: exchange tile of this row
+        rows_iter++;
+        int32_t *const xw_mine = &s_xw[WSPEC ? par : 0][WSPEC ? ws_grp : 0][0][WSPEC ? lane : 0] + (WSPEC ? min_ch * 64u : 0u);
+        auto row_head = [&]() {
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
             // all of the row's bypassed LSBs (at most one per matrix) are cut from the window at once
             // and dealt to their matrices in stream order -- straight-line, no per-bit read
-            uint32_t bypass_bits = 0;
             if (__any(bypass_mask != 0)) {
                 const uint32_t cnt = (uint32_t)__popc(bypass_mask);          // <= MAXMAT
                 const uint32_t field = rd.read_resident(cnt);
@@ -1183,7 +1207,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     }
                 }
             }
-            int32_t val[NS];
             uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
             const bool wave_iir = __any(iir_any != 0); // IIR taps anywhere in the wave (rare)
 #pragma unroll
@@ -1192,7 +1215,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
                 const bool in = (uint32_t)k < nslots;
                 if (k >= 2 && !__any(in)) {
-                    val[k] = 0;
+                    if constexpr (!WSPEC)
+                        val[k] = 0;
                     continue;
                 }
                 const uint32_t pkk = in ? pk[k] : 0u;
@@ -1266,38 +1290,20 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                         iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
                                  (int32_t)((uint32_t)value - (uint32_t)ssum));
                 }
-                val[k] = in ? value : 0;
+                if constexpr (WSPEC) {
+                    if (in)
+                        xw_mine[k * 64] = value;          // straight to the exchange tile
+                } else {
+                    val[k] = in ? value : 0;
+                }
             }
             if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {
                 status |= ST_HUFFMAN;
                 active = false;
             }
             DVDA_STAMP(2);
-
-            // ---- gather the frame's channels 0..7 for the rematrix
-            int32_t ch[MAXCH];
-            if (PAIRED) {
-                // substreams of one segment sit in adjacent lanes; exchange through LDS
-                const int slot0 = PAIRED ? (lane & ~1) : 0;
-                int32_t(*X)[PAIRED ? 64 : 1] = s_xch[PAIRED ? wv : 0];
-#pragma unroll
-                for (int k = 0; k < NS; k++)
-                    if ((uint32_t)k < nslots && min_ch + k < MAXCH)
-                        X[min_ch + k][slot0] = val[k];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int c = 0; c < MAXCH; c++)
-                    ch[c] = X[c][slot0];
-            } else {
-                // one lane per segment: the single substream starts at channel 0 (checked at the
-                // restart header)
-#pragma unroll
-                for (int c = 0; c < MAXCH; c++)
-                    ch[c] = c < NS ? val[c < NS ? c : 0] : 0;
-            }
-
+        };
+        auto row_tail = [&](int32_t (&ch)[MAXCH]) {
             if (is_last_sub) {
                 if (GENERAL) {
                     // ---- general pass: park the filtered frame; it is rematrixed at the end of
@@ -1407,6 +1413,53 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     active = false;
                 }
             }
+        };
+        // ---- the frame's channels 0..7 come together for the rematrix
+        int32_t ch[MAXCH];
+        const bool in_row = active;
+        if constexpr (WSPEC) {
+            if (in_row)
+                row_head();
+            int32_t(*X)[WSPEC ? 64 : 1] = s_xw[WSPEC ? par : 0][WSPEC ? ws_grp : 0];
+            const uint32_t wave_alive = __any(in_row) ? 1u : 0u;     // (over the whole wave: outside the branch)
+            if (lane == 0)
+                s_alive[par][wv] = wave_alive;
+            // LDS only: the chunk in flight and the PCM stores are not waited for
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!__any(lane < WAVES && s_alive[par][lane < WAVES ? lane : 0] != 0))
+                break;
+            if (in_row) {
+                if (is_last_sub) {
+#pragma unroll
+                    for (int c = 0; c < MAXCH; c++)
+                        ch[c] = X[c][lane];
+                }
+                row_tail(ch);
+            }
+        } else if (in_row) {
+            row_head();
+            if (PAIRED) {
+                // substreams of one segment sit in adjacent lanes; exchange through LDS
+                const int slot0 = PAIRED ? (lane & ~1) : 0;
+                int32_t(*X)[(PAIRED && GENERAL) ? 64 : 1] = s_xch[(PAIRED && GENERAL) ? wv : 0];
+#pragma unroll
+                for (int k = 0; k < NS; k++)
+                    if ((uint32_t)k < nslots && min_ch + k < MAXCH)
+                        X[min_ch + k][slot0] = val[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < MAXCH; c++)
+                    ch[c] = X[c][slot0];
+            } else {
+                // one lane per segment: the single substream starts at channel 0 (checked at the
+                // restart header)
+#pragma unroll
+                for (int c = 0; c < MAXCH; c++)
+                    ch[c] = c < NS ? val[c < NS ? c : 0] : 0;
+            }
+            row_tail(ch);
         }
         DVDA_STAMP(3);
 

@@ -327,6 +327,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
     const uint64_t lanes = (uint64_t)c->max_segments * lanes_per_seg;
     const unsigned blocks = (unsigned)((lanes + DEC_THREADS - 1) / DEC_THREADS);
+    const unsigned ws_blocks = (unsigned)((lanes + WS_THREADS - 1) / WS_THREADS);   // fast pass, two substreams
 
     if (c->ev_used + 2 > c->ev.size()) {
         hipEvent_t e0, e1;
@@ -338,7 +339,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     HIP_TRY(hipEventRecord(c->ev[c->ev_used], st));
     // fast pass (timed: the dominant kernel)
     if (lanes_per_seg == 2)
-        hipLaunchKernelGGL((k_decode<6, true, false>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
+        hipLaunchKernelGGL((k_decode<6, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
     HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], st));
