@@ -55,7 +55,12 @@ constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
 #ifndef DVDA_OUT_ROWS
 #define DVDA_OUT_ROWS 4
 #endif
-constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel: 8 = one 32-byte sector per flush
+constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel and flush
+// (8 frames = whole 32-byte sectors and half the write requests, 16 = whole 64-byte writes, which the
+//  memory side takes 4 x faster than partial ones -- tools/fetch_calib.hip.  Neither fits: four
+//  2-wave workgroups share a CU only up to ~31 KB of LDS each (measured: 30 208 B fits, 32 256 B
+//  drops to three), the ring and the CRC tables take 17.9 KB, and an 8-frame tile, even with its
+//  last frame kept in registers, needs 21.5 KB.)
 
 // Diagnostic build switches (tools/ab_bench.sh): never defined in the shipped library.
 //   DVDA_EXP_NOSTORE  keep PCM values alive but do not store them (prices the write path)
@@ -399,8 +404,11 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
     // the low 7 bits, length z' + 3
     // (the low 7 bits moved to the top of a word with a sentinel 1 behind them: clz is 0..7 at once)
     const uint32_t z = (uint32_t)__clz((int)((t << 25) | 0x01000000u));   // 7 if the low 7 bits are 0
-    const uint32_t base = (0x08090B08u >> (8u * cb)) & 0xFFu; // 11, 9, 8 for books 1, 2, 3
-    uint32_t val = (t & 0x80u) ? base + z : 6u - z;
+    const uint32_t base = __builtin_amdgcn_ubfe(0x08090B08u, 8u * cb, 8u); // 11, 9, 8 for books 1, 2, 3
+    // both arms computed, one select: left to itself the compiler branches around them per lane
+    uint32_t up = base + z, dn = 6u - z;
+    asm volatile("" : "+v"(up), "+v"(dn));
+    uint32_t val = (t & 0x80u) ? up : dn;
     val = z > 6u ? 0xFFu : val;
     const uint32_t b = val | (((z > 6u ? 6u : z) + 3u) << 8);
     const uint32_t e = (t & 0x100u) ? a : b;
@@ -424,19 +432,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     if (GENERAL && *a.deferred == 0)
         return;                                                   // nothing was deferred: whole grid exits
     __shared__ uint8_t s_crc[4 * 256];
-    // fast pass over two-substream streams: a wave carries ONE substream of 64 segments (the short
-    // substream's wave then runs only its own two slots and no rematrix); the two waves of a group
-    // trade a row's channels through s_xw[row parity], one block barrier per row: wave w of a block
-    // is substream w & 1 of segment group w >> 1.  (Measured on the 2-substream bench shape: 100 ->
-    // 114 Gsamples/s over the lane-pair layout, which ran every wave through the long substream's
-    // slots and the rematrix; 2-, 4- and 8-wave blocks and the order of the roles were tried, 4 waves
-    // = two blocks per CU mixes short and long waves on the SIMDs best.)
+    // fast pass over two-substream streams: a wave carries ONE substream of 64 segments.  The odd
+    // wave of a group has each segment's last substream (the only one of a single-substream stream):
+    // it gathers the row's channels, rematrixes, stages and stores.  The even wave has the first
+    // substream of the two-substream streams: its own (typically two) slots and nothing else.  The
+    // pair trades a row's channels through s_xw[row parity], one block barrier per row.  (Measured
+    // on the 2-substream bench shape against the lane-pair layout, which ran every wave through the
+    // long substream's slots and the rematrix; 2-, 4- and 8-wave blocks were tried.)
     constexpr bool WSPEC = PAIRED && !GENERAL;
     constexpr int THREADS = WSPEC ? WS_THREADS : DEC_THREADS;
     constexpr int WAVES = THREADS / 64;
     constexpr int GROUPS = WSPEC ? WAVES / 2 : 1;
     __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
-    __shared__ int32_t s_out[GENERAL ? 1 : WAVES][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
+    __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS : WAVES)][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
     __shared__ int32_t s_xch[(PAIRED && GENERAL) ? WAVES : 1][MAXCH][(PAIRED && GENERAL) ? 64 : 1];
     __shared__ int32_t s_xw[WSPEC ? 2 : 1][GROUPS][MAXCH][WSPEC ? 64 : 1];
     __shared__ uint32_t s_alive[2][WAVES];
@@ -447,18 +455,17 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    // workspace lane = segment * L + substream in every layout
+    // two-wave layout: the odd wave of a group carries the LAST substream of each of its 64 segments
+    // (the only one of a single-substream stream), the even wave the first substream of the
+    // two-substream ones -- so the even waves never rematrix, stage or store PCM
     const uint32_t ws_grp = (uint32_t)wv >> 1;
-    const uint32_t ws_sub = (uint32_t)wv & 1u;
-    const uint32_t gl = WSPEC ? ((blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane) * 2u + ws_sub
-                              : blockIdx.x * THREADS + threadIdx.x;
+    const uint32_t ws_last = (uint32_t)wv & 1u;
+    const uint32_t gl0 = blockIdx.x * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
-    uint32_t segi = gl / L;
-    const uint32_t sub = gl - segi * L;     // substream handled by this lane
+    uint32_t segi = WSPEC ? (blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
     bool active = segi < n_seg;
-    uint32_t seg_lane = gl;                 // lane index that owns segment `segi` in the workspaces
 
     SegRec sr;
     sr.off = sr.end = 0;
@@ -475,6 +482,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         fbase = a.seg_fbase[segi] - a.seg_fbase[stream_first];
     }
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
+    // substream handled by this lane; workspace lane = segment * L + substream in every layout
+    // (an even-wave lane of a single-substream stream is idle and names the stream's absent substream 1)
+    const uint32_t sub = WSPEC ? (ws_last == (S == 2 ? 1u : 0u) ? 1u : 0u) : gl0 - segi * L;
+    const uint32_t gl = WSPEC ? segi * 2u + sub : gl0;
+    uint32_t seg_lane = gl;                 // lane index that owns segment `segi` in the workspaces
     const uint32_t assignment = (stream_sync >> 16) & 0x1F;
     const uint32_t rpa = rows_per_au((stream_sync >> 8) & 0xF);
     const uint32_t nch_out = channel_count(assignment);
@@ -1323,7 +1335,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     // ---- into the LDS staging tile [channel][frame][lane]; rows advance in lockstep so
                     //      the frame phase is the same in every lane
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
-                    int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
+                    int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
 #pragma unroll
                     for (int c = 0; c < 6; c++)
                         T[c][ph][GENERAL ? 0 : lane] = ch[c];
@@ -1472,7 +1484,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         //      older memory operation, so stores issued before it would be waited for as well; issued
         //      here they have a whole row to drain before the next wait
         if (!GENERAL && flush) {
-            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 if ((uint32_t)c < nch_out) {

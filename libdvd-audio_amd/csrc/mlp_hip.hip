@@ -22,6 +22,14 @@
 
 using namespace mlp;
 
+// diagnostic builds: extra dynamic LDS per fast-pass workgroup (occupancy probe, no code change)
+#if defined(DVDA_EXP_DYN_LDS)
+#include <stdlib.h>
+#define DVDA_DYN_LDS_EXPR (getenv("DVDA_DYN_LDS") ? (unsigned)atoi(getenv("DVDA_DYN_LDS")) : 0u)
+#else
+#define DVDA_DYN_LDS_EXPR 0
+#endif
+
 #define HIP_TRY(x)                                                                         \
     do {                                                                                   \
         hipError_t e_ = (x);                                                               \
@@ -341,7 +349,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     if (lanes_per_seg == 2)
         hipLaunchKernelGGL((k_decode<6, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
+        hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
     HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], st));
     c->ev_used += 2;
     const dim3 fgrid((c->n_streams + 255) / 256);

@@ -71,6 +71,27 @@ def check(path):
             b = int(mm.group(3)) if mm.group(3) else a
             if not (b < lo or a > hi):
                 viol.append((i + 1, 0, p, t))
+        # ... and the other way round (LLVM GCNHazardRecognizer, VMEM store of more than 64 bits: a VALU
+        # write of its data registers needs two wait states on gfx940+): the store may still be reading them
+        ws, k = 0, i + 1
+        while k < len(L) and ws < 2:
+            p = L[k].strip()
+            k += 1
+            if not p or p.startswith(';') or (p.startswith('.') and not p.endswith(':')):
+                continue
+            if p.endswith(':') or p.startswith('s_cbranch') or p.startswith('s_branch') or p.startswith('s_endpgm'):
+                break                                  # control flow: at least one more issue cycle, keep it simple
+            n = re.match(r'^s_nop\s+(\d+)', p)
+            if n:
+                ws += int(n.group(1)) + 1
+                continue
+            mm = re.match(r'^(v_\S+)\s+v\[?(\d+)(?::(\d+))?\]?', p)
+            if mm and not mm.group(1).startswith('v_cmp'):
+                a = int(mm.group(2))
+                b = int(mm.group(3)) if mm.group(3) else a
+                if not (b < lo or a > hi):
+                    viol.append((k, ws, p, t))
+            ws += 1
     return checked, unknown, viol
 
 
