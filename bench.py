@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--assignment", type=int, default=12,
                     help="channel assignment of the synthetic titles (12 = 6-ch, the BASELINE metric; "
                          "1 = 2-ch for configs[1] exploration)")
+    ap.add_argument("--layout", default="interleaved", choices=("interleaved", "planar"),
+                    help="PCM layout written by the decode: interleaved = frame-major, the order the "
+                         "reference's dvda_read() hands out (default, faster: one contiguous run per lane "
+                         "and flush); planar = the order its decode_packet appends to `samples`")
     return ap.parse_args()
 
 
@@ -141,7 +145,8 @@ def main():
     d_stride = torch.from_numpy(all_frames).to(dev)
     d_pcm = torch.empty(samples_per_step, dtype=torch.int32, device=dev)
 
-    ctx = hip.Context(local_rank, n_streams, n_segments, lanes_per_segment=args.substreams)
+    layout = hip.PCM_INTERLEAVED if args.layout == "interleaved" else hip.PCM_PLANAR
+    ctx = hip.Context(local_rank, n_streams, n_segments, lanes_per_segment=args.substreams, layout=layout)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -182,7 +187,8 @@ def main():
             b = flat[int(offs[u]):int(offs[u] + sizes[u])]
             want, r, st = ora.decode(b, nch, int(frames[u]))
             got = d_pcm[int(out_off[i]):int(out_off[i]) + int(all_frames[i]) * nch].cpu().numpy()
-            got = got.reshape(nch, int(all_frames[i]))
+            got = got.reshape(int(all_frames[i]), nch).T if layout == hip.PCM_INTERLEAVED \
+                else got.reshape(nch, int(all_frames[i]))
             bit_exact = bit_exact and st == 0 and np.array_equal(got, want)
         if not bit_exact:
             raise SystemExit("HIP decode differs from the oracle")
@@ -228,6 +234,9 @@ def main():
                 "workload": "BASELINE configs[2]: synthetic 6ch/96kHz/24bit MLP, 2 matrices + 8-tap FIR, "
                             "codebook 1, CRC on, restart every 8 AUs",
                 "substreams": args.substreams,
+                "pcm_layout": "interleaved int32 [frame][channel] (reference dvda_read order)"
+                              if layout == hip.PCM_INTERLEAVED else
+                              "planar int32 [channel][frame] (reference decode_packet order)",
                 "titles_per_gpu": n_streams, "unique_titles_per_gpu": args.streams,
                 "access_units_per_title": args.aus, "segments_per_gpu": n_segments,
                 "samples_per_step_per_gpu": samples_per_step,

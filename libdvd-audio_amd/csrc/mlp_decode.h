@@ -78,6 +78,7 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 #endif
 #if defined(DVDA_EXP_NOSTORE)
 #define DVDA_STORE_V4(dst, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
+#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
 #else
 // One 16-byte store instruction, opaque to the optimizer: left to itself the compiler merges this
 // store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
@@ -96,6 +97,13 @@ typedef int dvda_v4i __attribute__((ext_vector_type(4)));
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
         asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_MODS ::"v"(dst), "v"(v4_) : "memory"); \
+    } while (0)
+// the same at a constant byte offset from one base address
+#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
+    do {                                                                                            \
+        dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
+        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" DVDA_STORE_MODS                   \
+                     ::"v"(dst), "v"(v4_), "n"(off_) : "memory");                                   \
     } while (0)
 #endif
 
@@ -134,6 +142,7 @@ struct DecodeArgs {
     uint32_t fb_slots;
     const int32_t *init_fir;       // optional: FIR history a stream starts with, [stream][2][48] (streaming tier)
     uint32_t *deferred;            // set by the fast pass when anything is left to the general pass
+    uint32_t interleaved;          // PCM layout: 0 planar, 1 frame-major (see k_decode)
 };
 
 __device__ const CrcTable d_crc = make_crc();
@@ -425,7 +434,12 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 //   the unit's end with the parameters its last block left (src/mlp.c:504-525), and -- for a
 //   stream whose access units do not have the standard length -- decodes the whole stream in
 //   order with a running output position.
-template <int NS, bool PAIRED, bool GENERAL>
+// ILV (fast pass; the general pass reads a.interleaved): PCM leaves frame-major,
+// pcm[off + frame * channels + wave_channel] -- the order reference dvda_read() hands out
+// (src/dvd-audio.c:781-792) -- instead of planar pcm[off + wave_channel * stride + frame], the order
+// decode_packet appends to `samples` (src/mlp.c:527-533).  A lane's flush is then ONE contiguous
+// run of 16 * channels bytes (whole 32-byte sectors) instead of six 16-byte pieces in six places.
+template <int NS, bool PAIRED, bool GENERAL, bool ILV = false>
 __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
@@ -491,6 +505,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     const uint32_t rpa = rows_per_au((stream_sync >> 8) & 0xF);
     const uint32_t nch_out = channel_count(assignment);
     const uint32_t wavepk = wave_pack(assignment);
+    const uint32_t wave_inv = ILV ? wave_inv_pack(assignment) : 0u;   // nibble w = MLP channel at RIFF position w
     uint32_t status = 0;
     if (active && (sr.flags & ST_FATAL_INDEX))
         active = false;                                         // reported by the index
@@ -1413,7 +1428,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
 #pragma unroll
                                 for (int c = 0; c < 6; c++)
                                     if ((uint32_t)c < nch_out)
-                                        a.pcm[out_base + (uint64_t)nib(wavepk, c) * out_stride + orow] = ch[c];
+                                        a.pcm[out_base + (a.interleaved ? orow * nch_out + nib(wavepk, c)
+                                                                        : (uint64_t)nib(wavepk, c) * out_stride + orow)] = ch[c];
                             }
                             rows_written++;
                         }
@@ -1483,7 +1499,60 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
         //      older memory operation, so stores issued before it would be waited for as well; issued
         //      here they have a whole row to drain before the next wait
-        if (!GENERAL && flush) {
+        if (!GENERAL && ILV && flush) {
+            // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
+            const int32_t *Tl = &s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)][0][0][GENERAL ? 0 : lane];
+            int32_t *dst = a.pcm + out_base + flush_row * nch_out;
+            if (__builtin_expect(__all(nch_out == 6u && vec_ok), 1)) {
+                // (one straight-line version per channel count was tried: the extra code costs the
+                //  6-channel case 10 %, the other counts take the general loop below)
+                const int32_t *cb[6];                     // tile row of the channel at RIFF position w
+#pragma unroll
+                for (int w = 0; w < 6; w++)
+                    cb[w] = Tl + nib(wave_inv, w) * (OUT_ROWS * 64);
+                // the reads of the next 16 bytes are in flight while the last ones are stored
+                // (reading the whole tile first costs more registers than the row loop has)
+                int32_t o[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    o[0][j] = cb[j % 6][(j / 6) * 64];
+#pragma unroll
+                for (int v = 0; v < (OUT_ROWS * 6) / 4; v++) {
+                    if (v + 1 < (OUT_ROWS * 6) / 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            o[(v + 1) & 1][j] = cb[(4 * v + 4 + j) % 6][((4 * v + 4 + j) / 6) * 64];
+                    }
+                    DVDA_STORE_V4_AT(dst, 16 * v, o[v & 1][0], o[v & 1][1], o[v & 1][2], o[v & 1][3]);
+                }
+            } else {
+                // any channel count, lanes of different formats, unaligned buffers
+                uint32_t fi = 0, fw = 0;
+                for (uint32_t v = 0; v < (uint32_t)OUT_ROWS * 6u / 4u; v++) {
+                    if (v * 4u < (uint32_t)OUT_ROWS * nch_out) {
+                        int32_t o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            o[j] = Tl[(nib(wave_inv, fw) * OUT_ROWS + fi) * 64];
+                            fw++;
+                            if (fw == nch_out) {
+                                fw = 0;
+                                fi++;
+                            }
+                        }
+                        if (vec_ok) {
+                            DVDA_STORE_V4(dst + 4 * v, o[0], o[1], o[2], o[3]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                dst[4 * v + j] = o[j];
+                            DVDA_COV(13);            // unaligned output: scalar stores
+                        }
+                    }
+                }
+            }
+        }
+        if (!GENERAL && !ILV && flush) {
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
 #pragma unroll
             for (int c = 0; c < 6; c++) {

@@ -78,6 +78,7 @@ struct dvda_mlp_hip_ctx {
     uint64_t tiles;
     bool indexed;
     uint32_t lanes_per_seg;
+    uint32_t pcm_layout;           // DVDA_PCM_PLANAR / DVDA_PCM_INTERLEAVED
     // timing of the decode kernel
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
     size_t ev_used;
@@ -133,6 +134,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->ev_used = 0;
     c->d_init_fir = nullptr;
     c->lanes_per_seg = 2;
+    c->pcm_layout = DVDA_PCM_PLANAR;
     const size_t ns = (size_t)max_segments;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -330,6 +332,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.fb_slots = c->fb_slots;
     a.init_fir = c->d_init_fir;
     a.deferred = c->d_deferred;
+    a.interleaved = c->pcm_layout == DVDA_PCM_INTERLEAVED;
     HIP_TRY(hipMemsetAsync(c->d_deferred, 0, sizeof(uint32_t), st));
     // two lanes per segment unless the caller knows every stream has one substream
     const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
@@ -346,10 +349,17 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     }
     HIP_TRY(hipEventRecord(c->ev[c->ev_used], st));
     // fast pass (timed: the dominant kernel)
-    if (lanes_per_seg == 2)
-        hipLaunchKernelGGL((k_decode<6, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
+    if (a.interleaved) {
+        if (lanes_per_seg == 2)
+            hipLaunchKernelGGL((k_decode<6, true, false, true>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
+    } else {
+        if (lanes_per_seg == 2)
+            hipLaunchKernelGGL((k_decode<6, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
+    }
     HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], st));
     c->ev_used += 2;
     const dim3 fgrid((c->n_streams + 255) / 256);
@@ -368,6 +378,14 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
                            (const uint32_t *)a.deferred);
     }
     HIP_TRY(hipGetLastError());
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *c, uint32_t layout)
+{
+    if (!c || (layout != DVDA_PCM_PLANAR && layout != DVDA_PCM_INTERLEAVED))
+        return DVDA_HIP_EINVAL;
+    c->pcm_layout = layout;
     return DVDA_HIP_OK;
 }
 

@@ -86,6 +86,19 @@ constexpr uint32_t wave_pack(unsigned a)
     return p;
 }
 
+// wave_inv_pack(assignment): nibble w = MLP channel stored at RIFF-WAVE position w (inverse of wave_pack)
+constexpr uint32_t wave_inv_pack(unsigned a)
+{
+    const uint32_t p = wave_pack(a);
+    uint32_t inv = 0;
+    for (unsigned c = 0; c < 6; c++) {
+        const uint32_t w = (p >> (4 * c)) & 0xFu;
+        if (w < 6)
+            inv |= c << (4 * w);
+    }
+    return inv;
+}
+
 constexpr uint32_t channel_count(unsigned a)
 {
     constexpr uint8_t count[21] = {1, 2, 3, 4, 3, 4, 5, 3, 4, 5, 4, 5, 6, 4, 5, 4, 5, 6, 5, 5, 6};

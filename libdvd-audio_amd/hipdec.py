@@ -37,7 +37,8 @@ _lib = None
 
 EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
            "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
-           "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_set_lanes_per_segment", "dvda_mlp_hip_segment_info",
+           "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_set_lanes_per_segment",
+           "dvda_mlp_hip_set_pcm_layout", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
            "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",
@@ -69,6 +70,7 @@ def lib():
         L.dvda_mlp_hip_segment_count.argtypes = [vp, ctypes.POINTER(u32), vp]
         L.dvda_mlp_hip_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
         L.dvda_mlp_hip_set_lanes_per_segment.argtypes = [vp, u32]
+        L.dvda_mlp_hip_set_pcm_layout.argtypes = [vp, u32]
         L.dvda_mlp_hip_version.restype = ctypes.c_char_p
         L.dvda_hip_open_mlpdecoder.restype = vp
         L.dvda_hip_open_mlpdecoder.argtypes = [ctypes.c_uint] * 5 + [ctypes.c_int]
@@ -98,14 +100,18 @@ def _check(rc, what):
         raise HipError("%s failed: %s (%d)" % (what, names.get(rc, "?"), rc))
 
 
+PCM_PLANAR, PCM_INTERLEAVED = 0, 1      # DVDA_PCM_* of include/dvda_mlp_hip.h
+
+
 class Context:
     """One decode context = one GPU's index workspace (dvda_mlp_hip_create)."""
 
-    def __init__(self, device=0, max_streams=1, max_segments=1024, lanes_per_segment=2):
+    def __init__(self, device=0, max_streams=1, max_segments=1024, lanes_per_segment=2, layout=PCM_PLANAR):
         self._h = ctypes.c_void_p()
         _check(lib().dvda_mlp_hip_create(ctypes.byref(self._h), device, max_streams, max_segments),
                "dvda_mlp_hip_create")
         _check(lib().dvda_mlp_hip_set_lanes_per_segment(self._h, lanes_per_segment), "set_lanes")
+        _check(lib().dvda_mlp_hip_set_pcm_layout(self._h, layout), "set_pcm_layout")
         self.device = device
         self.n_streams = 0
 
@@ -163,13 +169,15 @@ def pack_streams(streams):
     return flat, np.asarray(offs, np.uint64), np.asarray(lens, np.uint64)
 
 
-def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2):
+def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2, layout=PCM_PLANAR):
     """Decodes a list of complete MLP byte streams on the GPU.
 
     Returns (pcm, infos): pcm[i] is an int32 array [channels, pcm_frames] in RIFF-WAVE
     channel order -- what the reference appends to `samples` (src/mlp.c:527-533) --
-    and infos[i] the dvda_mlp_stream_info of stream i.  Raises HipError if the HIP
-    path is unavailable; never falls back to a CPU decoder.
+    and infos[i] the dvda_mlp_stream_info of stream i.  With layout=PCM_INTERLEAVED the
+    library writes frame-major (the dvda_read order) and pcm[i] is that buffer viewed
+    as [pcm_frames, channels] and transposed, so callers compare the same way.  Raises
+    HipError if the HIP path is unavailable; never falls back to a CPU decoder.
     """
     import torch
     if not torch.cuda.is_available():
@@ -179,7 +187,7 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2):
     total = int(len(flat) - 64)
     if max_segments is None:
         max_segments = max(64, total // 64)
-    ctx = Context(device, len(streams), max_segments, lanes_per_segment)
+    ctx = Context(device, len(streams), max_segments, lanes_per_segment, layout)
     try:
         d_bytes = torch.from_numpy(flat).to(dev)
         d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
@@ -219,8 +227,13 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2):
         pcm = []
         for i, inf in enumerate(infos):
             r, c = rows[i], nch[i]
-            a = host[out_off[i]:out_off[i] + r * c].reshape(c, r) if r * c else np.zeros((c, 0), np.int32)
-            pcm.append(a[:, :int(inf.pcm_frames)].copy())
+            if not r * c:
+                a = np.zeros((c, 0), np.int32)
+            elif layout == PCM_INTERLEAVED:
+                a = host[out_off[i]:out_off[i] + r * c].reshape(r, c).T
+            else:
+                a = host[out_off[i]:out_off[i] + r * c].reshape(c, r)
+            pcm.append(np.ascontiguousarray(a[:, :int(inf.pcm_frames)]))
         return pcm, list(infos)
     finally:
         ctx.close()

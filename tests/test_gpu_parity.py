@@ -5,6 +5,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _both(hip, streams, **kw):
+    """decode_streams in both PCM layouts of the C ABI (planar = the reference's `samples` order,
+    interleaved = its dvda_read order): the same values and statuses, whatever the case is."""
+    pcm, infos = hip.decode_streams(streams, layout=hip.PCM_PLANAR, **kw)
+    pcm_i, infos_i = hip.decode_streams(streams, layout=hip.PCM_INTERLEAVED, **kw)
+    assert len(pcm) == len(pcm_i)
+    for i, (a, b, x, y) in enumerate(zip(pcm, pcm_i, infos, infos_i)):
+        assert (x.status, x.pcm_frames, x.channels) == (y.status, y.pcm_frames, y.channels), \
+            "stream %d: planar %#x/%d vs interleaved %#x/%d" % (i, x.status, x.pcm_frames, y.status, y.pcm_frames)
+        if not (x.status & ~hip.ST_BENIGN):
+            assert a.shape == b.shape and np.array_equal(a, b), "stream %d: layouts differ at %s" % (
+                i, np.argwhere(a != b)[:4].tolist() if a.shape == b.shape else (a.shape, b.shape))
+    return pcm, infos
+
+
 def _check(pkg, oracle, cfgs_seeds, lanes=2):
     syn, hip = pkg.synth, pkg.hipdec
     streams, frames, cfgs = [], [], []
@@ -13,7 +28,7 @@ def _check(pkg, oracle, cfgs_seeds, lanes=2):
         streams.append(b)
         frames.append(f)
         cfgs.append(cfg)
-    pcm, infos = hip.decode_streams(streams, lanes_per_segment=lanes)
+    pcm, infos = _both(hip, streams, lanes_per_segment=lanes)
     for i, (b, f, cfg) in enumerate(zip(streams, frames, cfgs)):
         nch = syn.channels(cfg.assignment)
         want, r, st = oracle.decode(b, nch, f)
@@ -62,7 +77,7 @@ def test_golden_vectors_on_gpu(pkg):
     paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
     assert len(paths) >= 12
     zs = [np.load(p) for p in paths]
-    pcm, infos = hip.decode_streams([z["mlp"] for z in zs], lanes_per_segment=2)
+    pcm, infos = _both(hip, [z["mlp"] for z in zs], lanes_per_segment=2)
     for path, z, got, inf in zip(paths, zs, pcm, infos):
         assert inf.status & ~hip.ST_BENIGN == 0, "%s status %#x" % (os.path.basename(path), inf.status)
         assert got.shape == z["pcm"].shape, os.path.basename(path)
@@ -154,7 +169,7 @@ def test_edge_cases_truncated_ragged_and_single_unit(pkg, oracle):
         streams.append(b)
         frames.append(f)
     cut = streams[3][:len(streams[3]) - 123]            # ends inside the last access unit
-    pcm, infos = hip.decode_streams(streams[:3] + [cut], lanes_per_segment=2)
+    pcm, infos = _both(hip, streams[:3] + [cut], lanes_per_segment=2)
     for i in range(3):
         want, r, st = oracle.decode(streams[i], syn.channels(cfgs[i].assignment), frames[i])
         assert infos[i].status & ~hip.ST_BENIGN == 0 and np.array_equal(pcm[i], want)
@@ -178,7 +193,7 @@ def test_corruption_is_reported_not_decoded(pkg, oracle):
     size0 = 2 * (((int(good[0]) & 0xF) << 8) | int(good[1]))
     crc_only[size0 - 1] ^= 0xFF
     nosync = good[size0:].copy()                        # starts with a non-sync frame
-    pcm, infos = hip.decode_streams([good, flip, crc_only, nosync, good], lanes_per_segment=1)
+    pcm, infos = _both(hip, [good, flip, crc_only, nosync, good], lanes_per_segment=1)
     want, r, st = oracle.decode(good, 6, frames)
     for i in (0, 4):
         assert infos[i].status == 0 and np.array_equal(pcm[i], want)
@@ -196,8 +211,8 @@ def test_linearity_free_property_checksum_of_large_batch(pkg, oracle):
     syn, hip = pkg.synth, pkg.hipdec
     cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=128)
     streams = [syn.stream(cfg, 7000 + i)[0] for i in range(48)]
-    pcm1, infos1 = hip.decode_streams(streams, lanes_per_segment=1)
-    pcm2, infos2 = hip.decode_streams(streams, lanes_per_segment=2)
+    pcm1, infos1 = _both(hip, streams, lanes_per_segment=1)
+    pcm2, infos2 = _both(hip, streams, lanes_per_segment=2)
     for i, b in enumerate(streams):
         want, r, st = oracle.decode(b, 6, 128 * 80)
         assert st == 0 and infos1[i].status == 0 and infos2[i].status == 0
@@ -236,7 +251,7 @@ def test_false_sync_pattern_in_ignored_bytes_is_resolved(pkg, oracle, S):
     chained, cframes = syn.stream(chained_cfg, 4321)
     cases = [(_inject_false_sync(clean, 3), frames), (_inject_false_sync(clean, 39), frames),
              (_inject_false_sync(chained, 10), cframes), (clean, frames)]
-    pcm, infos = hip.decode_streams([c[0] for c in cases], lanes_per_segment=2)
+    pcm, infos = _both(hip, [c[0] for c in cases], lanes_per_segment=2)
     for (b, f), got, inf in zip(cases, pcm, infos):
         want, r, st = oracle.decode(b, 6, f)
         assert st == 0 and r == f
@@ -272,7 +287,7 @@ def test_mixed_corpus_192k_mlp_and_raw_pcm_titles_on_concurrent_streams(pkg, ora
     def run_mlp():
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
-                got["mlp"] = pkg.hipdec.decode_streams([b for b, _ in titles], lanes_per_segment=1)
+                got["mlp"] = _both(pkg.hipdec, [b for b, _ in titles], lanes_per_segment=1)
         except Exception as e:          # surfaced in the main thread
             errors.append(e)
 
@@ -322,7 +337,7 @@ def test_garbage_and_bit_flips_never_hang_and_never_pass_silently(pkg, oracle):
         streams.append(s)
     for i in range(6):
         streams.append(base[:rng.randint(40, len(base))].copy())          # cut anywhere
-    pcm, infos = hip.decode_streams(streams, lanes_per_segment=1)
+    pcm, infos = _both(hip, streams, lanes_per_segment=1)
     clean = 0
     for s, p, inf in zip(streams, pcm, infos):
         want, r, st = oracle.decode(s, 6, frames)
@@ -351,7 +366,7 @@ def test_long_last_access_unit_is_timing_not_overflow(pkg, oracle):
     b, f = syn.stream(cfg, 10303)
     want, r, st = oracle.decode(b, 6, f)
     assert st == 0 and r == f
-    pcm, infos = hip.decode_streams([b], lanes_per_segment=2)
+    pcm, infos = _both(hip, [b], lanes_per_segment=2)
     assert infos[0].status & hip.ST["TIMING"]
     assert infos[0].status & ~hip.ST_BENIGN == 0
     assert np.array_equal(pcm[0], want)

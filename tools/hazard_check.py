@@ -50,29 +50,19 @@ def check(path):
             unknown += 1
         elif found[1].startswith('v_') and ws < 2:
             viol.append((i + 1, ws, found[1], t))
-    # asm PCM stores (global_store_dwordx4 ..., v[x:y], off): GFX9 wants one wait state between a VALU
-    # write of store data wider than 64 bits and the store
+    # asm PCM stores (global_store_dwordx4 ..., v[x:y], off ...): a VMEM store of more than 64 bits may
+    # still be reading its data registers when the next instructions issue -- a VALU write of them needs
+    # two wait states on gfx940+ (LLVM GCNHazardRecognizer::createsVALUHazard, "store data over written
+    # by the next instruction"); the compiler pads its own stores, not the ones inside inline asm
     for i, l in enumerate(L):
         t = l.strip()
-        if not t.startswith('global_store_dwordx4') or 'ASMSTART' not in L[i - 1]:
+        if not t.startswith('global_store_dwordx4') or not any('ASMSTART' in L[j] for j in (i - 1, i - 2)):
             continue
         m = re.search(r'v\[(\d+):(\d+)\], off', t)
         if not m:
             continue
         lo, hi = int(m.group(1)), int(m.group(2))
-        k = i - 2
-        while k >= 0 and (not L[k].strip() or L[k].strip().startswith(';')):
-            k -= 1
-        p = L[k].strip()
         checked += 1
-        mm = re.match(r'^(v_\S+)\s+v\[?(\d+)(?::(\d+))?\]?', p)
-        if mm:
-            a = int(mm.group(2))
-            b = int(mm.group(3)) if mm.group(3) else a
-            if not (b < lo or a > hi):
-                viol.append((i + 1, 0, p, t))
-        # ... and the other way round (LLVM GCNHazardRecognizer, VMEM store of more than 64 bits: a VALU
-        # write of its data registers needs two wait states on gfx940+): the store may still be reading them
         ws, k = 0, i + 1
         while k < len(L) and ws < 2:
             p = L[k].strip()
@@ -106,9 +96,9 @@ def main():
                        stderr=subprocess.DEVNULL)
         path = out
     checked, unknown, viol = check(path)
-    print("inline-asm selects: %d, mask defined in another block: %d, hazard violations: %d" % (checked, unknown, len(viol)))
+    print("inline-asm selects + stores: %d, mask defined in another block: %d, hazard violations: %d" % (checked, unknown, len(viol)))
     for v in viol[:10]:
-        print("  line %d: %d wait state(s) after `%s` before `%s`" % v)
+        print("  line %d: only %d wait state(s) between `%s` and `%s`" % v)
     return 1 if (viol or unknown or checked == 0) else 0
 
 

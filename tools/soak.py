@@ -36,7 +36,9 @@ for i in range(n):
     batch.append(b)
     meta.append((i, asg, S, feats, f))
     if len(batch) == 32 or i == n - 1:
-        pcm, infos = hip.decode_streams(batch, lanes_per_segment=2)
+        # batches alternate between the two PCM layouts of the C ABI
+        pcm, infos = hip.decode_streams(batch, lanes_per_segment=2,
+                                        layout=hip.PCM_INTERLEAVED if (i // 32) & 1 else hip.PCM_PLANAR)
         for b, (idx, asg, S, feats, f), p, inf in zip(batch, meta, pcm, infos):
             want, r, st = oracle.decode(b, syn.channels(asg), f)
             ok = st == 0 and (inf.status & ~hip.ST_BENIGN) == 0 and p.shape == want.shape and np.array_equal(p, want)
