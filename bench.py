@@ -212,7 +212,8 @@ def main():
         traffic_bytes = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("samples_per_launch") == samples_per_step and tj.get("compressed_bytes") == comp_bytes:
+            if tj.get("samples_per_launch") == samples_per_step and tj.get("compressed_bytes") == comp_bytes \
+                    and tj.get("pcm_layout", "planar") == args.layout:
                 traffic_bytes = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass

@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -19,7 +20,8 @@ for f in glob.glob(os.path.join(pmc, "*", "**", "*counter_collection.csv"), recu
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             name = row["Kernel_Name"]
-            key = "decode_fast" if ("k_decode" in name and "false>" in name.split("(")[0].replace(" ", "")[-8:]) else \
+            m = re.search(r"k_decode<\s*\d+\s*,\s*(\w+)\s*,\s*(\w+)", name)      # <NS, PAIRED, GENERAL[, ILV]>
+            key = "decode_fast" if (m and m.group(2) == "false") else \
                   "sync_mask" if "k_sync_mask" in name else None
             if key:
                 vals[(key, row["Counter_Name"])].append(float(row["Counter_Value"]))
@@ -33,11 +35,13 @@ fetch = 2.0 * mean(("decode_fast", "FETCH_SIZE")) * 1024
 write = mean(("decode_fast", "WRITE_SIZE")) * 1024
 calib = 2.0 * mean(("sync_mask", "FETCH_SIZE")) * 1024
 out = {
-    "kernel": "k_decode<6,false,false> (fast pass)",
+    "kernel": "k_decode<6,false,false,%s> (fast pass, %s PCM)" % (
+        ("true", "interleaved") if "interleaved" in cfg.get("pcm_layout", "") else ("false", "planar")),
     "hbm_bytes_per_launch": int(fetch + write),
     "fetch_bytes_corrected": int(fetch), "write_bytes": int(write),
     "calibration": {"k_sync_mask_fetch_corrected": int(calib), "input_bytes": cfg["compressed_bytes_per_gpu"]},
     "samples_per_launch": cfg["samples_per_step_per_gpu"], "compressed_bytes": cfg["compressed_bytes_per_gpu"],
+    "pcm_layout": "interleaved" if "interleaved" in cfg.get("pcm_layout", "") else "planar",
     "algorithmic_bytes": j["roofline"]["algorithmic_bytes_per_launch"],
     "source": os.path.basename(pmc.rstrip("/")),
 }
