@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
             if (__builtin_expect(__all(nch_out == 6u && vec_ok), 1)) {
                 // (one straight-line version per channel count was tried: the extra code costs the
-                //  6-channel case 10 %, the other counts take the general loop below)
+                //  6-channel case 10 %; 6 and 2 channels have theirs, the rest takes the general loop)
                 const int32_t *cb[6];                     // tile row of the channel at RIFF position w
 #pragma unroll
                 for (int w = 0; w < 6; w++)
@@ -1525,6 +1525,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     }
                     DVDA_STORE_V4_AT(dst, 16 * v, o[v & 1][0], o[v & 1][1], o[v & 1][2], o[v & 1][3]);
                 }
+            } else if (__all(nch_out == 2u && vec_ok)) {
+                // 2 channels: the four frames are one 32-byte sector
+                const int32_t *c0 = Tl + nib(wave_inv, 0) * (OUT_ROWS * 64), *c1 = Tl + nib(wave_inv, 1) * (OUT_ROWS * 64);
+                DVDA_STORE_V4_AT(dst, 0, c0[0], c1[0], c0[64], c1[64]);
+                DVDA_STORE_V4_AT(dst, 16, c0[128], c1[128], c0[192], c1[192]);
             } else {
                 // any channel count, lanes of different formats, unaligned buffers
                 uint32_t fi = 0, fw = 0;
