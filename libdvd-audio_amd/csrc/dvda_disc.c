@@ -87,7 +87,9 @@ struct DVDA_Track_Reader_s {
     unsigned bps_code[2], rate_code[2], assignment;
     unsigned channels, status;
     uint64_t frames, served, stride;
-    int32_t *pcm;              /* host, planar [channel][stride], RIFF-WAVE order */
+    int interleaved;           /* MLP tracks: frame-major [frame][channel] = the dvda_read order;
+                                  PCM tracks: planar [channel][stride]; RIFF-WAVE channel order */
+    int32_t *pcm;              /* host copy of d_pcm, made by the first dvda_read() */
     int32_t *d_pcm;            /* device copy, kept for the GPU WAV packer */
     uint8_t *wav;              /* host payload produced by dvda_hip_reader_wav_payload */
 };
@@ -603,7 +605,8 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         (void)hipFree(d_mlp);
         d_sec = d_mlp = NULL;
         for (int attempt = 0; attempt < 2; attempt++) {
-            if (dvda_mlp_hip_create(&ctx, g_device, 1, segs) != DVDA_HIP_OK)
+            if (dvda_mlp_hip_create(&ctx, g_device, 1, segs) != DVDA_HIP_OK ||
+                dvda_mlp_hip_set_pcm_layout(ctx, DVDA_PCM_INTERLEAVED) != DVDA_HIP_OK)
                 goto fail;
             if (dvda_mlp_hip_index(ctx, d_stream, padded, d_meta + 0, d_meta + 1, 1, NULL) != DVDA_HIP_OK)
                 goto fail;
@@ -656,6 +659,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         r->status = info.status;
         r->frames = info.pcm_frames;
         r->stride = stride;
+        r->interleaved = 1;            /* decoded frame-major: dvda_read() copies frames straight out */
         if (r->channels == 0 || r->channels != info.channels)
             goto fail;
         r->d_pcm = d_pcm;              /* the host copy is made by the first dvda_read() */
@@ -840,7 +844,7 @@ unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *r)
 unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
 {
     if (!r->pcm) {
-        /* planar PCM of the whole track, fetched once */
+        /* PCM of the whole track, fetched once */
         const size_t bytes = r->stride * r->channels * sizeof(int32_t);
         r->pcm = malloc(bytes ? bytes : 1);
         if (!r->pcm || hipMemcpy(r->pcm, r->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -851,10 +855,14 @@ unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
     }
     const uint64_t left = r->frames - r->served;
     const unsigned n = left < pcm_frames ? (unsigned)left : pcm_frames;
-    for (unsigned c = 0; c < r->channels; c++) {
-        const int32_t *src = r->pcm + (size_t)c * r->stride + r->served;
-        for (unsigned i = 0; i < n; i++)
-            buffer[(size_t)i * r->channels + c] = src[i];
+    if (r->interleaved) {
+        memcpy(buffer, r->pcm + (size_t)r->served * r->channels, (size_t)n * r->channels * sizeof(int32_t));
+    } else {
+        for (unsigned c = 0; c < r->channels; c++) {
+            const int32_t *src = r->pcm + (size_t)c * r->stride + r->served;
+            for (unsigned i = 0; i < n; i++)
+                buffer[(size_t)i * r->channels + c] = src[i];
+        }
     }
     r->served += n;
     return n;
@@ -873,8 +881,12 @@ unsigned long long dvda_hip_reader_wav_payload(DVDA_Track_Reader *r, const unsig
     r->wav = malloc(bytes);
     if (!r->wav || !dev_alloc((void **)&d_out, bytes))
         return 0;
-    /* planes start at r->served inside each channel: pass the shifted base, same stride */
-    if (dvda_mlp_hip_pack_wav(r->d_pcm + r->served, r->stride, r->channels, left, bits, d_out, NULL) != DVDA_HIP_OK ||
+    /* planar: planes start at r->served inside each channel (shifted base, same stride);
+     * frame-major: the values already are in payload order = one "channel" of left * channels values */
+    const int rc = r->interleaved
+        ? dvda_mlp_hip_pack_wav(r->d_pcm + r->served * r->channels, 4, 1, left * r->channels, bits, d_out, NULL)
+        : dvda_mlp_hip_pack_wav(r->d_pcm + r->served, r->stride, r->channels, left, bits, d_out, NULL);
+    if (rc != DVDA_HIP_OK ||
         hipMemcpy(r->wav, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipFree(d_out);
         return 0;
