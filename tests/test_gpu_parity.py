@@ -409,3 +409,42 @@ def test_device_code_book_decode_equals_the_tables_exhaustively(pkg, oracle):
                 assert (int(got[book, peek]) & 0xFF) == 0xFF, (book, peek)
             else:
                 assert int(got[book, peek]) == want, (book, peek, hex(int(got[book, peek])), hex(want))
+
+
+@pytest.mark.parametrize("layout", ["planar", "interleaved"])
+@pytest.mark.parametrize("assignment,lanes", [(12, 1), (1, 1), (6, 2), (12, 2)])
+def test_output_buffer_not_16_byte_aligned(pkg, oracle, assignment, lanes, layout):
+    """d_out_off / the buffer need not be 16-byte aligned: the kernels then leave the 16-byte stores
+    for scalar ones (both PCM layouts; 6-, 2- and 5-channel flush paths)."""
+    import torch
+    syn, hip = pkg.synth, pkg.hipdec
+    lay = hip.PCM_INTERLEAVED if layout == "interleaved" else hip.PCM_PLANAR
+    dev = torch.device("cuda", 0)
+    cfg = syn.make_cfg(assignment=assignment, rate_code=1, n_substreams=lanes if assignment != 12 or lanes == 2 else 1,
+                       n_aus=24, profile=1, features=syn.SF_FAST, restart_interval=4)
+    b, f = syn.stream(cfg, 4711)
+    nch = syn.channels(assignment)
+    want, r, st = oracle.decode(b, nch, f)
+    assert st == 0
+    flat, offs, lens = hip.pack_streams([b])
+    d_bytes = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    for mis in (1, 2, 3):
+        ctx = hip.Context(0, 1, 1024, 2 if cfg.n_substreams == 2 else lanes, lay)
+        try:
+            ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), 1, 0)
+            stride = f + 8
+            d_pcm = torch.full((stride * nch + 16,), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+            d_oo = torch.tensor([mis], dtype=torch.int64, device=dev)
+            d_st = torch.tensor([stride], dtype=torch.int64, device=dev)
+            ctx.decode(d_pcm.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), 0)
+            inf = ctx.stream_info()[0]
+            assert inf.status & ~hip.ST_BENIGN == 0 and inf.pcm_frames == f
+            host = d_pcm.cpu().numpy()
+            body = host[mis:mis + stride * nch]
+            got = body.reshape(stride, nch).T[:, :f] if lay == hip.PCM_INTERLEAVED else body.reshape(nch, stride)[:, :f]
+            assert np.array_equal(got, want), "misalignment %d" % mis
+            assert (host[:mis] == 0x5A5A5A5A).all(), "wrote in front of the buffer"
+        finally:
+            ctx.close()
