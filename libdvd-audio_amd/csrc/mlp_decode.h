@@ -76,19 +76,20 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 #else
 #define DVDA_STAMP(i) ((void)0)
 #endif
-#if defined(DVDA_EXP_NOSTORE)
-#define DVDA_STORE_V4(dst, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
-#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
-#else
-// One 16-byte store instruction, opaque to the optimizer: left to itself the compiler merges this
-// store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
-// which doubles the store instructions and splits every half-sector write in two.
 // coverage counters of the rarely taken paths (DVDA_EXP_COUNT builds, tools/coverage_run.py)
 #if defined(DVDA_EXP_COUNT)
 #define DVDA_COV(i) do { if (a.dbg) atomicAdd(&a.dbg[(i)], 1ull); } while (0)
 #else
 #define DVDA_COV(i) ((void)0)
 #endif
+#if defined(DVDA_EXP_NOSTORE)
+// diagnostic: the kernel without its 16-byte PCM stores (what do they cost?)
+#define DVDA_STORE_V4(dst, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
+#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
+#else
+// One 16-byte store instruction, opaque to the optimizer: left to itself the compiler merges this
+// store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
+// which doubles the store instructions and splits every half-sector write in two.
 typedef int dvda_v4i __attribute__((ext_vector_type(4)));
 #ifndef DVDA_STORE_MODS
 #define DVDA_STORE_MODS ""
@@ -597,6 +598,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     }
     const bool vec_ok = (((out_base | out_stride) & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0);   // 16-byte aligned rows
+    // frame-major, and every segment of this wave is 6 channels in identity RIFF order (all 6-channel
+    // assignments but 0x14) into an aligned buffer: the tile is staged frame-major too -- [frame][channel]
+    // instead of [channel][frame] -- and a flush reads it front to back.  Decided once per wave.
+    const bool ilv_direct = ILV && !GENERAL &&
+                            __all(segi >= n_seg || (nch_out == 6u && (wavepk & 0xFFFFFFu) == 0x543210u && vec_ok));
 
     BitReader rd;
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
@@ -1351,9 +1357,16 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     //      the frame phase is the same in every lane
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
                     int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
+                    if (ILV && ilv_direct) {
+                        int32_t *Td = &T[0][0][GENERAL ? 0 : lane] + ph * (6 * 64);
 #pragma unroll
-                    for (int c = 0; c < 6; c++)
-                        T[c][ph][GENERAL ? 0 : lane] = ch[c];
+                        for (int c = 0; c < 6; c++)
+                            Td[c * 64] = ch[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            T[c][ph][GENERAL ? 0 : lane] = ch[c];
+                    }
                     // ---- RIFF order (src/mlp.c:527-533): every OUT_ROWS-th frame each channel's staged
                     //      frames leave as 16-byte stores that together cover whole 32-byte sectors
                     // `room` rows are left before the segment's standard length or the output
@@ -1503,28 +1516,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
             const int32_t *Tl = &s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
-            if (__builtin_expect(__all(nch_out == 6u && vec_ok), 1)) {
-                // (one straight-line version per channel count was tried: the extra code costs the
-                //  6-channel case 10 %; 6 and 2 channels have theirs, the rest takes the general loop)
-                const int32_t *cb[6];                     // tile row of the channel at RIFF position w
+            if (__builtin_expect(ilv_direct, 1)) {
+                // the tile already is in output order: 24 consecutive planes, two per LDS read
 #pragma unroll
-                for (int w = 0; w < 6; w++)
-                    cb[w] = Tl + nib(wave_inv, w) * (OUT_ROWS * 64);
-                // the reads of the next 16 bytes are in flight while the last ones are stored
-                // (reading the whole tile first costs more registers than the row loop has)
-                int32_t o[2][4];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    o[0][j] = cb[j % 6][(j / 6) * 64];
-#pragma unroll
-                for (int v = 0; v < (OUT_ROWS * 6) / 4; v++) {
-                    if (v + 1 < (OUT_ROWS * 6) / 4) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            o[(v + 1) & 1][j] = cb[(4 * v + 4 + j) % 6][((4 * v + 4 + j) / 6) * 64];
-                    }
-                    DVDA_STORE_V4_AT(dst, 16 * v, o[v & 1][0], o[v & 1][1], o[v & 1][2], o[v & 1][3]);
-                }
+                for (int v = 0; v < (OUT_ROWS * 6) / 4; v++)
+                    DVDA_STORE_V4_AT(dst, 16 * v, Tl[(4 * v) * 64], Tl[(4 * v + 1) * 64], Tl[(4 * v + 2) * 64],
+                                     Tl[(4 * v + 3) * 64]);
             } else if (__all(nch_out == 2u && vec_ok)) {
                 // 2 channels: the four frames are one 32-byte sector
                 const int32_t *c0 = Tl + nib(wave_inv, 0) * (OUT_ROWS * 64), *c1 = Tl + nib(wave_inv, 1) * (OUT_ROWS * 64);
