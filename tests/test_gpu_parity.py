@@ -315,14 +315,17 @@ def test_mixed_corpus_192k_mlp_and_raw_pcm_titles_on_concurrent_streams(pkg, ora
 
 @pytest.mark.gpu
 @pytest.mark.timeout(120)
-def test_garbage_and_bit_flips_never_hang_and_never_pass_silently(pkg, oracle):
+@pytest.mark.parametrize("S", [1, 2])
+def test_garbage_and_bit_flips_never_hang_and_never_pass_silently(pkg, oracle, S):
     """Robustness: random bytes, streams with random bit flips and streams cut at random places go
     through the whole batch path.  The call must return; a stream the oracle decodes cleanly must
     come out identical; a stream the oracle rejects must carry a non-benign status (or stop at the
-    same PCM-frame count) -- never clean status with different PCM."""
+    same PCM-frame count) -- never clean status with different PCM.  (S = 2: the two substreams of a
+    segment run in different waves that meet at a barrier every row -- one of them dying must not
+    stall or derail the other.)"""
     syn, hip = pkg.synth, pkg.hipdec
     rng = np.random.RandomState(2024)
-    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=16)
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=16)
     base, frames = syn.stream(cfg, 99)
     streams = [rng.randint(0, 256, size=4000).astype(np.uint8)]          # pure noise
     noise_with_sync = rng.randint(0, 256, size=3000).astype(np.uint8)
@@ -337,7 +340,7 @@ def test_garbage_and_bit_flips_never_hang_and_never_pass_silently(pkg, oracle):
         streams.append(s)
     for i in range(6):
         streams.append(base[:rng.randint(40, len(base))].copy())          # cut anywhere
-    pcm, infos = _both(hip, streams, lanes_per_segment=1)
+    pcm, infos = _both(hip, streams, lanes_per_segment=S)
     clean = 0
     for s, p, inf in zip(streams, pcm, infos):
         want, r, st = oracle.decode(s, 6, frames)
