@@ -124,7 +124,8 @@ int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d
  * reference's dvda_read() hands out (src/dvd-audio.c:781-792); d_out_stride[i] stays the capacity
  * in PCM frames, so stream i occupies channels * d_out_stride[i] values either way.  Same sample
  * values; each lane's stores become one contiguous run, which the memory side takes much better
- * (8 % faster, 40 % less write traffic on the bench shape). */
+ * (6-channel titles: 5-8 % faster, 40 % less write traffic; 2-channel: the same speed; other channel
+ * counts: a few per cent slower than planar -- DESIGN.md section 4). */
 #define DVDA_PCM_PLANAR      0u
 #define DVDA_PCM_INTERLEAVED 1u
 int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *ctx, uint32_t layout);

@@ -18,8 +18,11 @@
 //   * residuals, FIR history/coefficients, codebook parameters and the first two
 //     matrices live in VGPRs; nothing between the ring and the PCM store touches
 //     memory (cold state only: IIR taps, matrices 3..6 in a workspace)
-//   * PCM leaves as 16-byte stores (4 frames x 1 channel per lane, staged in an LDS tile),
-//     issued after the ring commit so that no s_waitcnt counts them
+//   * PCM leaves as 16-byte stores, staged four frames at a time in an LDS tile and issued after
+//     the ring commit so that no s_waitcnt counts them: planar layout = one store per channel into six
+//     places, frame-major layout = one contiguous run per lane (template parameter ILV)
+//   * two-substream streams: one wave per substream in the fast pass, a row's channels cross through
+//     LDS at one workgroup barrier per row (WSPEC)
 //   * Huffman codes are decoded arithmetically (the three books share one
 //     structure, mlp_tables.h) -- no table, no LDS latency on the parse chain
 //
