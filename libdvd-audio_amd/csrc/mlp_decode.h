@@ -55,6 +55,9 @@ constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
 constexpr int RING_PLANES = DVDA_RING_PLANES;   // planes x 16 B per lane (8 = 128-byte ring)
 constexpr int RING_DWORDS = RING_PLANES * 4;
 constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
+#ifndef DVDA_WS_BALANCE
+#define DVDA_WS_BALANCE 1        // two-wave layout: the first substream's wave rematrixes and stores
+#endif
 #ifndef DVDA_OUT_ROWS
 #define DVDA_OUT_ROWS 4
 #endif
@@ -482,9 +485,20 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     __shared__ int32_t s_xch[(PAIRED && GENERAL) ? WAVES : 1][MAXCH][(PAIRED && GENERAL) ? 64 : 1];
     __shared__ int32_t s_xw[WSPEC ? 2 : 1][GROUPS][MAXCH][WSPEC ? 64 : 1];
     __shared__ uint32_t s_alive[2][WAVES];
+    // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
+    // (last substream, odd wave) for the lane that applies them (first substream, even wave)
+    constexpr bool WS_BAL = WSPEC && DVDA_WS_BALANCE;
+    // (two copies, by version parity: the reader may still be at the last one when the next is written;
+    //  word 0 of copy 0 is the version of the newest)
+    __shared__ uint32_t s_par[WS_BAL ? GROUPS : 1][2][16][WS_BAL ? 64 : 1];
 
     for (int i = threadIdx.x; i < 4 * 256; i += THREADS)
         s_crc[i] = d_crc.t[i];
+    if (WS_BAL) {
+        // plane 7 of the exchange tiles carries "row n of the other lane is there": start from "no row"
+        for (int i = threadIdx.x; i < 2 * GROUPS * 64; i += THREADS)
+            s_xw[WS_BAL ? i / (GROUPS * 64) : 0][WS_BAL ? (i / 64) % GROUPS : 0][7][WS_BAL ? i % 64 : 0] = 0;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -540,6 +554,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         active = false;
     }
     const bool is_last_sub = (sub + 1 == S);
+    // who turns the segment's channels into PCM: the lane of the last substream -- except in the two-wave
+    // layout, where the (short) first substream's lane of a two-substream segment takes that over from the
+    // (long) last one: it reads the matrices the other lane parses and the pair's work is even
+    const bool adopt = WS_BAL && S == 2u && sub == 0u;
+    const bool lends = WS_BAL && S == 2u && sub == 1u;
+    const bool owner = WS_BAL ? (adopt || (is_last_sub && !lends)) : is_last_sub;
 
     uint64_t out_base = 0, out_stride = 0;
     if (active) {
@@ -683,6 +703,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     uint32_t min_ch = 0, max_ch = 0, max_mat_ch = 0, noise_shift = 0, seed = 0;
     uint32_t matrix_len = 0, bypass_mask = 0, outch_pack = 0;
     uint32_t oshift_pack = 0, qss_pack = 0;
+    uint32_t qss_A = 0, mmc_A = 0;    // quant step sizes / max_matrix_channel the rematrix works with
+    uint32_t par_seen = 0, par_pub = 0;   // WS_BAL: version of the published parameters (taken / written)
+    const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
     uint32_t nslots = 0;
     bool have_restart = false;
     uint32_t iir_any = 0;             // bit k: slot k has IIR order > 0
@@ -714,7 +737,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             for (int c = 0; c < 6; c++)
                 acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(mc[c >> 1]) : lo16(mc[c >> 1]));
             const uint32_t oc = nib(outch_pack, m);
-            const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) +
+            const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_A, oc)) +
                                          ((bypass_bits >> m) & 1u));
             // `on` is folded into the channel number (0xFF matches nothing) and the value is fenced, or
             // the compiler turns it back into "compare, and with the mask, wait state, select" per channel
@@ -747,15 +770,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 uint32_t mc[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
-                one_matrix(mc, a.mat_ws[(size_t)(m * 5 + 4) * a.total_lanes + gl], m, true);
+                    mc[j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl_r];
+                one_matrix(mc, a.mat_ws[(size_t)(m * 5 + 4) * a.total_lanes + gl_r], m, true);
             }
         }
         // output shifts are rare (all zero on most streams): one wave-uniform test skips them
         if (__any(oshift_pack != 0)) {
 #pragma unroll
             for (int c = 0; c < MAXCH; c++)
-                if ((uint32_t)c <= max_mat_ch)
+                if ((uint32_t)c <= mmc_A)
                     ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
         }
     };
@@ -767,6 +790,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     uint32_t rows_iter = 0;            // two-wave layout: parity of the exchange buffer
     for (;;) {
         DVDA_STAMP(5);
+        bool hdr_parsed = false;       // this lane parsed a block header in this iteration
         // =================================================== header phase
         if (__builtin_expect(active && rows_left == 0, 0)) {
             if (!in_frame) {
@@ -870,8 +894,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 bool ok = true;
                 uint32_t err = ST_PARAMS;
                 bool matrix_class_change = false;
+                bool hdr_restart = false;
                 if (rd.read(1)) {
                     const bool restart = rd.read(1) != 0;
+                    hdr_restart = restart;
                     if (restart) {
                         // ---- restart header (src/mlp.c:822-851)
                         const uint32_t h0 = rd.read(14);           // 13u sync, 1u noise_type
@@ -1174,6 +1200,31 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     ok = false;
                     err = ST_ENVELOPE;
                 }
+                hdr_parsed = true;
+                if (!adopt) {
+                    qss_A = qss_pack;
+                    mmc_A = max_mat_ch;
+                }
+                if (lends) {
+                    // ---- the parameters the other wave rematrixes with; the seed only when a restart
+                    //      header set it (the other lane steps its own copy from there)
+                    par_pub += 2u;
+                    uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][(par_pub >> 1) & 1u][0][WS_BAL ? lane : 0];
+                    constexpr int PS = WS_BAL ? 64 : 1;
+                    P[1 * PS] = seed;
+                    P[2 * PS] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
+                    P[3 * PS] = outch_pack;
+                    P[4 * PS] = qss_pack;
+                    P[5 * PS] = oshift_pack;
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            P[(6 + m * 4 + j) * PS] = mreg[m][j];
+                        P[(14 + m) * PS] = mnoise[m];
+                    }
+                    s_par[WS_BAL ? ws_grp : 0][0][0][WS_BAL ? lane : 0] = par_pub | (hdr_restart ? 1u : 0u);
+                }
                 if (matrix_class_change)
                     status |= ST_MIDFRAME;
                 if (!ok) {
@@ -1359,7 +1410,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             DVDA_STAMP(2);
         };
         auto row_tail = [&](int32_t (&ch)[MAXCH]) {
-            if (is_last_sub) {
+            if (owner && (!adopt || active)) {
                 if (GENERAL) {
                     // ---- general pass: park the filtered frame; it is rematrixed at the end of
                     //      the access unit with the parameters its last block leaves
@@ -1484,6 +1535,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             if (in_row)
                 row_head();
             int32_t(*X)[WSPEC ? 64 : 1] = s_xw[WSPEC ? par : 0][WSPEC ? ws_grp : 0];
+            if (WS_BAL && in_row && lends)
+                X[7][lane] = (int32_t)(bypass_bits | (rows_iter << 24));    // + "this row is there"
             const uint32_t wave_alive = __any(in_row) ? 1u : 0u;     // (over the whole wave: outside the branch)
             if (lane == 0)
                 s_alive[par][wv] = wave_alive;
@@ -1492,10 +1545,44 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             if (!__any(lane < WAVES && s_alive[par][lane < WAVES ? lane : 0] != 0))
                 break;
             if (in_row) {
-                if (is_last_sub) {
+                if (owner) {
 #pragma unroll
                     for (int c = 0; c < MAXCH; c++)
                         ch[c] = X[c][lane];
+                }
+                if (adopt) {
+                    // ---- the other lane's row: its bypassed LSBs, and is it there at all?
+                    const uint32_t tagw = (uint32_t)ch[7];
+                    ch[7] = 0;
+                    bypass_bits = tagw & 0xFFFFFFu;
+                    if ((tagw >> 24) != (rows_iter & 0xFFu)) {
+                        active = false;                  // it stopped (its status says why): no more output
+                    } else {
+                        const uint32_t verw = s_par[WS_BAL ? ws_grp : 0][0][0][WS_BAL ? lane : 0];
+                        if (__builtin_expect((verw & ~1u) != par_seen || hdr_parsed, 0)) {
+                            // ---- new parameters over there, or this lane's own header parse has just
+                            //      overwritten the registers they live in: (re)load them
+                            const uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][(verw >> 1) & 1u][0][WS_BAL ? lane : 0];
+                            constexpr int PS = WS_BAL ? 64 : 1;
+                            if ((verw & 1u) && (verw & ~1u) != par_seen)
+                                seed = P[1 * PS];
+                            par_seen = verw & ~1u;
+                            const uint32_t w2 = P[2 * PS];
+                            noise_shift = w2 & 0xFFu;
+                            matrix_len = (w2 >> 8) & 0xFFu;
+                            mmc_A = w2 >> 16;
+                            outch_pack = P[3 * PS];
+                            qss_A = P[4 * PS];
+                            oshift_pack = P[5 * PS];
+#pragma unroll
+                            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                    mreg[m][j] = P[(6 + m * 4 + j) * PS];
+                                mnoise[m] = P[(14 + m) * PS];
+                            }
+                        }
+                    }
                 }
                 row_tail(ch);
             }
@@ -1622,7 +1709,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     if (segi < n_seg) {
         if (status)
             atomicOr(&a.seg_status[segi], status);
-        if ((!GENERAL || general_head) && is_last_sub && sub < S)
+        if ((!GENERAL || general_head) && owner && sub < S)
             a.seg_rows[segi] = rows_written;
     }
 }
