@@ -1349,10 +1349,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 uint64_t step = __builtin_amdgcn_ballot_w64(adv != 0);
                 asm volatile("" : "+s"(step));
                 const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
-                uint32_t nh = rd.hi, nl = rd.lo, nn = rd.nx;
-                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(nh) : "v"(rd.lo), "s"(step));
-                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(nl) : "v"(rd.nx), "s"(step));
-                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(nn) : "v"(cand1), "s"(step));
+                // (three-operand form: with the result tied to the first source the compiler copied
+                //  hi / lo / nx before every select, they are still needed by the rare second step)
+                uint32_t nh, nl, nn;
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nh) : "v"(rd.hi), "v"(rd.lo), "s"(step));
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nl) : "v"(rd.lo), "v"(rd.nx), "s"(step));
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nn) : "v"(rd.nx), "v"(cand1), "s"(step));
                 if (__builtin_expect(__any(adv == 2), 0)) {
                     const bool two = adv == 2;
                     if (two && in)
