@@ -285,11 +285,32 @@ struct BitReader {
     // hashes ring dwords [crc_pos, limit) into the parity/CRC state (limit <= fillpos)
     __device__ __forceinline__ void crc_catchup(uint32_t limit)
     {
+        // whole dwords: a loop with nothing but the hash in it (the out-of-line tail below used to sit
+        // in the same loop and cost every iteration its call frame)
+        {
+            // (one counter: the dwords there are, capped by the dwords that are whole)
+            const int32_t avail = (int32_t)(limit - crc_pos);
+            uint32_t steps = crc_rem >= 7u ? (crc_rem - 3u) >> 2 : 0u;
+            steps = avail > 0 ? (steps < (uint32_t)avail ? steps : (uint32_t)avail) : 0u;
+            crc_rem -= 4u * steps;
+            for (; steps; steps--) {
+                const uint32_t v = *slot(crc_pos);
+                crc_pos++;
+                // slicing-by-4: only the first lookup depends on the running state
+                const uint32_t c = crc_st & 0xFF;
+                const uint32_t n = crc_tab[768 + ((c ^ v) & 0xFF)] ^ crc_tab[512 + ((v >> 8) & 0xFF)] ^
+                                   crc_tab[256 + ((v >> 16) & 0xFF)] ^ crc_tab[v >> 24];
+                crc_st = (crc_st & ~0xFFu) | n;
+                par ^= v;
+            }
+        }
+        if (__builtin_expect(crc_rem == 0 || crc_rem >= 7, 1))
+            return;
+        // the last 1..6 bytes of the substream's data (and the general form)
         while (crc_rem && (int32_t)(limit - crc_pos) > 0) {
             const uint32_t v = *slot(crc_pos);
             crc_pos++;
             if (__builtin_expect(crc_rem >= 7, 1)) {
-                // slicing-by-4: only the first lookup depends on the running state
                 const uint32_t c = crc_st & 0xFF;
                 const uint32_t n = crc_tab[768 + ((c ^ v) & 0xFF)] ^ crc_tab[512 + ((v >> 8) & 0xFF)] ^
                                    crc_tab[256 + ((v >> 16) & 0xFF)] ^ crc_tab[v >> 24];
