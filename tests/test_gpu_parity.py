@@ -451,3 +451,18 @@ def test_output_buffer_not_16_byte_aligned(pkg, oracle, assignment, lanes, layou
             assert (host[:mis] == 0x5A5A5A5A).all(), "wrote in front of the buffer"
         finally:
             ctx.close()
+
+
+def test_pcm_layout_argument_is_checked(pkg):
+    """dvda_mlp_hip_set_pcm_layout: the two layouts are accepted, anything else is DVDA_HIP_EINVAL (-3)
+    and leaves the context as it was."""
+    hip = pkg.hipdec
+    ctx = hip.Context(0, 1, 64, 1)
+    try:
+        L = hip.lib()
+        assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, hip.PCM_INTERLEAVED) == 0
+        assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, 2) == -3
+        assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, hip.PCM_PLANAR) == 0
+        assert L.dvda_mlp_hip_set_pcm_layout(None, hip.PCM_PLANAR) == -3
+    finally:
+        ctx.close()
