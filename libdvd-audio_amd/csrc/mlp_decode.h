@@ -433,9 +433,10 @@ struct BitReader {
 // peek t: returns value | length << 8, value 0xFF for the two invalid codes of a book, and 0 (no
 // bits, value 0) for "book" 0 = no code.  Checked exhaustively against the table by
 // dvda_mlp_hip_selftest_huff (tests/test_gpu_parity.py).
-// m_esc / m_book: wave masks of "t & 0x100" (escape form) and "cb != 0", compared by the caller well
-// ahead of here so that the two selects at the end need no wait-state padding (tools/hazard_check.py)
-__device__ __forceinline__ uint32_t huff_decode_m(uint32_t cb, uint32_t t, uint64_t m_esc, uint64_t m_book)
+// m_esc: wave mask of "t & 0x100" (escape form), compared by the caller well ahead of here so that the
+// select at the end needs no wait-state padding (tools/hazard_check.py); bmask: all ones when there is
+// a code book (cb != 0), else 0 -- the caller keeps that as bit 31 of the packed slot parameters
+__device__ __forceinline__ uint32_t huff_decode_m(uint32_t cb, uint32_t t, uint64_t m_esc, uint32_t bmask)
 {
     // "1" + (3 - cb) bits -> 7 + bits, length 4 - cb: the bits are the top of the low byte
     const uint32_t a = (((t & 0xFFu) >> (5u + cb)) + 7u) | ((4u - cb) << 8);
@@ -452,20 +453,18 @@ __device__ __forceinline__ uint32_t huff_decode_m(uint32_t cb, uint32_t t, uint6
     uint32_t e = val | (((z > 6u ? 6u : z) + 3u) << 8);
 #if defined(DVDA_HUFF_PLAIN_SELECTS)
     e = (t & 0x100u) ? a : e;
-    return cb ? e : 0u;
+    return e & bmask;
 #else
-    uint32_t r;
     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(e) : "v"(a), "s"(m_esc));
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(e), "s"(m_book));
-    return r;
+    return e & bmask;
 #endif
 }
 
 __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 {
-    uint64_t m_esc = __builtin_amdgcn_ballot_w64((t & 0x100u) != 0), m_book = __builtin_amdgcn_ballot_w64(cb != 0);
-    asm volatile("" : "+s"(m_esc), "+s"(m_book));
-    return huff_decode_m(cb, t, m_esc, m_book);
+    uint64_t m_esc = __builtin_amdgcn_ballot_w64((t & 0x100u) != 0);
+    asm volatile("" : "+s"(m_esc));
+    return huff_decode_m(cb, t, m_esc, cb ? 0xFFFFFFFFu : 0u);
 }
 
 // ----------------------------------------------------------------------------
@@ -683,7 +682,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     int32_t st[NS][8];                // FIR history: st[k][0] = most recent output
     uint32_t cf[NS][4];               // FIR coefficients, int16 pairs, zero beyond the order
     uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
-                                      // fir_order<<19 | fir_shift<<23 | iir_shift<<27
+                                      // fir_order<<19 | fir_shift<<23 | iir_shift<<27 | (codebook != 0)<<31
     int32_t sho[NS];                  // signed huffman offset (src/mlp.c:1152-1176)
     uint32_t mreg[2][4];              // channel coefficients of matrices 0 and 1 (int16 pairs), zero
                                       // beyond max_matrix_channel
@@ -1199,7 +1198,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                                     const int32_t nsho = hoff - huff_center(codebook, lb);
                                     const uint32_t npk = codebook | (lb << 2) | (q << 7) | (shift << 11) |
                                                          (iir_order << 15) | (fir_order << 19) |
-                                                         (fir_shift << 23) | (iir_shift << 27);
+                                                         (fir_shift << 23) | (iir_shift << 27) |
+                                                         (codebook ? 1u << 31 : 0u);
 #pragma unroll
                                     for (int kk = 0; kk < NS; kk++)
                                         if ((uint32_t)kk == k) {
@@ -1346,15 +1346,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 const uint32_t pkk = in ? pk[k] : 0u;
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
-                uint64_t m_book = __builtin_amdgcn_ballot_w64(cb != 0);
+                const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
                 // the two dwords behind the window: one address, one two-address LDS read (mirror plane)
                 const uint32_t *look = rd.slot(rd.next);
                 const uint32_t cand1 = __builtin_bswap32(look[0]), cand2 = __builtin_bswap32(look[64]);
                 const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
                 const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);      // bit 8 of the 9-bit peek
-                asm volatile("" : "+s"(m_esc), "+s"(m_book));
-                const uint32_t e = huff_decode_m(cb, top >> 23, m_esc, m_book);
+                asm volatile("" : "+s"(m_esc));
+                const uint32_t e = huff_decode_m(cb, top >> 23, m_esc, bmask);
                 const uint32_t msb = e & 0xFFu;
                 const uint32_t len = e >> 8;
                 msb_or |= msb;                            // valid values are < 0x20
