@@ -1743,9 +1743,12 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
                                                   const uint32_t *__restrict__ seg_status,
                                                   const uint32_t *__restrict__ seg_rows,
                                                   StreamRec *__restrict__ streams, uint32_t n_streams,
-                                                  const uint32_t *__restrict__ only_if)
+                                                  const uint32_t *__restrict__ only_if,
+                                                  uint32_t *__restrict__ fb_counter)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 && fb_counter)
+        *fb_counter = 0;        // the general pass that follows starts with no frame buffer handed out
     if (s >= n_streams)
         return;
     if (only_if && *only_if == 0)

@@ -236,9 +236,15 @@ static void exscan(dvda_mlp_hip_ctx *c, hipStream_t st, const uint32_t *in, uint
                        n_cap);
 }
 
-__global__ void k_init_streams(StreamRec *s, uint32_t n)
+// one dispatch for the three things an index call starts from: empty stream records, and the
+// per-segment status / row counters at zero
+__global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, uint32_t *seg_rows, uint32_t n_seg)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_seg) {
+        seg_status[i] = 0;
+        seg_rows[i] = 0;
+    }
     if (i < n) {
         StreamRec r;
         r.first_seg = 0xFFFFFFFFu;
@@ -278,10 +284,11 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     c->d_n_cand = c->d_tile_base + tiles;
     const uint32_t ms = c->max_segments;
 
-    hipLaunchKernelGGL(k_init_streams, dim3((n_streams + 255) / 256), dim3(256), 0, st, c->d_streams,
-                       n_streams);
-    HIP_TRY(hipMemsetAsync(c->d_seg_status, 0, (size_t)ms * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(c->d_seg_rows, 0, (size_t)ms * sizeof(uint32_t), st));
+    {
+        const uint32_t n_init = n_streams > ms ? n_streams : ms;
+        hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
+                           n_streams, c->d_seg_status, c->d_seg_rows, ms);
+    }
     hipLaunchKernelGGL(k_sync_mask, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, d_bytes,
                        total_bytes, c->d_masks, c->d_tile_count);
     exscan(c, st, c->d_tile_count, c->d_tile_base, (uint32_t)tiles, nullptr, (uint32_t)tiles);
@@ -364,18 +371,18 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     c->ev_used += 2;
     const dim3 fgrid((c->n_streams + 255) / 256);
     hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status,
-                       c->d_seg_rows, c->d_streams, c->n_streams, (const uint32_t *)nullptr);
+                       c->d_seg_rows, c->d_streams, c->n_streams, (const uint32_t *)nullptr, c->d_fb_counter);
     // general pass, twice: the second run picks up streams whose non-standard timing only
     // showed inside a chained run.  Lanes without deferred work exit at once.
     for (int pass = 0; pass < 2; pass++) {
-        HIP_TRY(hipMemsetAsync(c->d_fb_counter, 0, sizeof(uint32_t), st));
+        // (the frame-buffer counter was reset by the k_finalize in front of this pass)
         if (lanes_per_seg == 2)
             hipLaunchKernelGGL((k_decode<6, true, true>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
         else
             hipLaunchKernelGGL((k_decode<6, false, true>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase,
                            c->d_seg_status, c->d_seg_rows, c->d_streams, c->n_streams,
-                           (const uint32_t *)a.deferred);
+                           (const uint32_t *)a.deferred, c->d_fb_counter);
     }
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
