@@ -97,3 +97,49 @@ def test_shard_is_balanced_and_deterministic(pkg):
     again = pkg.shard.shard_titles(sizes, 8, 3)
     assert np.array_equal(again, parts[3])
     assert len(pkg.shard.shard_titles([], 4, 1)) == 0
+
+
+def _run_bench(extra, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                       env=env, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_launcher_starts_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment must start 2 ranks itself.  On this box
+    (no GPU) the ranks run in plumbing mode: rank environment, shard and the summary all-reduce are the
+    real code, nothing is decoded (value null)."""
+    rc, rec, err = _run_bench(["--gpus", "2", "--streams", "12", "--aus", "8"], {"DVDA_BENCH_PLUMBING": "1"})
+    assert rc == 0, err[-2000:]
+    assert rec["n_gpus"] == 2 and rec["plumbing_only"] is True and rec["value"] is None
+    assert rec["scaling"] == "weak"
+    assert rec["config"]["titles_all_ranks"] == 24               # weak: every rank brings its own 12 titles
+    assert rec["config"]["samples_all_ranks"] == 24 * 8 * 80 * 6
+    assert abs(rec["seconds_max_over_ranks"] - 0.002) < 1e-9     # max over ranks, not rank 0's
+
+
+def test_bench_c4_shards_the_1024_units_strongly():
+    """configs[3]: the single-access-unit streams are dealt to the ranks (strong scaling): the ranks'
+    shares add up to the whole list whatever N is."""
+    one = _run_bench(["--gpus", "1", "--workload", "c4", "--streams", "96"], {"DVDA_BENCH_PLUMBING": "1"})
+    two = _run_bench(["--gpus", "2", "--workload", "c4", "--streams", "96"], {"DVDA_BENCH_PLUMBING": "1"})
+    assert one[0] == 0 and two[0] == 0, (one[2][-1000:], two[2][-1000:])
+    assert one[1]["scaling"] == two[1]["scaling"] == "strong"
+    for k in ("titles_all_ranks", "samples_all_ranks", "compressed_bytes_all_ranks"):
+        assert one[1]["config"][k] == two[1]["config"][k], k
+    assert one[1]["config"]["titles_all_ranks"] == 96 and one[1]["config"]["samples_all_ranks"] == 96 * 480
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    """Without the plumbing switch `--gpus 2` on a box with fewer GPUs fails cleanly (never a silent
+    one-rank run that prints n_gpus: 1)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has 2 GPUs")
+    rc, rec, err = _run_bench(["--gpus", "2"], {"DVDA_BENCH_PLUMBING": "0"})
+    assert rc == 2 and rec is None and "needs 2 GPUs" in err

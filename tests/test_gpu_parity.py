@@ -466,3 +466,25 @@ def test_pcm_layout_argument_is_checked(pkg):
         assert L.dvda_mlp_hip_set_pcm_layout(None, hip.PCM_PLANAR) == -3
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_config3_1024_independent_access_units(pkg, oracle, S):
+    """BASELINE configs[3]: a batch of 1 024 independent 6-ch/96 kHz streams of ONE access unit each
+    (major sync + restart header + raw lead-in block), different seeds -- every one of them against the
+    oracle, both PCM layouts; and the shard of that list over 8 ranks covers it exactly."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=1)
+    flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
+    streams = [flat[int(o):int(o + s)] for o, s in zip(offs, sizes)]
+    assert (frames == 80).all()
+    pcm, infos = _both(hip, streams, lanes_per_segment=S)
+    for i, b in enumerate(streams):
+        want, r, st = oracle.decode(b, 6, 80)
+        assert st == 0 and r == 80
+        assert infos[i].status == 0 and infos[i].pcm_frames == 80 and infos[i].segments == 1
+        assert np.array_equal(pcm[i], want), "unit %d differs" % i
+    parts = [pkg.shard.shard_titles(sizes, 8, r) for r in range(8)]
+    assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(1024))
+    loads = np.array([sizes[p].sum() for p in parts])
+    assert loads.max() - loads.min() <= sizes.max()
