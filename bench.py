@@ -331,7 +331,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     cfg = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=args.aus)
     flat, offs, sizes, frames = syn.batch(cfg, 1, args.streams)
     nseg = args.streams * args.replicas * ((args.aus + cfg.restart_interval - 1) // cfg.restart_interval)
-    run("planar_layout", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, "planar", 1,
+    run("planar_layout", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, "planar", 0,
         note="same titles as the headline, PCM written planar [channel][frame] (reference decode_packet order)")
     # ---- batch-size sweep on the headline layout (non-multiples of the 2 048 resident waves included)
     sweep = []
@@ -346,11 +346,11 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     # ---- two substreams (ch 0-1 | ch 2-5, matrices in substream 1)
     cfg2 = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=2, n_aus=args.aus)
     flat, offs, sizes, frames = syn.batch(cfg2, 1, args.streams)
-    run("two_substreams", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, args.layout, 2)
+    run("two_substreams", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, args.layout, 0)
     # ---- configs[1] shape: 2-ch / 96 kHz / 24-bit titles
     cfg1 = syn.make_cfg(assignment=1, rate_code=rate, n_substreams=1, n_aus=args.aus)
     flat, offs, sizes, frames = syn.batch(cfg1, 1, args.streams)
-    run("stereo_c2", flat, offs, sizes, frames, np.full(len(sizes), 2), nseg, args.replicas, "planar", 1,
+    run("stereo_c2", flat, offs, sizes, frames, np.full(len(sizes), 2), nseg, args.replicas, "planar", 0,
         note="BASELINE configs[1] shape (2ch/96k/24b), planar layout")
     # ---- heterogeneous batches: fuzz-profile titles, mixed layouts / rates / restart intervals -- header
     #      parses diverge inside the waves.  "heterogeneous": what varies from disc to disc (block splits,
@@ -367,7 +367,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         specs = [(syn.make_cfg(assignment=asg, rate_code=rc, n_substreams=1, n_aus=64, profile=1, features=feats,
                                restart_interval=ri), 512) for asg, rc, ri in shapes]
         flat, offs, sizes, frames, nchs, nseg_h = gen_mixed(syn, specs, 90000)
-        run(name, flat, offs, sizes, frames, nchs, nseg_h * 4, 4, "planar", 1,
+        run(name, flat, offs, sizes, frames, nchs, nseg_h * 4, 4, "planar", 0,
             note="8 fuzz-profile configurations (6/2/5/1-ch, 48/96/192 kHz, restart every 2..16 AUs; %s), "
                  "16 384 titles of 64 access units" % note)
     # ---- chained titles: no raw lead-in after a title's first segment, the FIR history runs through
@@ -375,11 +375,11 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     cfgc = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=128, profile=1,
                         features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(cfgc, 1, 1024)
-    run("chained_titles", flat, offs, sizes, frames, np.full(len(sizes), 6), 1024 * (128 // 8 + 2), 1, args.layout, 1,
+    run("chained_titles", flat, offs, sizes, frames, np.full(len(sizes), 6), 1024 * (128 // 8 + 2), 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="1 024 titles x 128 access units, every segment depends on the one before")
     one = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=512, profile=1, features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(one, 7, 1)
-    run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 1,
+    run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 512 access units (the low-parallelism case)")
     return out
 
@@ -416,7 +416,7 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         bufs.append(dict(d_in=torch.zeros(maxb, dtype=torch.uint8, device=dev),
                          d_pcm=torch.empty(maxt, dtype=torch.int32, device=dev),
                          st=torch.cuda.Stream(dev),
-                         ctx=hip.Context(local_rank, maxn, nseg, lanes_per_segment=1, layout=layout)))
+                         ctx=hip.Context(local_rank, maxn, nseg, lanes_per_segment=0, layout=layout)))
     for s in slots:     # the small per-stream tables live on the device (they are part of the request, not payload)
         s["d_off"] = torch.from_numpy(s["off"]).to(dev)
         s["d_len"] = torch.from_numpy(s["len"]).to(dev)
@@ -554,7 +554,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
     n_seg = len(sizes) * replicas * ((aus + cfg.restart_interval - 1) // cfg.restart_interval)
     b = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, np.full(len(sizes), nch), replicas, args.layout,
-              args.substreams, max(n_seg, 64))
+              0, max(n_seg, 64))          # 0: the library picks the kernels from the indexed substream counts
 
     def barrier():
         torch.cuda.synchronize(dev)

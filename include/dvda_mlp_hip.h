@@ -51,7 +51,10 @@ extern "C" {
 /* per-stream / per-segment status bits (0 = decoded exactly as the reference
  * decodes a well-formed stream).  The low 10 bits mirror oracle/mlp_oracle.h. */
 #define DVDA_ST_NO_SYNC      (1u << 0)   /* stream does not begin with a major sync             */
-#define DVDA_ST_SYNC_CHANGE  (1u << 1)   /* later major sync differs (reference drops the frame) */
+#define DVDA_ST_SYNC_CHANGE  (1u << 1)   /* a later major sync carries other stream parameters: that access
+                                            unit was dropped and decoding went on, as the reference does
+                                            (src/mlp.c:449-460) -- informational; together with
+                                            DVDA_ST_IRREGULAR: could not be resolved, not decoded        */
 #define DVDA_ST_PARITY       (1u << 2)
 #define DVDA_ST_CRC          (1u << 3)
 #define DVDA_ST_EOF          (1u << 4)   /* parse ran past a substream / frame end               */
@@ -64,21 +67,28 @@ extern "C" {
 #define DVDA_ST_IRREGULAR    (1u << 16)  /* frame chain does not land on the next major sync     */
 #define DVDA_ST_TIMING       (1u << 17)  /* an access unit's PCM-frame count differs from the
                                             stream's standard 40/80/160: stream decoded in order
-                                            by the general pass                                  */
+                                            by the sequential pass                               */
 #define DVDA_ST_MIDFRAME     (1u << 18)  /* matrix-class parameters changed after a frame's
-                                            first block: segment re-decoded frame-buffered       */
+                                            first block: segment decoded by the chain passes
+                                            (rematrix per access unit, src/mlp.c:504-525)        */
 #define DVDA_ST_CHAINED      (1u << 19)  /* segment's first block uses the FIR history of the
-                                            previous segment: decoded as part of a run           */
+                                            previous segment (the reference never clears it):
+                                            decoded by the chain passes                          */
 #define DVDA_ST_OVERFLOW     (1u << 20)  /* output capacity (out_stride) too small               */
 #define DVDA_ST_TRUNCATED    (1u << 21)  /* stream ends inside a frame (tail not consumed)       */
-#define DVDA_ST_CAPACITY     (1u << 22)  /* general-pass workspace exhausted (too many deferred runs) */
-#define DVDA_ST_GENERAL      (1u << 23)  /* segment was decoded by the general pass (informational)   */
+#define DVDA_ST_CAPACITY     (1u << 22)  /* more major syncs than max_segments: the stream (and those behind
+                                            it) were indexed only in part -- create a larger context     */
+#define DVDA_ST_GENERAL      (1u << 23)  /* segment was decoded by a pass behind the fast pass (informational) */
 #define DVDA_ST_FALSE_SYNC   (1u << 24)  /* segment-level only: a sync pattern inside another segment's
                                             frame chain (payload / padding bytes), resolved and skipped */
-/* DVDA_ST_CHAINED, _MIDFRAME and _TIMING are raised by the fast pass and then decoded exactly by
- * the general pass that follows it; they stay set as information.  Bits that do not invalidate
- * the PCM: */
-#define DVDA_ST_BENIGN (DVDA_ST_TRUNCATED | DVDA_ST_CHAINED | DVDA_ST_MIDFRAME | DVDA_ST_TIMING | DVDA_ST_GENERAL)
+#define DVDA_ST_SEQ          (1u << 25)  /* IIR taps, a restart header inside an access unit, or very dense
+                                            parameter changes in a chained segment: stream decoded in order
+                                            by the sequential pass                                        */
+/* DVDA_ST_CHAINED, _MIDFRAME, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
+ * the passes behind it (chain passes: parse in parallel, the filter recursion alone per channel, rematrix
+ * in parallel; or the sequential pass); they stay set as information.  Bits that do not invalidate the PCM: */
+#define DVDA_ST_BENIGN (DVDA_ST_TRUNCATED | DVDA_ST_CHAINED | DVDA_ST_MIDFRAME | DVDA_ST_TIMING | DVDA_ST_GENERAL | \
+                        DVDA_ST_SEQ | DVDA_ST_SYNC_CHANGE)
 
 typedef struct dvda_mlp_hip_ctx dvda_mlp_hip_ctx;
 
@@ -98,8 +108,10 @@ typedef struct dvda_mlp_stream_info {
 /* ------------------------------------------------------------------ tier A */
 
 /* Creates a decode context on HIP device `device` able to hold an index for up
- * to max_streams streams / max_segments restart segments.  Device workspace is
- * allocated here, never inside the decode calls (graph-capture friendly). */
+ * to max_streams streams / max_segments restart segments.  The workspace of the index and of the
+ * fast pass is allocated here.  A batch that needs the passes behind the fast pass (chained FIR
+ * history, mid-frame parameter changes, non-standard timing) grows their workspace on first use
+ * inside dvda_mlp_hip_decode. */
 int dvda_mlp_hip_create(dvda_mlp_hip_ctx **ctx, int device, uint32_t max_streams,
                         uint32_t max_segments);
 void dvda_mlp_hip_destroy(dvda_mlp_hip_ctx *ctx);
@@ -115,7 +127,10 @@ int dvda_mlp_hip_index(dvda_mlp_hip_ctx *ctx, const uint8_t *d_bytes, uint64_t t
 
 /* Decodes every indexed segment.  Stream i's PCM is written planar at
  * d_pcm[d_out_off[i] + channel * d_out_stride[i] + pcm_frame], channel in
- * RIFF-WAVE order (reference src/mlp.c:416-438, 527-533). */
+ * RIFF-WAVE order (reference src/mlp.c:416-438, 527-533).
+ * The call waits once on `stream` for the fast pass: a 32-byte summary tells the host whether the
+ * chain passes / the sequential pass have anything to do (they are not launched otherwise); what it
+ * enqueues after that is asynchronous again. */
 int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d_out_off,
                         const uint64_t *d_out_stride, void *stream);
 
@@ -138,14 +153,15 @@ int dvda_mlp_hip_stream_info(dvda_mlp_hip_ctx *ctx, dvda_mlp_stream_info *infos,
 /* Number of segments found by the last index call (blocks on `stream`). */
 int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *ctx, uint32_t *n_segments, void *stream);
 
-/* Average duration in milliseconds of the decode kernel launches recorded since
- * the last call (HIP events on the launch stream); *launches receives the count.
- * Blocks until those launches have finished. */
+/* Average duration in milliseconds of the fast-pass kernel launches recorded since
+ * the last call (HIP events on the launch stream, a ring of the newest 256 decode calls made at
+ * create time); *launches receives the count.  Blocks until those launches have finished. */
 int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *launches);
 
-/* Number of lanes the decode kernels use per segment: 1 when every stream of the batch is known
- * to carry a single substream starting at channel 0 (faster; anything else in the batch is
- * reported as DVDA_ST_ENVELOPE), 2 (default) otherwise. */
+/* Which fast-pass kernels run.  0 (default): chosen per batch from the substream counts the index
+ * found -- streams with one substream take the one-lane-per-segment kernel, streams with two the
+ * two-wave kernel, a mixed batch both (a kernel whose class is absent exits at once).  1 / 2 force one
+ * kernel for the whole batch (1: a two-substream stream is then reported as DVDA_ST_ENVELOPE). */
 int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
 
 /* Per-segment results of the last decode (blocks on `stream`). */
@@ -171,6 +187,14 @@ const char *dvda_mlp_hip_version(void);
  * 9-bit peek) and returns host_out[book * 512 + peek] = value | length << 8 (value 0xFF = invalid
  * code; book 0 = no code = 0).  The tables it must equal are reference src/mlp_codebook{1,2,3}.json. */
 int dvda_mlp_hip_selftest_huff(int device, uint32_t *host_out);
+
+/* Self-test: reads n fields from host_bytes with the kernels' MSB-first bit reader on the device --
+ * widths[i] > 0: unsigned field of that many bits (0..32), < 0: signed field of -widths[i] bits (sign bit
+ * first, two's complement), 0: nothing -- into host_out[i].  resident != 0 takes the unsigned fields
+ * (< 32 bits) through the row loop's branch-free read.  The contract is reference
+ * src/bitstream.c:1077-1111, 1198-1206; its known answers are src/bitstream.c:4864-4868, 4940-4944. */
+int dvda_mlp_hip_selftest_bits(int device, const uint8_t *host_bytes, uint32_t n_bytes, const int32_t *host_widths,
+                               uint32_t n, int64_t *host_out, uint32_t resident);
 
 /* ------------------------------------------------------------------ PCM tier */
 /* Raw-PCM AOB tracks: what reference src/dvd-audio.c:1016-1084 (decode_pcm_audio),

@@ -1,0 +1,475 @@
+// mlp_chain.h -- the chain passes: segments the fused fast pass cannot decode on its own.
+//
+// The reference never clears a channel's FIR history (src/mlp.c:297-304, 1302): a segment whose first block
+// runs FIR taps (ST_CHAINED) continues the recursion of the segment before it, and on a stream without raw
+// lead-in blocks that makes the whole title ONE dependency chain.  Only the recursion itself is serial --
+// filter_channel (src/mlp.c:1243-1306), a dozen instructions per sample -- so the work is cut there:
+//
+//   parse    k_decode<.., PARSE>   one lane per deferred (segment, substream), all in parallel: the bitstream
+//            (mlp_decode.h)        parse with everything but the filter -- residuals, bypassed LSBs and noise
+//                                  seeds into eight planes per segment, the filter parameters of every block
+//                                  that sets them into block records, the rematrix parameters each access unit
+//                                  ends with into one record per unit
+//   filter   k_chain_filter        one lane per (chain, substream, channel): the recursion and nothing else,
+//                                  through every segment of the chain, in place on the channel's plane
+//   rematrix k_chain_rematrix      one lane per PCM frame: noise, matrices, output shift, RIFF order -- per
+//                                  access unit with the parameters its LAST block left (src/mlp.c:504-525), which
+//                                  is also what a segment with mid-frame parameter changes (ST_MIDFRAME) needs
+//
+// k_chain_plan + a 3-channel scan + k_chain_lists lay out the workspaces and list the deferred segments and
+// the chain heads.  Streams with non-standard timing, IIR taps or restart headers inside a frame go to the
+// sequential pass instead (ST_TIMING / ST_SEQ, mlp_decode.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mlp_decode.h"
+
+namespace mlp {
+
+struct ChainArgs {
+    const SegRec *seg;
+    const uint32_t *seg_fbase;
+    const uint32_t *n_seg_ptr;
+    uint32_t max_seg;
+    StreamRec *streams;
+    uint32_t *seg_status;
+    uint32_t *seg_rows;
+    const uint32_t *seg_meta;
+    uint4 *plan;                   // [max_seg + 1]: exclusive scan of (rows, deferred, heads, 0); [n] = totals
+    uint32_t *def_list;            // deferred segments, in order
+    uint32_t *head_list;           // first segment of every chain
+    int32_t *res;
+    const uint32_t *brec;
+    const uint32_t *frec;
+    int32_t *fir_ws;
+    uint32_t total_lanes;
+    const int32_t *init_fir;
+    int32_t *pcm;
+    const uint64_t *out_off;
+    const uint64_t *out_stride;
+    uint32_t interleaved;
+};
+
+__device__ __forceinline__ uint32_t chain_n_seg(const ChainArgs &a)
+{
+    const uint32_t n = *a.n_seg_ptr;
+    return n > a.max_seg ? a.max_seg : n;
+}
+
+// is segment i one the chain passes decode?  (flagged by the fast pass, free of errors, standard timing)
+__device__ __forceinline__ bool chain_deferred(const ChainArgs &a, uint32_t i)
+{
+    const SegRec r = a.seg[i];
+    if ((r.flags & (SEG_DEAD | ST_FATAL_INDEX)) || r.nframes == 0)
+        return false;
+    const uint32_t ss = a.seg_status[i];
+    if (!(ss & (ST_CHAINED | ST_MIDFRAME)) || (ss & ~ST_INFO))
+        return false;
+    return (a.streams[r.stream].status & (ST_TIMING | ST_SEQ)) == 0;
+}
+
+__device__ __forceinline__ uint32_t chain_prev_live(const ChainArgs &a, uint32_t i, uint32_t first)
+{
+    uint32_t p = i;
+    while (p > first) {
+        p--;
+        if (!(a.seg[p].flags & SEG_DEAD))
+            return p;
+    }
+    return i;       // none
+}
+
+// one lane per segment: (rows, deferred, head) into plan[] for the scan
+__global__ __launch_bounds__(256) void k_chain_plan(ChainArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = chain_n_seg(a);
+    if (i >= n)
+        return;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (chain_deferred(a, i)) {
+        const SegRec r = a.seg[i];
+        const StreamRec sr = a.streams[r.stream];
+        const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
+        v.x = (r.nframes - r.ndrop) * rpa;
+        v.y = 1;
+        // a chain starts where the history does not come from a deferred segment: no FIR taps on the first
+        // block, the stream's first segment, or a segment before it that the fast pass finished
+        bool head = !(a.seg_status[i] & ST_CHAINED);
+        if (!head) {
+            const uint32_t p = chain_prev_live(a, i, sr.first_seg);
+            head = p == i || !chain_deferred(a, p);
+        }
+        v.z = head ? 1u : 0u;
+    }
+    a.plan[i] = v;
+}
+
+// ---- exclusive scan of uint4 (.x .y .z independent channels), n from the device; out[n] = totals
+__device__ __forceinline__ uint4 add4(const uint4 p, const uint4 q)
+{
+    return make_uint4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+}
+
+__global__ __launch_bounds__(1024) void k_scan4_blocks(uint4 *__restrict__ io, uint4 *__restrict__ block_sum,
+                                                       const uint32_t *__restrict__ n_ptr, uint32_t n_cap)
+{
+    __shared__ uint4 s_v[1024];
+    uint32_t n = *n_ptr;
+    if (n > n_cap)
+        n = n_cap;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint4 v = i < n ? io[i] : make_uint4(0, 0, 0, 0);
+    s_v[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint4 t = threadIdx.x >= (uint32_t)o ? s_v[threadIdx.x - o] : make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        s_v[threadIdx.x] = add4(s_v[threadIdx.x], t);
+        __syncthreads();
+    }
+    if (i < n) {
+        const uint4 inc = s_v[threadIdx.x];
+        io[i] = make_uint4(inc.x - v.x, inc.y - v.y, inc.z - v.z, 0);
+    }
+    if (threadIdx.x == 1023)
+        block_sum[blockIdx.x] = s_v[1023];
+}
+
+// single workgroup: exclusive scan of the block sums in place (n_blocks <= 1M), total behind them
+__global__ __launch_bounds__(1024) void k_scan4_sums(uint4 *__restrict__ sums, uint32_t n_blocks)
+{
+    __shared__ uint4 s_part[1024];
+    const uint32_t per = (n_blocks + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per;
+    const uint32_t hi = lo + per < n_blocks ? lo + per : n_blocks;
+    uint4 sum = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lo; i < hi; i++)
+        sum = add4(sum, sums[i]);
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint4 t = threadIdx.x >= (uint32_t)o ? s_part[threadIdx.x - o] : make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        s_part[threadIdx.x] = add4(s_part[threadIdx.x], t);
+        __syncthreads();
+    }
+    uint4 run = threadIdx.x ? s_part[threadIdx.x - 1] : make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint4 v = sums[i];
+        sums[i] = run;
+        run = add4(run, v);
+    }
+    if (threadIdx.x == 1023)
+        sums[n_blocks] = s_part[1023];
+}
+
+__global__ __launch_bounds__(1024) void k_scan4_add(uint4 *__restrict__ io, const uint4 *__restrict__ block_base,
+                                                    uint32_t n_blocks, const uint32_t *__restrict__ n_ptr, uint32_t n_cap)
+{
+    uint32_t n = *n_ptr;
+    if (n > n_cap)
+        n = n_cap;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n)
+        io[i] = add4(io[i], block_base[blockIdx.x]);
+    if (i == 0)
+        io[n] = block_base[n_blocks];
+}
+
+// after the scan: the deferred segments and the chain heads as dense lists
+__global__ __launch_bounds__(256) void k_chain_lists(ChainArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = chain_n_seg(a);
+    if (i >= n)
+        return;
+    const uint4 p = a.plan[i], q = a.plan[i + 1];
+    if (q.y != p.y)
+        a.def_list[p.y] = i;
+    if (q.z != p.z)
+        a.head_list[p.z] = i;
+}
+
+// ------------------------------------------------------------------------------------------------ filter
+// filter_channel (src/mlp.c:1278-1300) for one sample, history h[] most recent first at rotation T: the
+// newest value sits in h[(8 - T) & 7] and the result replaces the oldest, so eight consecutive steps
+// T = 0..7 need no register moves.  The multiply by the newest value comes last: everything before it is
+// independent of the previous step's result.
+template <int T>
+__device__ __forceinline__ int32_t fir_step_rot(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask,
+                                                int32_t residual)
+{
+    int64_t acc = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; j--)
+        acc += (int64_t)c[j] * (int64_t)h[(8 - T + j) & 7];
+    const int32_t ss = (int32_t)(acc >> shift);
+    const int32_t v = (int32_t)(((uint32_t)ss + (uint32_t)residual) & qmask);
+    h[(7 - T) & 7] = v;
+    return v;
+}
+
+__device__ __forceinline__ int32_t fir_step_one(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask,
+                                                int32_t residual)
+{
+    int64_t acc = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; j--)
+        acc += (int64_t)c[j] * (int64_t)h[j];
+    const int32_t ss = (int32_t)(acc >> shift);
+    const int32_t v = (int32_t)(((uint32_t)ss + (uint32_t)residual) & qmask);
+#pragma unroll
+    for (int j = 7; j > 0; j--)
+        h[j] = h[j - 1];
+    h[0] = v;
+    return v;
+}
+
+__device__ __forceinline__ void fir_step8(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask, int4 &p,
+                                          int4 &q)
+{
+    p.x = fir_step_rot<0>(h, c, shift, qmask, p.x);
+    p.y = fir_step_rot<1>(h, c, shift, qmask, p.y);
+    p.z = fir_step_rot<2>(h, c, shift, qmask, p.z);
+    p.w = fir_step_rot<3>(h, c, shift, qmask, p.w);
+    q.x = fir_step_rot<4>(h, c, shift, qmask, q.x);
+    q.y = fir_step_rot<5>(h, c, shift, qmask, q.y);
+    q.z = fir_step_rot<6>(h, c, shift, qmask, q.z);
+    q.w = fir_step_rot<7>(h, c, shift, qmask, q.w);
+}
+
+// One lane per (chain, substream, channel slot): 16 lanes per chain (2 substreams x 8 slots, 6 used).
+__global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ci = g >> 4, sub = (g >> 3) & 1u, k = g & 7u;
+    const uint32_t n = chain_n_seg(a);
+    if (ci >= a.plan[n].z || k >= 6u)
+        return;
+    uint32_t seg = a.head_list[ci];
+    const SegRec r0 = a.seg[seg];
+    const StreamRec sr = a.streams[r0.stream];
+    const uint32_t S = (sr.sync >> 24) & 0xFu;
+    if (sub >= S)
+        return;
+    const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
+    const size_t TL = a.total_lanes;
+    const bool writer = sub == 0 && k == 0;         // the lane that publishes per-segment results
+
+    int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t shift = 0, qmask = 0xFFFFFFFFu;
+    uint32_t prev_meta = 0;                         // channel range of the segment the history comes from
+    uint32_t fail = 0;                              // why the chain stops (status bits for what follows)
+    if (a.seg_status[seg] & ST_CHAINED) {
+        if (seg == sr.first_seg) {
+            if (a.init_fir) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    h[j] = a.init_fir[((size_t)r0.stream * 2 + sub) * 48 + k * 8 + j];
+            } else {
+                fail = ST_ENVELOPE;     // FIR taps on a fresh decoder: the reference reads out of bounds
+            }
+        } else {
+            const uint32_t p = chain_prev_live(a, seg, sr.first_seg);
+            const uint32_t ps = a.seg_status[p] | (a.seg[p].flags & ST_FATAL_INDEX);
+            prev_meta = a.seg_meta[(size_t)p * 2 + sub];
+            if ((ps & ~ST_INFO) || (ps & (ST_CHAINED | ST_MIDFRAME)) || !(prev_meta & 0x100u)) {
+                fail = (ps & ~ST_INFO) ? (ps & ~ST_INFO) : ST_ENVELOPE;     // nothing to continue from
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    h[j] = a.fir_ws[(size_t)(k * 8 + j) * TL + (size_t)p * 2 + sub];
+            }
+        }
+    }
+
+    for (;;) {
+        const SegRec r = a.seg[seg];
+        const uint32_t ss = a.seg_status[seg];
+        const uint32_t meta = a.seg_meta[(size_t)seg * 2 + sub];
+        if (!fail) {
+            if (ss & ~ST_INFO)
+                fail = ss & ~ST_INFO;               // the parse pass stopped on an error here
+            else if ((ss & (ST_TIMING | ST_SEQ)) || !(meta & 0x100u))
+                fail = ST_SEQ;                      // the sequential pass takes the stream
+            else if (prev_meta && (ss & ST_CHAINED) && ((prev_meta ^ meta) & 0xFFu))
+                fail = ST_ENVELOPE;                 // the substream's channel range changes under a running history
+        }
+        if (fail) {
+            // the chain ends here: what follows cannot be decoded by these passes.  An error is handed on
+            // (the reference would have stopped at it); ST_SEQ needs nothing -- the whole stream is decoded
+            // again, in order
+            if (writer && fail != ST_SEQ)
+                atomicOr(&a.seg_status[seg], fail & ~ST_INFO);
+        } else {
+            const uint32_t min_ch = meta & 0xFu, max_ch = (meta >> 4) & 0xFu;
+            const uint32_t R = (r.nframes - r.ndrop) * rpa;
+            const uint4 pl = a.plan[seg];
+            if (k <= max_ch - min_ch) {
+                int32_t *P = a.res + (size_t)pl.x * 8u + (size_t)(min_ch + k) * R;
+                const uint32_t *rp = a.brec + 2ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
+                uint32_t row = 0;
+                uint32_t next_row = rp[0];
+                while (row < R) {
+                    while (next_row == row) {
+                        // ---- a block that sets filter parameters starts here (src/mlp.c:1033-1068, 1260-1270)
+                        const uint32_t mask = rp[1];
+                        if ((mask >> k) & 1u) {
+                            const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & ((1u << k) - 1u));
+                            const uint32_t pk = w[0];
+                            shift = pk & 0xFu;
+                            qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                c[2 * j] = lo16(w[1 + j]);
+                                c[2 * j + 1] = hi16(w[1 + j]);
+                            }
+                        }
+                        rp += 2 + BREC_SLOT_WORDS * __popc(mask);
+                        next_row = rp[0];
+                    }
+                    const uint32_t run_end = (next_row > row && next_row < R) ? next_row : R;
+                    while (row < run_end && (row & 3u)) {
+                        P[row] = fir_step_one(h, c, shift, qmask, P[row]);
+                        row++;
+                    }
+                    // sixteen PCM frames per turn, the next sixteen already on their way
+                    if (row + 16 <= run_end) {
+                        int4 v0 = *reinterpret_cast<const int4 *>(P + row), v1 = *reinterpret_cast<const int4 *>(P + row + 4),
+                             v2 = *reinterpret_cast<const int4 *>(P + row + 8), v3 = *reinterpret_cast<const int4 *>(P + row + 12);
+                        while (row + 16 <= run_end) {
+                            int4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+                            const bool more = row + 32 <= run_end;
+                            if (more) {
+                                n0 = *reinterpret_cast<const int4 *>(P + row + 16);
+                                n1 = *reinterpret_cast<const int4 *>(P + row + 20);
+                                n2 = *reinterpret_cast<const int4 *>(P + row + 24);
+                                n3 = *reinterpret_cast<const int4 *>(P + row + 28);
+                            }
+                            fir_step8(h, c, shift, qmask, v0, v1);
+                            fir_step8(h, c, shift, qmask, v2, v3);
+                            *reinterpret_cast<int4 *>(P + row) = v0;
+                            *reinterpret_cast<int4 *>(P + row + 4) = v1;
+                            *reinterpret_cast<int4 *>(P + row + 8) = v2;
+                            *reinterpret_cast<int4 *>(P + row + 12) = v3;
+                            row += 16;
+                            v0 = n0;
+                            v1 = n1;
+                            v2 = n2;
+                            v3 = n3;
+                        }
+                    }
+                    while (row + 8 <= run_end) {
+                        int4 v0 = *reinterpret_cast<const int4 *>(P + row), v1 = *reinterpret_cast<const int4 *>(P + row + 4);
+                        fir_step8(h, c, shift, qmask, v0, v1);
+                        *reinterpret_cast<int4 *>(P + row) = v0;
+                        *reinterpret_cast<int4 *>(P + row + 4) = v1;
+                        row += 8;
+                    }
+                    while (row < run_end) {
+                        P[row] = fir_step_one(h, c, shift, qmask, P[row]);
+                        row++;
+                    }
+                }
+            }
+            // ---- the history at the segment's end (what a later call, or the next chain, continues from)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                a.fir_ws[(size_t)(k * 8 + j) * TL + (size_t)seg * 2 + sub] = h[j];
+            if (writer)
+                atomicOr(&a.seg_status[seg], ST_GENERAL);       // filtered: the rematrix pass may take it
+            prev_meta = meta;
+        }
+        // ---- on to the next segment of the stream while it continues this history
+        uint32_t nxt = seg + 1;
+        while (nxt < n && a.seg[nxt].stream == r.stream && (a.seg[nxt].flags & SEG_DEAD))
+            nxt++;
+        if (nxt >= n || a.seg[nxt].stream != r.stream)
+            break;
+        const uint4 pn = a.plan[nxt], qn = a.plan[nxt + 1];
+        if (qn.y == pn.y || qn.z != pn.z)
+            break;                                  // not deferred, or the head of the next chain
+        seg = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- rematrix
+// One lane per PCM frame of a deferred segment: noise, matrices, output shift (src/mlp.c:1308-1358, 515-525),
+// RIFF channel order (src/mlp.c:416-438, 527-533).  grid = (deferred segments, ceil(longest segment / 256)).
+__global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
+{
+    const uint32_t n = chain_n_seg(a);
+    const uint32_t j = blockIdx.x;
+    if (j >= a.plan[n].y)
+        return;
+    const uint32_t seg = a.def_list[j];
+    const uint32_t ss = a.seg_status[seg];
+    if (!(ss & ST_GENERAL) || (ss & ~ST_INFO))
+        return;                                     // not filtered (its chain stopped before it)
+    const SegRec r = a.seg[seg];
+    const StreamRec sr = a.streams[r.stream];
+    const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
+    const uint32_t R = (r.nframes - r.ndrop) * rpa;
+    const uint32_t row = blockIdx.y * 256u + threadIdx.x;
+    const uint64_t row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
+    const uint64_t out_stride = a.out_stride[r.stream];
+    if (row == 0) {
+        a.seg_rows[seg] = R;
+        if (row0 + R > out_stride)
+            atomicOr(&a.seg_status[seg], ST_OVERFLOW);          // rows = the size needed
+    }
+    if (row >= R)
+        return;
+    const uint4 pl = a.plan[seg];
+    const int32_t *P = a.res + (size_t)pl.x * 8u + row;
+    int32_t ch[MAXCH];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+        ch[c] = P[(size_t)c * R];
+    ch[6] = ch[7] = 0;
+    const uint32_t bypass_bits = (uint32_t)P[(size_t)6 * R];
+    const uint32_t seed = (uint32_t)P[(size_t)7 * R];
+    const uint32_t *F = a.frec + ((size_t)(pl.x / 40u) + row / rpa) * FREC_WORDS;
+    const uint32_t w0 = F[0];
+    const uint32_t noise_shift = w0 & 0xFFu, matrix_len = (w0 >> 8) & 0xFFu, mmc = w0 >> 16;
+    const uint32_t outch_pack = F[1], qss_pack = F[2], oshift_pack = F[3];
+    const uint32_t shifted = (seed >> 7) & 0xFFFFu;
+    const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
+    const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
+    for (uint32_t m = 0; m < matrix_len; m++) {
+        const uint32_t *M = F + 4 + m * 5;
+        const uint32_t nz = M[4];
+        int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const uint32_t w = M[c >> 1];
+            acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(w) : lo16(w));
+        }
+        const uint32_t oc = nib(outch_pack, m);
+        const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) + ((bypass_bits >> m) & 1u));
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            ch[c] = (uint32_t)c == oc ? nv : ch[c];
+    }
+    if (oshift_pack) {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            if ((uint32_t)c <= mmc)
+                ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
+    }
+    const uint64_t orow = row0 + row;
+    if (orow >= out_stride)
+        return;
+    const uint32_t assignment = (sr.sync >> 16) & 0x1F;
+    const uint32_t nch_out = channel_count(assignment);
+    const uint32_t wavepk = wave_pack(assignment);
+    int32_t *out = a.pcm + a.out_off[r.stream];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+        if ((uint32_t)c < nch_out)
+            out[a.interleaved ? orow * nch_out + nib(wavepk, c) : (uint64_t)nib(wavepk, c) * out_stride + orow] = ch[c];
+}
+
+} // namespace mlp

@@ -119,12 +119,36 @@ constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_R
                    ST_PARAMS = 1u << 6, ST_HUFFMAN = 1u << 7, ST_FILTER = 1u << 8,
                    ST_ENVELOPE = 1u << 9, ST_IRREGULAR = 1u << 16, ST_TIMING = 1u << 17,
                    ST_MIDFRAME = 1u << 18, ST_CHAINED = 1u << 19, ST_OVERFLOW = 1u << 20,
-                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23;
-constexpr uint32_t ST_FATAL_INDEX = (1u << 0) | (1u << 1) | ST_EOF | ST_IRREGULAR;
-// conditions the fast pass only reports; the general pass (k_decode<.., GENERAL = true>) decodes them
-constexpr uint32_t ST_DEFERRED = ST_CHAINED | ST_MIDFRAME | ST_TIMING;
+                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23, ST_SEQ = 1u << 25;
+constexpr uint32_t ST_SYNC_CHANGE = 1u << 1, ST_TRUNCATED = 1u << 21;
+constexpr uint32_t ST_FATAL_INDEX = (1u << 0) | ST_EOF | ST_IRREGULAR;
+// conditions the fast pass only reports.  ST_CHAINED / ST_MIDFRAME segments are decoded by the three
+// chain passes (parse -> filter recurrence -> rematrix, mlp_chain.h); a stream with ST_TIMING or ST_SEQ
+// is decoded in order by the sequential pass (k_decode<.., GENERAL = true>)
+constexpr uint32_t ST_DEFERRED = ST_CHAINED | ST_MIDFRAME | ST_TIMING | ST_SEQ;
+// bits that are information, not errors
+constexpr uint32_t ST_INFO = ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | ST_TRUNCATED | ST_SYNC_CHANGE;
 constexpr int FB_ROWS = 1024;                   // PCM frames one access unit may hold in the general pass
 constexpr int FB_WORDS = FB_ROWS * (MAXCH + 1); // 8 channels + bypassed-LSB bits per frame
+
+// device -> host after the fast pass (one small copy, then the host decides what else to launch)
+struct DecodeSummary {
+    unsigned long long chain_rows; // PCM frames (standard timing) of the segments flagged ST_CHAINED / ST_MIDFRAME
+    uint32_t chain_segs;           // how many such segments
+    uint32_t chain_max_rows;       // the longest of them
+    uint32_t seq_streams;          // streams flagged ST_TIMING / ST_SEQ (counted by k_finalize)
+    uint32_t pad[3];
+};
+constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
+constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs
+// block-record dwords one (segment, substream) may use: one full record (2 header words + 6 slots) per 32
+// PCM frames on average -- the BASELINE recipe needs a tenth of that; a stream that changes parameters
+// more often than that is decoded by the sequential pass instead (ST_SEQ)
+__host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return rows + 64u; }
+// where the chain workspaces of a deferred segment start, from its ChainPlan entry (rows / deferred
+// segments before it): planes at res + 8 * rows_before; block records (two substreams) at
+// brec + 2 * rows_before + 128 * segs_before; per-access-unit records at frec[rows_before / 40 + unit]
+// (40 = the shortest access unit: a segment's rows / 40 is at least its number of units)
 
 struct DecodeArgs {
     const uint8_t *bytes;
@@ -144,12 +168,23 @@ struct DecodeArgs {
     uint32_t total_lanes;
     unsigned long long *dbg;       // diagnostic builds only (DVDA_EXP_STAMP): per-phase cycle sums
     int32_t *fir_ws;               // FIR history at each segment's end: [(slot*8 + j) * total_lanes + lane]
-    int32_t *fb;                   // general pass: frame buffers [fb_slots][FB_ROWS][9]
-    uint32_t *fb_counter;
-    uint32_t fb_slots;
+    int32_t *fb;                   // sequential pass: frame buffers [lane pair][FB_ROWS][9]
     const int32_t *init_fir;       // optional: FIR history a stream starts with, [stream][2][48] (streaming tier)
-    uint32_t *deferred;            // set by the fast pass when anything is left to the general pass
+    DecodeSummary *summary;        // what the fast pass leaves to the passes behind it (read by the host)
     uint32_t interleaved;          // PCM layout: 0 planar, 1 frame-major (see k_decode)
+    const uint32_t *cls;           // [2]: the batch holds streams with one / two substreams (set by the index)
+    uint32_t only_S;               // fast pass: decode only streams with this many substreams (0 = all)
+    uint32_t *seg_meta;            // per workspace lane: min_ch | max_ch << 4 at the segment's end
+    // sequential pass: lane pair j decodes stream list[list_base + j] from its first segment on
+    // chain parse pass: lane (pair) j parses deferred segment list[list_base + j]
+    const uint32_t *list;
+    uint32_t list_base, list_n;
+    // chain parse pass: where segment `seg` puts its planes / records (ChainPlan, mlp_chain.h)
+    const uint4 *plan;             // per segment: .x deferred rows before it, .y deferred segments before it,
+                                   //              .z chains before it
+    int32_t *res;                  // [deferred rows][8 planes], plane-major per segment
+    uint32_t *brec;                // block records, per (segment, substream)
+    uint32_t *frec;                // per access unit: the rematrix parameters its last block leaves
 };
 
 __device__ const CrcTable d_crc = make_crc();
@@ -482,12 +517,15 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 // (src/dvd-audio.c:781-792) -- instead of planar pcm[off + wave_channel * stride + frame], the order
 // decode_packet appends to `samples` (src/mlp.c:527-533).  A lane's flush is then ONE contiguous
 // run of 16 * channels bytes (whole 32-byte sectors) instead of six 16-byte pieces in six places.
-template <int NS, bool PAIRED, bool GENERAL, bool ILV = false>
-__global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
+template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false>
+__global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
+    static_assert(!(GENERAL && PARSE), "one mode at a time");
+    static_assert(!GENERAL || PAIRED, "the sequential pass always runs as lane pairs");
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
-    if (GENERAL && *a.deferred == 0)
-        return;                                                   // nothing was deferred: whole grid exits
+    // fast pass: the batch holds no stream of this kernel's class (set by the index): whole grid exits
+    if (!GENERAL && a.only_S && a.cls[a.only_S - 1u] == 0)
+        return;
     __shared__ uint8_t s_crc[4 * 256];
     // fast pass over two-substream streams: a wave carries ONE substream of 64 segments.  The odd
     // wave of a group has each segment's last substream (the only one of a single-substream stream):
@@ -496,13 +534,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     // pair trades a row's channels through s_xw[row parity], one block barrier per row.  (Measured
     // on the 2-substream bench shape against the lane-pair layout, which ran every wave through the
     // long substream's slots and the rematrix; 2-, 4- and 8-wave blocks were tried.)
-    constexpr bool WSPEC = PAIRED && !GENERAL;
+    constexpr bool WSPEC = PAIRED && !GENERAL && !PARSE;
+    constexpr bool SIDE = PAIRED && !WSPEC;                       // the two lanes of a segment side by side
     constexpr int THREADS = WSPEC ? WS_THREADS : DEC_THREADS;
     constexpr int WAVES = THREADS / 64;
     constexpr int GROUPS = WSPEC ? WAVES / 2 : 1;
+    constexpr int TP = PARSE ? 8 : 6;                             // staged planes: channels (+ bypassed LSBs, seed)
     __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
-    __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS : WAVES)][6][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging (fast pass)
-    __shared__ int32_t s_xch[(PAIRED && GENERAL) ? WAVES : 1][MAXCH][(PAIRED && GENERAL) ? 64 : 1];
+    __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
+    __shared__ int32_t s_xch[SIDE ? WAVES : 1][MAXCH][SIDE ? 64 : 1];
     __shared__ int32_t s_xw[WSPEC ? 2 : 1][GROUPS][MAXCH][WSPEC ? 64 : 1];
     __shared__ uint32_t s_alive[2][WAVES];
     // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
@@ -532,8 +572,23 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
-    uint32_t segi = WSPEC ? (blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
+    // which segment: the fast pass covers the index in order; the sequential pass starts lane pair j at the
+    // first segment of stream list[list_base + j]; the chain parse pass gives deferred segment
+    // list[list_base + j] to lane (pair) j
+    const uint32_t item = WSPEC ? (blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
+    uint32_t segi = item;
     bool active = segi < n_seg;
+    if (GENERAL || PARSE) {
+        active = item < a.list_n && (!PARSE || item < a.plan[n_seg].y);
+        segi = 0;
+        if (active) {
+            const uint32_t e = a.list[a.list_base + item];
+            segi = GENERAL ? a.streams[e].first_seg : e;
+            active = segi < n_seg;
+        }
+        if (!active)
+            segi = n_seg;           // (names no segment: nothing is published for this lane)
+    }
 
     SegRec sr;
     sr.off = sr.end = 0;
@@ -541,19 +596,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     sr.nframes = 0;
     sr.flags = 0;
     sr.sync = 0;
-    uint32_t fbase = 0, stream_sync = 0, stream_first = 0, stream_status = 0;
+    sr.ndrop = 0;
+    uint32_t fbase = 0, stream_sync = 0, stream_first = 0;
     if (active) {
         sr = a.seg[segi];
         stream_first = a.streams[sr.stream].first_seg;
         stream_sync = a.streams[sr.stream].sync;
-        stream_status = a.streams[sr.stream].status;
         fbase = a.seg_fbase[segi] - a.seg_fbase[stream_first];
     }
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
-    // substream handled by this lane; workspace lane = segment * L + substream in every layout
+    // substream handled by this lane; workspace lane = segment * 2 + substream in every layout and pass
     // (an even-wave lane of a single-substream stream is idle and names the stream's absent substream 1)
-    const uint32_t sub = WSPEC ? (ws_last == (S == 2 ? 1u : 0u) ? 1u : 0u) : gl0 - segi * L;
-    const uint32_t gl = WSPEC ? segi * 2u + sub : gl0;
+    const uint32_t sub = WSPEC ? (ws_last == (S == 2 ? 1u : 0u) ? 1u : 0u) : gl0 - item * L;
+    const uint32_t gl = segi * 2u + sub;
     uint32_t seg_lane = gl;                 // lane index that owns segment `segi` in the workspaces
     const uint32_t assignment = (stream_sync >> 16) & 0x1F;
     const uint32_t rpa = rows_per_au((stream_sync >> 8) & 0xF);
@@ -565,8 +620,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         active = false;                                         // reported by the index
     if (active && (sub >= S || sr.nframes == 0))
         active = false;
+    const bool mine = GENERAL || !a.only_S || S == a.only_S;    // else: the other kernel's stream, hands off
+    if (!mine)
+        active = false;
     if (active && S > L) {
-        status |= ST_ENVELOPE;                                  // 2-substream stream in a 1-lane launch
+        status |= ST_ENVELOPE;                                  // 2-substream stream in a forced 1-lane launch
         active = false;
     }
     if (active && (rpa == 0 || nch_out == 0)) {
@@ -582,71 +640,52 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     const bool owner = WS_BAL ? (adopt || (is_last_sub && !lends)) : is_last_sub;
 
     uint64_t out_base = 0, out_stride = 0;
-    if (active) {
+    if (active && !PARSE) {
         out_base = a.out_off[sr.stream];
         out_stride = a.out_stride[sr.stream];
     }
     uint64_t row0 = (uint64_t)fbase * rpa;           // first PCM frame of this segment in its stream
-    uint64_t row_limit = row0 + (uint64_t)sr.nframes * rpa;
-    // general pass: does this lane head a run, and does the whole stream go in order?
-    const bool seq = GENERAL && (stream_status & ST_TIMING);
-    bool resume_fir = false, general_head = false, resume_from_init = false;
-    uint32_t prev_seg = 0;
+    uint64_t row_limit = row0 + (uint64_t)(sr.nframes - sr.ndrop) * rpa;
+    // sequential pass: the whole stream in order from its first segment, one frame buffer per lane pair
+    constexpr bool seq = GENERAL;
+    bool resume_from_init = false;
     int32_t *fbuf = nullptr;
     if (GENERAL && active) {
         const uint32_t st_j = a.seg_status[segi];
-        bool head;
-        if (seq) {
-            head = segi == stream_first;
-        } else {
-            // segments the general pass has already decoded carry ST_GENERAL
-            const bool flagged = (st_j & (ST_CHAINED | ST_MIDFRAME)) != 0 && !(st_j & ST_GENERAL);
-            prev_seg = segi;                                    // previous LIVE segment of the stream
-            while (prev_seg > stream_first) {
-                prev_seg--;
-                if (!(a.seg[prev_seg].flags & SEG_DEAD))
-                    break;
-            }
-            const uint32_t st_p = prev_seg < segi ? a.seg_status[prev_seg] : 0u;
-            const bool prev_flagged = (st_p & (ST_CHAINED | ST_MIDFRAME)) != 0 && !(st_p & ST_GENERAL);
-            head = flagged && !((st_j & ST_CHAINED) && prev_flagged);
-            resume_fir = head && (st_j & ST_CHAINED);
-        }
-        bool resume_init = false;
-        if (head && (st_j & ST_CHAINED) && segi == stream_first) {
-            if (a.init_fir) {
-                resume_init = true;         // history carried over from an earlier call
-                resume_fir = false;
-            } else {
+        if (st_j & ST_CHAINED) {
+            if (a.init_fir)
+                resume_from_init = true;    // history carried over from an earlier call
+            else {
                 status |= ST_ENVELOPE;      // FIR taps on a fresh decoder: the reference reads out of bounds
-                head = false;
+                active = false;
             }
         }
-        if (st_j & ~(ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | (1u << 21)))
-            head = false;                   // a real error was already reported for this segment
-        if (head && is_last_sub) {
-            const uint32_t slot = atomicAdd(a.fb_counter, 1u);
-            if (slot >= a.fb_slots)
-                status |= ST_CAPACITY;
-            else
-                fbuf = a.fb + (size_t)slot * FB_WORDS;
-        }
-        if (PAIRED) {
-            // both lanes of a pair must agree on the capacity verdict
-            const uint32_t other = __shfl_xor(status & ST_CAPACITY, 1);
-            status |= other;
-        }
-        if (!head || (status & ST_CAPACITY))
-            active = false;
-        general_head = active;
-        resume_from_init = active && resume_init;
+        fbuf = a.fb + (size_t)item * FB_WORDS;
         if (active) {
-            atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | (1u << 21));
-            if (seq) {
-                row0 = 0;
-                row_limit = ~0ull;
-            }
+            atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
+            row0 = 0;
+            row_limit = ~0ull;
         }
+    }
+    // chain parse pass: the segment's planes [8][R] of residuals (+ bypassed LSBs, noise seeds) take the
+    // place of the PCM buffer
+    uint32_t seg_R = 0;                      // PCM frames of this segment at standard timing
+    uint32_t *brec = nullptr, *brec_end = nullptr;
+    uint32_t *frec = nullptr;
+    if (PARSE && active) {
+        const uint4 pl = a.plan[segi];
+        const uint32_t st_j = a.seg_status[segi];
+        seg_R = (sr.nframes - sr.ndrop) * rpa;
+        out_base = (uint64_t)pl.x * 8u;
+        out_stride = seg_R;
+        row0 = 0;
+        row_limit = seg_R;
+        const uint32_t cap = brec_capacity(seg_R);
+        brec = a.brec + 2ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap;
+        brec_end = brec + cap - 2u;                 // room for the terminator
+        frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
+        (void)st_j;
+        atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
     }
     // fast pass: rows this lane may still write (see the row loop)
     uint32_t room = 0;
@@ -655,12 +694,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         if (edge > row0)
             room = edge - row0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(edge - row0);
     }
-    const bool vec_ok = (((out_base | out_stride) & 3) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0);   // 16-byte aligned rows
+    const bool vec_ok = PARSE || ((((out_base | out_stride) & 3) == 0) &&
+                                  ((reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0));   // 16-byte aligned rows
     // frame-major, and every segment of this wave is 6 channels in identity RIFF order (all 6-channel
     // assignments but 0x14) into an aligned buffer: the tile is staged frame-major too -- [frame][channel]
     // instead of [channel][frame] -- and a flush reads it front to back.  Decided once per wave.
-    const bool ilv_direct = ILV && !GENERAL &&
+    const bool ilv_direct = ILV && !GENERAL && !PARSE &&
                             __all(segi >= n_seg || (nch_out == 6u && (wavepk & 0xFFFFFFu) == 0x543210u && vec_ok));
 
     BitReader rd;
@@ -703,14 +742,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
 #pragma unroll
         for (int j = 0; j < 4; j++)
             mreg[m][j] = 0;
-    if (GENERAL && resume_fir) {
-        // history left by the previous segment's lane in the fast pass
-#pragma unroll
-        for (int k = 0; k < NS; k++)
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                st[k][j] = a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + (prev_seg * L + sub)];
-    }
     if (GENERAL && resume_from_init) {
 #pragma unroll
         for (int k = 0; k < NS; k++)
@@ -740,7 +771,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
     uint64_t row = row0;              // next output PCM frame index
     uint32_t rows_written = 0;
     uint32_t rows_done = 0;           // rows decoded by this lane (lockstep across the wave)
-
+    uint32_t au_idx = 0;              // chain parse pass: PCM-yielding access units of the segment so far
+    uint32_t drops_seen = 0;          // frames dropped so far (major sync with other stream parameters)
 
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
     //      ch[0..7] in MLP channel order, shifted in place
@@ -813,10 +845,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         bool hdr_parsed = false;       // this lane parsed a block header in this iteration
         // =================================================== header phase
         if (__builtin_expect(active && rows_left == 0, 0)) {
-            if (!in_frame) {
+            // (a loop only because of dropped frames: a frame that carries a major sync with other stream
+            //  parameters yields nothing and the next one is looked at, src/mlp.c:449-460)
+            while (active && !in_frame) {
                 if (frames_done == sr.nframes) {
-                    // ---- segment finished: publish it; the general pass walks on while the next
-                    //      segment of the stream depends on this one (or the stream goes in order)
+                    // ---- segment finished: publish it; the sequential pass walks on to the stream's next one
                     if (GENERAL && a.fir_ws) {
 #pragma unroll
                         for (int k = 0; k < NS; k++)
@@ -824,32 +857,31 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                             for (int j = 0; j < 8; j++)
                                 a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + seg_lane] = st[k][j];
                     }
+                    if (GENERAL || PARSE)
+                        a.seg_meta[seg_lane] = min_ch | (max_ch << 4) | (1u << 8);
+                    if (PARSE && brec)
+                        brec[0] = brec[1] = 0xFFFFFFFFu;         // end of this (segment, substream)'s records
                     bool go_on = false;
                     if (GENERAL) {
-                        atomicOr(&a.seg_status[segi], status | ((status & ~(ST_DEFERRED | ST_OVERFLOW)) ? 0u : ST_GENERAL));
+                        atomicOr(&a.seg_status[segi], status | ((status & ~ST_INFO) ? 0u : ST_GENERAL));
                         if (is_last_sub)
                             a.seg_rows[segi] = rows_written;
                         uint32_t nxt = segi + 1;                 // next live segment
                         while (nxt < n_seg && a.seg[nxt].stream == sr.stream && (a.seg[nxt].flags & SEG_DEAD))
                             nxt++;
-                        if (!(status & ~(ST_DEFERRED | ST_OVERFLOW)) && nxt < n_seg) {
+                        if (!(status & ~ST_INFO) && nxt < n_seg) {
                             const SegRec nr = a.seg[nxt];
                             const uint32_t nst = a.seg_status[nxt];
                             if (nr.stream == sr.stream && !(nr.flags & ST_FATAL_INDEX) && nr.nframes &&
-                                !(nst & ~(ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | (1u << 21))) &&
-                                (seq || (nst & ST_CHAINED))) {
+                                !(nst & ~ST_INFO)) {
                                 go_on = true;
-                                atomicAnd(&a.seg_status[nxt], ST_DEFERRED | ST_FATAL_INDEX | (1u << 21));
-                                seg_lane += (nxt - segi) * L;
+                                atomicAnd(&a.seg_status[nxt], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
+                                seg_lane += (nxt - segi) * 2u;
                                 segi = nxt;
                                 sr = nr;
-                                if (!seq) {
-                                    row0 = (uint64_t)(a.seg_fbase[nxt] - a.seg_fbase[stream_first]) * rpa;
-                                    row_limit = row0 + (uint64_t)nr.nframes * rpa;
-                                    row = row0;
-                                }
                                 cur = nr.off;
                                 frames_done = 0;
+                                drops_seen = 0;
                                 rows_written = 0;
                             }
                         }
@@ -857,17 +889,32 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     }
                     if (!go_on)
                         active = false;
+                    continue;
                 }
-                if (active && frames_done != sr.nframes) {
+                {
                     // ---- frame header "4p 12u 16p" (src/mlp.c:392-394)
                     rd.crc_rem = 0;
                     rd.seek_byte(cur);
                     const uint32_t hdr = rd.read(32);
                     const uint32_t fsize = 2u * ((hdr >> 16) & 0xFFFu);
                     const uint64_t frame_end = cur + fsize;
-                    // ---- major sync only on the segment's first frame (validated by the index)
-                    if (frames_done == 0)
+                    // ---- major sync: the segment's first frame has one (validated by the index).  Any other
+                    //      frame that carries a valid one was walked through by the index because its stream
+                    //      parameters differ from the stream's: the reference drops it, restart header and
+                    //      all, and decodes on with the state it has (src/mlp.c:449-460)
+                    if (frames_done == 0) {
                         rd.seek_byte(cur + 4 + 28);
+                    } else if (__builtin_expect(rd.peek32() == 0xF8726FBBu && fsize >= 32u && sr.ndrop != 0, 0)) {
+                        rd.seek_byte(cur + 20);
+                        const uint32_t count = rd.read(4);
+                        if (count == 1u || count == 2u) {
+                            cur = frame_end;
+                            frames_done++;
+                            drops_seen++;
+                            continue;
+                        }
+                        rd.seek_byte(cur + 4);
+                    }
                     // ---- substream info "1u 1u 1u 1p 12u" (+16p) (src/mlp.c:463-468, 660-667)
                     uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0;
                     bool bad = false;
@@ -915,6 +962,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 uint32_t err = ST_PARAMS;
                 bool matrix_class_change = false;
                 bool hdr_restart = false;
+                uint32_t chg_mask = 0, chg_cnt = 0;        // chain parse pass: slots whose filter parameters this block sets
+                bool seq_needed = false;                   // ... and what only the sequential pass decodes
                 if (rd.read(1)) {
                     const bool restart = rd.read(1) != 0;
                     hdr_restart = restart;
@@ -1059,11 +1108,17 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                             const uint32_t c = min_ch + k;
                             uint32_t pk_old = 0;
                             int32_t sho_old = 0;
+                            uint32_t cf_old[4] = {0, 0, 0, 0};
 #pragma unroll
                             for (int kk = 0; kk < NS; kk++)
                                 if ((uint32_t)kk == k) {
                                     pk_old = pk[kk];
                                     sho_old = sho[kk];
+                                    if (PARSE) {
+#pragma unroll
+                                        for (int j = 0; j < 4; j++)
+                                            cf_old[j] = cf[kk][j];
+                                    }
                                 }
                             uint32_t codebook = pk_old & 3u;
                             const uint32_t lb_old = (pk_old >> 2) & 31u, q_old = (pk_old >> 7) & 15u;
@@ -1212,6 +1267,22 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                                             }
                                         }
                                     iir_any = (iir_any & ~(1u << k)) | ((iir_order ? 1u : 0u) << k);
+                                    if (PARSE) {
+                                        // ---- what the filter pass needs of this slot from this row on
+                                        if (iir_order)
+                                            seq_needed = true;      // IIR taps: the sequential pass has them
+                                        uint32_t *w = brec + 2 + BREC_SLOT_WORDS * chg_cnt;
+                                        if (w + BREC_SLOT_WORDS > brec_end) {
+                                            seq_needed = true;      // more parameter changes than the records hold
+                                        } else {
+                                            w[0] = shift | (q << 4) | (fir_order << 8);
+#pragma unroll
+                                            for (int j = 0; j < 4; j++)
+                                                w[1 + j] = new_fir ? ncf[j] : cf_old[j];
+                                            chg_mask |= 1u << k;
+                                            chg_cnt++;
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -1222,6 +1293,18 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     err = ST_ENVELOPE;
                 }
                 hdr_parsed = true;
+                if (PARSE && ok && chg_mask) {
+                    brec[0] = rows_done;                // first PCM frame (of the segment) the record applies to
+                    brec[1] = chg_mask;
+                    brec += 2 + BREC_SLOT_WORDS * chg_cnt;
+                }
+                if (PARSE && ok && (seq_needed || (hdr_restart && blocks_in_frame))) {
+                    // IIR taps, a restart header inside a frame (the noise seed of the frame's earlier rows
+                    // changes under it), or more parameter changes than the records hold: the whole stream
+                    // goes through the sequential pass
+                    status |= ST_SEQ;
+                    active = false;
+                }
                 if (!adopt) {
                     qss_A = qss_pack;
                     mmc_A = max_mat_ch;
@@ -1251,8 +1334,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 if (!ok) {
                     status |= err;
                     active = false;
-                } else if (!GENERAL && (status & ST_CHAINED)) {
-                    active = false;            // left to the general pass (needs the previous history)
+                } else if (PARSE && !active) {
+                    // (ST_SEQ above)
+                } else if (!GENERAL && !PARSE && (status & ST_CHAINED)) {
+                    active = false;            // left to the chain passes (needs the previous history)
                 } else {
                     rows_left = block_size;
                     blocks_in_frame++;
@@ -1389,6 +1474,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 rd.nx = nn;
                 rd.next += adv;
                 rd.ofs = o3 & 31u;
+                int32_t value;
+                if constexpr (PARSE) {
+                    // chain parse pass: the residual itself is the product (the filter pass runs the recurrence)
+                    value = residual;
+                    (void)shift;
+                    (void)wave_iir;
+                } else {
                 // ---- FIR/IIR reconstruction (src/mlp.c:1278-1300)
                 int64_t acc0 = (int64_t)lo16(cf[k][0]) * (int64_t)st[k][0];
                 int64_t acc1 = (int64_t)hi16(cf[k][0]) * (int64_t)st[k][1];
@@ -1408,7 +1500,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                         acc += iir_mac(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes);
                 }
                 const int32_t ssum = (int32_t)(acc >> shift);
-                const int32_t value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
+                value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
                 // history moves only for channels this lane really carries
 #pragma unroll
                 for (int j = 7; j > 0; j--)
@@ -1418,6 +1510,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                     if (iir_on)
                         iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
                                  (int32_t)((uint32_t)value - (uint32_t)ssum));
+                }
                 }
                 if constexpr (WSPEC) {
                     if (in)
@@ -1448,7 +1541,16 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                         fr[MAXCH] = (int32_t)bypass_bits;
                     }
                 } else {
-                    rematrix(ch, bypass_bits);
+                    if constexpr (PARSE) {
+                        // ---- the row's residuals in MLP channel order, its bypassed LSBs and the noise seed it
+                        //      is rematrixed with (stepped once per PCM frame, src/mlp.c:1327-1334)
+                        ch[6] = (int32_t)bypass_bits;
+                        ch[7] = (int32_t)seed;
+                        const uint32_t shifted = (seed >> 7) & 0xFFFFu;
+                        seed = (seed << 16) ^ shifted ^ (shifted << 5);
+                    } else {
+                        rematrix(ch, bypass_bits);
+                    }
                     // ---- into the LDS staging tile [channel][frame][lane]; rows advance in lockstep so
                     //      the frame phase is the same in every lane
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
@@ -1460,7 +1562,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                             Td[c * 64] = ch[c];
                     } else {
 #pragma unroll
-                        for (int c = 0; c < 6; c++)
+                        for (int c = 0; c < TP; c++)
                             T[c][ph][GENERAL ? 0 : lane] = ch[c];
                     }
                     // ---- RIFF order (src/mlp.c:527-533): every OUT_ROWS-th frame each channel's staged
@@ -1520,6 +1622,26 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                         active = false;
                     }
                     rd.crc_st = 0;
+                    if (PARSE && is_last_sub && active) {
+                        // ---- what this access unit is rematrixed with: the parameters its last block leaves
+                        //      (src/mlp.c:504-525), for the rematrix pass
+                        uint32_t *F = frec + (size_t)au_idx * FREC_WORDS;
+                        F[0] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
+                        F[1] = outch_pack;
+                        F[2] = qss_pack;
+                        F[3] = oshift_pack;
+#pragma unroll
+                        for (int m = 0; m < 2; m++) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                F[4 + m * 5 + j] = mreg[m][j];
+                            F[4 + m * 5 + 4] = mnoise[m];
+                        }
+                        for (uint32_t m = 2; m < matrix_len; m++)
+                            for (uint32_t j = 0; j < 5; j++)
+                                F[4 + m * 5 + j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
+                    }
+                    au_idx++;
                     if (GENERAL && is_last_sub && active) {
                         // ---- rematrix the whole access unit with the parameters in force now
                         const uint64_t frow0 = row - frame_rows;
@@ -1614,7 +1736,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
             if (PAIRED) {
                 // substreams of one segment sit in adjacent lanes; exchange through LDS
                 const int slot0 = PAIRED ? (lane & ~1) : 0;
-                int32_t(*X)[(PAIRED && GENERAL) ? 64 : 1] = s_xch[(PAIRED && GENERAL) ? wv : 0];
+                int32_t(*X)[SIDE ? 64 : 1] = s_xch[SIDE ? wv : 0];
 #pragma unroll
                 for (int k = 0; k < NS; k++)
                     if ((uint32_t)k < nslots && min_ch + k < MAXCH)
@@ -1644,7 +1766,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
         //      older memory operation, so stores issued before it would be waited for as well; issued
         //      here they have a whole row to drain before the next wait
-        if (!GENERAL && ILV && flush) {
+        if (!GENERAL && !PARSE && ILV && flush) {
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
             const int32_t *Tl = &s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
@@ -1686,7 +1808,18 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
                 }
             }
         }
-        if (!GENERAL && !ILV && flush) {
+        if (PARSE && flush) {
+            // ---- chain parse pass: the segment's eight planes, four PCM frames each (rows per segment are a
+            //      multiple of 40, the planes start 16-byte aligned)
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
+#pragma unroll
+            for (int c = 0; c < TP; c++) {
+                int32_t *dst = a.res + out_base + (uint64_t)c * out_stride + flush_row;
+                DVDA_STORE_V4(dst, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane], T[c][2][GENERAL ? 0 : lane],
+                              T[c][3][GENERAL ? 0 : lane]);
+            }
+        }
+        if (!GENERAL && !PARSE && !ILV && flush) {
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
@@ -1719,40 +1852,49 @@ __global__ __launch_bounds__((PAIRED && !GENERAL) ? WS_THREADS : DEC_THREADS, 2)
         for (int i = 0; i < 6; i++)
             atomicAdd(&a.dbg[i], stamp_acc[i]);
 #endif
-    if (!GENERAL && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
+    if (!GENERAL && !PARSE && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
         // FIR history at the segment's end, for a following segment that depends on it
 #pragma unroll
         for (int k = 0; k < NS; k++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st[k][j];
+        a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8);
     }
-    if (!GENERAL && (status & ST_DEFERRED))
-        atomicOr(a.deferred, 1u);
     if (segi < n_seg) {
-        if (status)
-            atomicOr(&a.seg_status[segi], status);
-        if ((!GENERAL || general_head) && owner && sub < S)
+        if (status) {
+            const uint32_t old = atomicOr(&a.seg_status[segi], status);
+            if (!GENERAL && !PARSE) {
+                // ---- what the passes behind the fast pass will have to do (the host reads the summary)
+                constexpr uint32_t CH = ST_CHAINED | ST_MIDFRAME;
+                if ((status & CH) && !(old & CH)) {
+                    const uint32_t rows = (sr.nframes - sr.ndrop) * rpa;
+                    atomicAdd(&a.summary->chain_segs, 1u);
+                    atomicAdd(&a.summary->chain_rows, (unsigned long long)rows);
+                    atomicMax(&a.summary->chain_max_rows, rows);
+                }
+            }
+        }
+        if (!GENERAL && !PARSE && owner && sub < S && mine)
             a.seg_rows[segi] = rows_written;
     }
 }
 
-// Per-stream totals after decode: one lane per stream.
+// Per-stream totals after a decode pass: one lane per stream.
+//   collect != 0: streams that the sequential pass has to decode (ST_TIMING / ST_SEQ on any segment) are
+//                 appended to seq_list and counted in summary->seq_streams (reset by the host before)
+//   last != 0   : the last pass is through: a segment still waiting for one is reported, never passed as clean
 __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg,
                                                   const uint32_t *__restrict__ seg_fbase,
                                                   const uint32_t *__restrict__ seg_status,
                                                   const uint32_t *__restrict__ seg_rows,
                                                   StreamRec *__restrict__ streams, uint32_t n_streams,
-                                                  const uint32_t *__restrict__ only_if,
-                                                  uint32_t *__restrict__ fb_counter)
+                                                  DecodeSummary *__restrict__ summary,
+                                                  uint32_t *__restrict__ seq_list, uint32_t collect, uint32_t last)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0 && fb_counter)
-        *fb_counter = 0;        // the general pass that follows starts with no frame buffer handed out
     if (s >= n_streams)
         return;
-    if (only_if && *only_if == 0)
-        return;                 // nothing was deferred: the sums of the fast pass stand
     StreamRec r = streams[s];
     if (r.first_seg == 0xFFFFFFFFu) {
         r.status |= 1u << 0;
@@ -1762,18 +1904,22 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
         r.consumed = 0;
     } else {
         uint64_t rows = 0;
-        // decode-time bits are rebuilt from the segments every time (the general pass clears what it
+        // decode-time bits are rebuilt from the segments every time (a later pass clears what it
         // repairs); only what the index found stays
-        uint32_t st = r.status & ~(0x3FCu | ST_DEFERRED | ST_OVERFLOW | ST_CAPACITY | ST_GENERAL);
+        uint32_t st = r.status & ~(0x3FCu | ST_DEFERRED | ST_OVERFLOW | ST_GENERAL);
         for (uint32_t i = r.first_seg; i < r.first_seg + r.n_seg; i++) {
+            const uint32_t ss = seg_status[i];
             rows += seg_rows[i];
-            st |= seg_status[i];
+            st |= ss | (seg[i].flags & ~SEG_DEAD);      // (what the index found on the segment stays)
+            if (last && (ss & ST_DEFERRED) && !(ss & ST_GENERAL) && !(ss & ~ST_INFO))
+                st |= ST_CAPACITY;      // deferred and never decoded (cannot happen; never silently)
         }
         r.frames = seg_fbase[r.first_seg + r.n_seg] - seg_fbase[r.first_seg];
         r.rows = rows;
         r.status = st;
+        if (collect && (st & (ST_TIMING | ST_SEQ)))
+            seq_list[atomicAdd(&summary->seq_streams, 1u)] = s;
     }
-    (void)seg;
     streams[s] = r;
 }
 
@@ -1783,6 +1929,49 @@ __global__ void k_selftest_huff(uint32_t *out)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4 * 512)
         out[i] = huff_decode(i >> 9, i & 511u);
+}
+
+// the cold-path bit reader on known bytes (dvda_mlp_hip_selftest_bits): widths[i] > 0 reads an unsigned
+// field of that many bits, < 0 a signed one (sign bit first, two's complement), 0 reads nothing;
+// resident != 0 takes unsigned fields through the row loop's branch-free read_resident() instead
+__global__ __launch_bounds__(64) void k_selftest_bits(const uint8_t *bytes, uint32_t n_bytes, const int32_t *widths,
+                                                      uint32_t n, int64_t *out, uint32_t resident)
+{
+    __shared__ uint32_t s_ring[RING_DWORDS + 1][64];
+    __shared__ uint8_t s_crc[4 * 256];
+    for (int i = threadIdx.x; i < 4 * 256; i += 64)
+        s_crc[i] = d_crc.t[i];
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    BitReader rd;
+    rd.gsrc = reinterpret_cast<const uint4 *>(bytes);
+    rd.ring = &s_ring[0][0];
+    rd.crc_tab = s_crc;
+    rd.max_chunk = (uint32_t)((((uint64_t)n_bytes + 63) >> 6) << 4);
+    rd.hi = rd.lo = rd.nx = 0;
+    rd.ofs = 0;
+    rd.next = 3;
+    rd.fillpos = 0;
+    rd.lo_valid = 0;
+    rd.crc_pos = 0;
+    rd.crc_rem = 0;
+    rd.crc_st = 0;
+    rd.par = 0;
+    rd.seek_byte(0);
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t w = widths[i];
+        if (w >= 0) {
+            if (resident && w < 32) {
+                rd.ensure(2);
+                out[i] = (int64_t)rd.read_resident((uint32_t)w);
+            } else {
+                out[i] = (int64_t)rd.read((uint32_t)w);
+            }
+        } else {
+            out[i] = (int64_t)rd.read_signed((uint32_t)-w);
+        }
+    }
 }
 
 } // namespace mlp

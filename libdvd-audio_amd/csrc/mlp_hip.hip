@@ -3,10 +3,13 @@
 //
 //   index : k_sync_mask -> k_exscan_u32 -> k_sync_scatter -> k_chase ->
 //           k_exscan_u32 -> k_link                 (framing, src/mlp.c:384-405)
-//   decode: k_decode<NS> -> k_finalize             (src/mlp.c:407-1358)
+//   decode: k_decode (fast pass) -> k_finalize -> [summary to the host] ->
+//           chain passes (mlp_chain.h) and / or the sequential pass, only when the fast pass
+//           left something to them                 (src/mlp.c:407-1358)
 //
-// No allocation, no host synchronisation inside index/decode: the workspace is
-// sized at create time and segment counts stay on the device.
+// The index does no allocation and no host synchronisation.  The decode waits once for the fast
+// pass (a 32-byte summary decides what else is launched); a batch with chained segments grows the
+// chain workspace on first use.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -16,6 +19,7 @@
 
 #include "../../include/dvda_mlp_hip.h"
 #include "mlp_decode.h"
+#include "mlp_chain.h"
 #include "mlp_index.h"
 #include "pcm_unswizzle.h"
 #include "wav_pack.h"
@@ -40,6 +44,9 @@ using namespace mlp;
         }                                                                                  \
     } while (0)
 
+constexpr uint32_t EV_RING = 256;       // decode calls whose kernel time is kept (the newest)
+constexpr uint32_t SEQ_ROUND = 1024;    // streams one round of the sequential pass decodes
+
 struct dvda_mlp_hip_ctx {
     int device;
     uint32_t max_streams, max_segments;
@@ -59,14 +66,28 @@ struct dvda_mlp_hip_ctx {
     uint32_t *d_n_cand;        // single counter (points at d_tile_base[tiles])
     uint32_t *d_scan_tmp;      // block sums of the multi-block scans
     uint64_t scan_tmp_cap;
-    uint32_t *d_deferred;      // set by the fast pass when any segment is left to the general pass
     int32_t *d_iir;
     uint32_t *d_mat;
     unsigned long long *d_dbg;
     int32_t *d_fir;
-    int32_t *d_fb;
-    uint32_t *d_fb_counter;
+    uint32_t *d_seg_meta;      // [iir_lanes]: channel range per (segment, substream) at the segment's end
+    uint32_t *d_cls;           // [2]: streams with one / two substreams in the batch
+    DecodeSummary *d_summary;
+    DecodeSummary *h_summary;  // pinned
+    uint32_t *d_seq_list;      // [max_streams]: streams for the sequential pass
+    uint4 *d_plan;             // [max_segments + 1]
+    uint4 *d_scan4_tmp;        // [max_segments / 1024 + 2]
+    uint32_t *d_def_list;      // [max_segments]
+    uint32_t *d_head_list;     // [max_segments]
+    // grown on first use (a batch that needs them):
+    int32_t *d_fb;             // sequential pass: one frame buffer per lane pair of a round
     uint32_t fb_slots;
+    int32_t *d_res;            // chain passes: planes
+    uint64_t res_cap;          // PCM frames
+    uint32_t *d_brec;
+    uint64_t brec_cap;         // dwords
+    uint32_t *d_frec;
+    uint64_t frec_cap;         // dwords
     const int32_t *d_init_fir;
     uint32_t iir_lanes;
     // call state
@@ -79,9 +100,10 @@ struct dvda_mlp_hip_ctx {
     bool indexed;
     uint32_t lanes_per_seg;
     uint32_t pcm_layout;           // DVDA_PCM_PLANAR / DVDA_PCM_INTERLEAVED
-    // timing of the decode kernel
-    std::vector<hipEvent_t> ev;   // pairs (start, stop)
-    size_t ev_used;
+    // timing of the fast-pass kernel: a fixed ring of (start, stop) pairs made at create time
+    hipEvent_t ev[2 * EV_RING];
+    uint32_t ev_made;          // events created
+    uint64_t ev_count;         // decode calls recorded since the last dvda_mlp_hip_kernel_time
 };
 
 static void free_ws(dvda_mlp_hip_ctx *c)
@@ -97,15 +119,26 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_seg_rows);
     (void)hipFree(c->d_streams);
     (void)hipFree(c->d_scan_tmp);
-    (void)hipFree(c->d_deferred);
     (void)hipFree(c->d_iir);
     (void)hipFree(c->d_mat);
     (void)hipFree(c->d_dbg);
     (void)hipFree(c->d_fir);
+    (void)hipFree(c->d_seg_meta);
+    (void)hipFree(c->d_cls);
+    (void)hipFree(c->d_summary);
+    if (c->h_summary)
+        (void)hipHostFree(c->h_summary);
+    (void)hipFree(c->d_seq_list);
+    (void)hipFree(c->d_plan);
+    (void)hipFree(c->d_scan4_tmp);
+    (void)hipFree(c->d_def_list);
+    (void)hipFree(c->d_head_list);
     (void)hipFree(c->d_fb);
-    (void)hipFree(c->d_fb_counter);
-    for (hipEvent_t e : c->ev)
-        (void)hipEventDestroy(e);
+    (void)hipFree(c->d_res);
+    (void)hipFree(c->d_brec);
+    (void)hipFree(c->d_frec);
+    for (uint32_t i = 0; i < c->ev_made; i++)
+        (void)hipEventDestroy(c->ev[i]);
 }
 
 extern "C" const char *dvda_mlp_hip_version(void) { return "dvda-mlp-hip 0.1 (gfx950)"; }
@@ -131,9 +164,10 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->tiles_cap = 0;
     c->scan_tmp_cap = 0;
     c->indexed = false;
-    c->ev_used = 0;
+    c->ev_made = 0;
+    c->ev_count = 0;
     c->d_init_fir = nullptr;
-    c->lanes_per_seg = 2;
+    c->lanes_per_seg = 0;           // chosen per batch from the indexed substream counts
     c->pcm_layout = DVDA_PCM_PLANAR;
     const size_t ns = (size_t)max_segments;
     hipError_t e = hipSuccess;
@@ -148,18 +182,32 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_seg_status, ns * sizeof(uint32_t));
     alloc((void **)&c->d_seg_rows, ns * sizeof(uint32_t));
     alloc((void **)&c->d_streams, (size_t)max_streams * sizeof(StreamRec));
-    alloc((void **)&c->d_deferred, sizeof(uint32_t));
     // two lanes per segment at most, rounded up to whole workgroups
     c->iir_lanes = (uint32_t)(((2 * ns + DEC_THREADS - 1) / DEC_THREADS) * DEC_THREADS);
     alloc((void **)&c->d_iir, (size_t)c->iir_lanes * MAXCH * 16 * sizeof(int32_t));
     alloc((void **)&c->d_mat, (size_t)c->iir_lanes * MAXMAT * 5 * sizeof(uint32_t));
     alloc((void **)&c->d_dbg, 16 * sizeof(unsigned long long));
     alloc((void **)&c->d_fir, (size_t)c->iir_lanes * 6 * 8 * sizeof(int32_t));
-    c->fb_slots = max_segments < 2048 ? max_segments : 2048;
-    alloc((void **)&c->d_fb, (size_t)c->fb_slots * FB_WORDS * sizeof(int32_t));
-    alloc((void **)&c->d_fb_counter, sizeof(uint32_t));
+    alloc((void **)&c->d_seg_meta, (size_t)c->iir_lanes * sizeof(uint32_t));
+    alloc((void **)&c->d_cls, 2 * sizeof(uint32_t));
+    alloc((void **)&c->d_summary, sizeof(DecodeSummary));
+    alloc((void **)&c->d_seq_list, (size_t)max_streams * sizeof(uint32_t));
+    alloc((void **)&c->d_plan, (ns + 1) * sizeof(uint4));
+    alloc((void **)&c->d_scan4_tmp, (ns / 1024 + 4) * sizeof(uint4));
+    alloc((void **)&c->d_def_list, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_head_list, ns * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&c->h_summary, sizeof(DecodeSummary), hipHostMallocDefault);
     if (e == hipSuccess)
         e = hipMemset(c->d_dbg, 0, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemset(c->d_seg_meta, 0, (size_t)c->iir_lanes * sizeof(uint32_t));
+    // the event ring is made here: the decode calls create nothing
+    for (uint32_t i = 0; e == hipSuccess && i < 2 * EV_RING; i++) {
+        e = hipEventCreate(&c->ev[i]);
+        if (e == hipSuccess)
+            c->ev_made = i + 1;
+    }
     if (e != hipSuccess) {
         fprintf(stderr, "dvda_mlp_hip: workspace allocation failed: %s\n", hipGetErrorString(e));
         free_ws(c);
@@ -284,6 +332,7 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     c->d_n_cand = c->d_tile_base + tiles;
     const uint32_t ms = c->max_segments;
 
+    HIP_TRY(hipMemsetAsync(c->d_cls, 0, 2 * sizeof(uint32_t), st));
     {
         const uint32_t n_init = n_streams > ms ? n_streams : ms;
         hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
@@ -296,14 +345,37 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
                        total_bytes, c->d_tile_base, c->d_cand_off, ms);
     hipLaunchKernelGGL(k_chase, dim3((ms + 255) / 256), dim3(256), 0, st, d_bytes, d_stream_off,
                        d_stream_len, n_streams, c->d_cand_off, c->d_n_cand, ms, c->d_seg,
-                       c->d_seg_frames, c->d_streams);
+                       c->d_seg_frames, c->d_streams, c->d_cls);
     hipLaunchKernelGGL(k_mark_dead, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
-                       c->d_n_cand, ms, c->d_seg, c->d_seg_frames);
+                       c->d_n_cand, ms, c->d_seg, c->d_seg_frames, c->d_streams);
     exscan(c, st, c->d_seg_frames, c->d_seg_fbase, 0u, c->d_n_cand, ms);
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
-                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams);
+                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams, n_streams);
     HIP_TRY(hipGetLastError());
     c->indexed = true;
+    return DVDA_HIP_OK;
+}
+
+// grows a device buffer outside the common path (the first batch that needs it)
+template <typename T>
+static int grow(T **p, uint64_t *cap, uint64_t need)
+{
+    if (need <= *cap)
+        return DVDA_HIP_OK;
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    need += need / 8 + 1024;
+    if (hipMalloc((void **)p, need * sizeof(T)) != hipSuccess)
+        return DVDA_HIP_ENOMEM;
+    *cap = need;
+    return DVDA_HIP_OK;
+}
+
+static int read_summary(dvda_mlp_hip_ctx *c, hipStream_t st)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_summary, c->d_summary, sizeof(DecodeSummary), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return DVDA_HIP_OK;
 }
 
@@ -317,6 +389,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     hipStream_t st = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
     DecodeArgs a;
+    memset(&a, 0, sizeof(a));
     a.bytes = c->d_bytes;
     a.total_bytes = c->total_bytes;
     a.seg = c->d_seg;
@@ -334,56 +407,149 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.total_lanes = c->iir_lanes;
     a.dbg = c->d_dbg;
     a.fir_ws = c->d_fir;
-    a.fb = c->d_fb;
-    a.fb_counter = c->d_fb_counter;
-    a.fb_slots = c->fb_slots;
     a.init_fir = c->d_init_fir;
-    a.deferred = c->d_deferred;
+    a.summary = c->d_summary;
     a.interleaved = c->pcm_layout == DVDA_PCM_INTERLEAVED;
-    HIP_TRY(hipMemsetAsync(c->d_deferred, 0, sizeof(uint32_t), st));
-    // two lanes per segment unless the caller knows every stream has one substream
-    const uint32_t lanes_per_seg = c->lanes_per_seg ? c->lanes_per_seg : 2;
-    const uint64_t lanes = (uint64_t)c->max_segments * lanes_per_seg;
-    const unsigned blocks = (unsigned)((lanes + DEC_THREADS - 1) / DEC_THREADS);
-    const unsigned ws_blocks = (unsigned)((lanes + WS_THREADS - 1) / WS_THREADS);   // fast pass, two substreams
+    a.cls = c->d_cls;
+    a.seg_meta = c->d_seg_meta;
+    HIP_TRY(hipMemsetAsync(c->d_summary, 0, sizeof(DecodeSummary), st));
+    // which kernels: one lane per segment for the streams with one substream, the two-wave layout for those
+    // with two -- both unless the caller forced one; a kernel whose class is absent from the batch (the
+    // index knows) exits at once
+    const uint32_t force = c->lanes_per_seg;
+    const bool run1 = force != 2, run2 = force != 1;
+    const uint64_t ms = c->max_segments;
+    const unsigned blocks1 = (unsigned)((ms + DEC_THREADS - 1) / DEC_THREADS);            // one lane per segment
+    const unsigned blocks2 = (unsigned)((2 * ms + DEC_THREADS - 1) / DEC_THREADS);        // lane pairs
+    const unsigned ws_blocks = (unsigned)((2 * ms + WS_THREADS - 1) / WS_THREADS);        // fast pass, two waves
 
-    if (c->ev_used + 2 > c->ev.size()) {
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        c->ev.push_back(e0);
-        c->ev.push_back(e1);
+    const uint32_t slot = (uint32_t)(c->ev_count % EV_RING);
+    HIP_TRY(hipEventRecord(c->ev[2 * slot], st));
+    // ---- fast pass (timed: the dominant kernel)
+    if (run1) {
+        a.only_S = force ? 0u : 1u;
+        if (a.interleaved)
+            hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
+        else
+            hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
     }
-    HIP_TRY(hipEventRecord(c->ev[c->ev_used], st));
-    // fast pass (timed: the dominant kernel)
-    if (a.interleaved) {
-        if (lanes_per_seg == 2)
+    if (run2) {
+        a.only_S = force ? 0u : 2u;
+        if (a.interleaved)
             hipLaunchKernelGGL((k_decode<6, true, false, true>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
         else
-            hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
-    } else {
-        if (lanes_per_seg == 2)
             hipLaunchKernelGGL((k_decode<6, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
-        else
-            hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
     }
-    HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], st));
-    c->ev_used += 2;
+    HIP_TRY(hipEventRecord(c->ev[2 * slot + 1], st));
+    c->ev_count++;
     const dim3 fgrid((c->n_streams + 255) / 256);
-    hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status,
-                       c->d_seg_rows, c->d_streams, c->n_streams, (const uint32_t *)nullptr, c->d_fb_counter);
-    // general pass, twice: the second run picks up streams whose non-standard timing only
-    // showed inside a chained run.  Lanes without deferred work exit at once.
-    for (int pass = 0; pass < 2; pass++) {
-        // (the frame-buffer counter was reset by the k_finalize in front of this pass)
-        if (lanes_per_seg == 2)
-            hipLaunchKernelGGL((k_decode<6, true, true>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
-        else
-            hipLaunchKernelGGL((k_decode<6, false, true>), dim3(blocks), dim3(DEC_THREADS), 0, st, a);
-        hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase,
-                           c->d_seg_status, c->d_seg_rows, c->d_streams, c->n_streams,
-                           (const uint32_t *)a.deferred, c->d_fb_counter);
+    hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
+                       c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
+    HIP_TRY(hipGetLastError());
+    int rc = read_summary(c, st);
+    if (rc)
+        return rc;
+
+    // ---- chain passes: segments that continue the FIR history of the one before them, or change
+    //      matrix-class parameters inside an access unit
+    if (c->h_summary->chain_segs) {
+        const uint64_t rows = c->h_summary->chain_rows;
+        const uint32_t segs = c->h_summary->chain_segs;
+        const uint32_t max_rows = c->h_summary->chain_max_rows;
+        if (rows >> 32)
+            return DVDA_HIP_ECAPACITY;          // plan entries are 32-bit (137 GB of planes)
+        if ((rc = grow(&c->d_res, &c->res_cap, rows * 8 + 64)) != 0 ||
+            (rc = grow(&c->d_brec, &c->brec_cap, 2 * rows + 128ull * segs + 64)) != 0 ||
+            (rc = grow(&c->d_frec, &c->frec_cap, (rows / 40 + segs + 1) * FREC_WORDS)) != 0)
+            return rc;
+        ChainArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.seg = c->d_seg;
+        ca.seg_fbase = c->d_seg_fbase;
+        ca.n_seg_ptr = c->d_n_cand;
+        ca.max_seg = c->max_segments;
+        ca.streams = c->d_streams;
+        ca.seg_status = c->d_seg_status;
+        ca.seg_rows = c->d_seg_rows;
+        ca.seg_meta = c->d_seg_meta;
+        ca.plan = c->d_plan;
+        ca.def_list = c->d_def_list;
+        ca.head_list = c->d_head_list;
+        ca.res = c->d_res;
+        ca.brec = c->d_brec;
+        ca.frec = c->d_frec;
+        ca.fir_ws = c->d_fir;
+        ca.total_lanes = c->iir_lanes;
+        ca.init_fir = c->d_init_fir;
+        ca.pcm = d_pcm;
+        ca.out_off = d_out_off;
+        ca.out_stride = d_out_stride;
+        ca.interleaved = a.interleaved;
+        const unsigned sblocks = (unsigned)((ms + 1023) / 1024);
+        hipLaunchKernelGGL(k_chain_plan, dim3((unsigned)((ms + 255) / 256)), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(k_scan4_blocks, dim3(sblocks), dim3(1024), 0, st, c->d_plan, c->d_scan4_tmp, c->d_n_cand,
+                           c->max_segments);
+        hipLaunchKernelGGL(k_scan4_sums, dim3(1), dim3(1024), 0, st, c->d_scan4_tmp, sblocks);
+        hipLaunchKernelGGL(k_scan4_add, dim3(sblocks), dim3(1024), 0, st, c->d_plan, c->d_scan4_tmp, sblocks,
+                           c->d_n_cand, c->max_segments);
+        hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((ms + 255) / 256)), dim3(256), 0, st, ca);
+        // parse: lane (pair) j takes deferred segment def_list[j]
+        a.list = c->d_def_list;
+        a.list_base = 0;
+        a.list_n = segs;
+        a.plan = c->d_plan;
+        a.res = c->d_res;
+        a.brec = c->d_brec;
+        a.frec = c->d_frec;
+        if (run1) {
+            a.only_S = force ? 0u : 1u;
+            hipLaunchKernelGGL((k_decode<6, false, false, false, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
+                               dim3(DEC_THREADS), 0, st, a);
+        }
+        if (run2) {
+            a.only_S = force ? 0u : 2u;
+            hipLaunchKernelGGL((k_decode<6, true, false, false, true>), dim3((2 * segs + DEC_THREADS - 1) / DEC_THREADS),
+                               dim3(DEC_THREADS), 0, st, a);
+        }
+        // filter: 16 lanes per chain (at most one chain per deferred segment)
+        hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);
+        // rematrix: one lane per PCM frame
+        hipLaunchKernelGGL(k_chain_rematrix, dim3(segs, (max_rows + 255) / 256), dim3(256), 0, st, ca);
+        HIP_TRY(hipMemsetAsync(&c->d_summary->seq_streams, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
+                           c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
+        HIP_TRY(hipGetLastError());
+        if ((rc = read_summary(c, st)) != 0)
+            return rc;
     }
+
+    // ---- sequential pass: streams with non-standard timing, IIR taps or restart headers inside an access
+    //      unit, whole and in order, one lane pair and one frame buffer per stream, a round at a time
+    const uint32_t n_seq = c->h_summary->seq_streams;
+    if (n_seq) {
+        const uint32_t round = n_seq < SEQ_ROUND ? n_seq : SEQ_ROUND;
+        if (round > c->fb_slots) {
+            (void)hipFree(c->d_fb);
+            c->d_fb = nullptr;
+            c->fb_slots = 0;
+            if (hipMalloc((void **)&c->d_fb, (size_t)round * FB_WORDS * sizeof(int32_t)) != hipSuccess)
+                return DVDA_HIP_ENOMEM;
+            c->fb_slots = round;
+        }
+        a.fb = c->d_fb;
+        a.list = c->d_seq_list;
+        a.only_S = 0;
+        for (uint32_t base = 0; base < n_seq; base += round) {
+            a.list_base = base;
+            a.list_n = n_seq - base < round ? n_seq - base : round;
+            hipLaunchKernelGGL((k_decode<6, true, true>), dim3((2 * a.list_n + DEC_THREADS - 1) / DEC_THREADS),
+                               dim3(DEC_THREADS), 0, st, a);
+        }
+    }
+    if (c->h_summary->chain_segs || n_seq)
+        hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
+                           c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 0u, 1u);
+    (void)blocks2;
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
 }
@@ -398,7 +564,7 @@ extern "C" int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *c, uint32_t layout)
 
 extern "C" int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *c, uint32_t lanes)
 {
-    if (!c || (lanes != 1 && lanes != 2))
+    if (!c || lanes > 2)
         return DVDA_HIP_EINVAL;
     c->lanes_per_seg = lanes;
     return DVDA_HIP_OK;
@@ -454,15 +620,16 @@ extern "C" int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *c, double *avg_ms, uin
         return DVDA_HIP_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     double total = 0;
-    uint32_t n = 0;
-    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
-        HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
+    // the ring holds the newest EV_RING decode calls
+    const uint32_t n = c->ev_count < EV_RING ? (uint32_t)c->ev_count : EV_RING;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t slot = (uint32_t)((c->ev_count - 1 - i) % EV_RING);
+        HIP_TRY(hipEventSynchronize(c->ev[2 * slot + 1]));
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2 * slot], c->ev[2 * slot + 1]));
         total += ms;
-        n++;
     }
-    c->ev_used = 0;
+    c->ev_count = 0;
     *avg_ms = n ? total / n : 0.0;
     if (launches)
         *launches = n;
@@ -492,6 +659,38 @@ extern "C" int dvda_mlp_hip_selftest_huff(int device, uint32_t *host_out)
     hipLaunchKernelGGL(k_selftest_huff, dim3(8), dim3(256), 0, 0, d);
     const hipError_t e = hipMemcpy(host_out, d, 4 * 512 * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
+    return e == hipSuccess ? DVDA_HIP_OK : DVDA_HIP_ENODEV;
+}
+
+// host_out[i] = field i read from `bytes` by the kernels' bit reader (widths as in k_selftest_bits)
+extern "C" int dvda_mlp_hip_selftest_bits(int device, const uint8_t *host_bytes, uint32_t n_bytes,
+                                          const int32_t *host_widths, uint32_t n, int64_t *host_out, uint32_t resident)
+{
+    if (!host_bytes || !host_widths || !host_out || n == 0 || n_bytes == 0)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d_b = nullptr;
+    int32_t *d_w = nullptr;
+    int64_t *d_o = nullptr;
+    const size_t padded = (((size_t)n_bytes + 63) & ~(size_t)63) + 128;
+    hipError_t e = hipMalloc((void **)&d_b, padded);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_w, n * sizeof(int32_t));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_o, n * sizeof(int64_t));
+    if (e == hipSuccess)
+        e = hipMemset(d_b, 0, padded);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_b, host_bytes, n_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_w, host_widths, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_bits, dim3(1), dim3(64), 0, 0, d_b, n_bytes, d_w, n, d_o, resident);
+        e = hipMemcpy(host_out, d_o, n * sizeof(int64_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_b);
+    (void)hipFree(d_w);
+    (void)hipFree(d_o);
     return e == hipSuccess ? DVDA_HIP_OK : DVDA_HIP_ENODEV;
 }
 
@@ -534,7 +733,7 @@ extern "C" int dvda_mlp_hip_segment_fir(dvda_mlp_hip_ctx *c, uint32_t segment, i
         return DVDA_HIP_EINVAL;
     if (!c->indexed)
         return DVDA_HIP_ESTATE;
-    const uint32_t L = c->lanes_per_seg ? c->lanes_per_seg : 2;
+    const uint32_t L = 2;       // workspace lane = segment * 2 + substream in every pass
     if ((uint64_t)segment * L + L > c->iir_lanes)
         return DVDA_HIP_EINVAL;
     HIP_TRY(hipSetDevice(c->device));

@@ -22,7 +22,12 @@ struct SegRec {
     uint32_t nframes;   // complete access units in the segment
     uint32_t flags;     // DVDA_ST_* bits found while indexing
     uint32_t sync;      // packed major sync: g0bps | g1bps<<4 | g0rate<<8 | g1rate<<12 | assignment<<16 | substreams<<24
+    uint32_t ndrop;     // access units among nframes that carry a major sync with OTHER stream parameters: the
+                        // reference drops such a frame and decodes on (src/mlp.c:449-460); they yield no PCM
+    uint32_t pad;
 };
+constexpr uint32_t SYNC_PARAMS = 0x00FFFFFFu;   // the five stream parameters of a packed sync (dvda_params_equal)
+constexpr uint32_t MAX_DROP = 4;                // mismatching major syncs one segment walks through
 
 struct StreamRec {
     uint32_t first_seg;   // index of the stream's first segment (0xFFFFFFFF = none)
@@ -74,6 +79,13 @@ __device__ __forceinline__ bool sync_frame_hdr(const uint8_t *b, uint64_t p, uin
         return false;
     const uint32_t count = ld_u8(b, p + 20) >> 4;
     return count == 1 || count == 2;
+}
+
+// packed major sync of the access unit at even offset p (layout of SegRec.sync)
+__device__ __forceinline__ uint32_t packed_sync_at(const uint8_t *b, uint64_t p)
+{
+    return (ld_u8(b, p + 8) >> 4) | ((ld_u8(b, p + 8) & 0xFu) << 4) | ((ld_u8(b, p + 9) >> 4) << 8) |
+           ((ld_u8(b, p + 9) & 0xFu) << 12) | ((ld_u8(b, p + 11) & 0x1Fu) << 16) | ((ld_u8(b, p + 20) >> 4) << 24);
 }
 
 // Pass 1: one mask byte per 16-byte chunk (bit j = candidate at chunk*16 + 2j),
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
                                                const uint32_t *__restrict__ n_cand_ptr,
                                                uint32_t max_cand, SegRec *__restrict__ seg,
                                                uint32_t *__restrict__ seg_frames,
-                                               StreamRec *__restrict__ streams)
+                                               StreamRec *__restrict__ streams, uint32_t *__restrict__ cls)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_cand = *n_cand_ptr;
@@ -306,6 +318,8 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     r.flags = 0;
     r.nframes = 0;
     r.sync = 0;
+    r.ndrop = 0;
+    r.pad = 0;
     uint64_t p = off;
     if (off >= s_end || ((off - s_begin) & 1) || !sync_frame_at(bytes, off, s_end)) {
         // candidate in inter-stream padding, at an odd stream offset, or cut by
@@ -313,9 +327,7 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
         r.flags = 1u << 16; // DVDA_ST_IRREGULAR
         r.end = off;
     } else {
-        r.sync = (ld_u8(bytes, off + 8) >> 4) | ((ld_u8(bytes, off + 8) & 0xFu) << 4) |
-                 ((ld_u8(bytes, off + 9) >> 4) << 8) | ((ld_u8(bytes, off + 9) & 0xFu) << 12) |
-                 ((ld_u8(bytes, off + 11) & 0x1Fu) << 16) | ((ld_u8(bytes, off + 20) >> 4) << 24);
+        r.sync = packed_sync_at(bytes, off);
         uint32_t n = 0;
         // one memory round trip per frame: the 8 header bytes of the frame at p (size field and
         // the place a major sync would sit) are fetched together and carried into the next step
@@ -338,14 +350,21 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
             p += size;
             n++;
             hdr = ld_hdr8(bytes, p);          // the buffer is readable 64 bytes past its end
-            if (sync_frame_hdr(bytes, p, s_end, hdr))
-                break;
+            if (sync_frame_hdr(bytes, p, s_end, hdr)) {
+                // a major sync whose five stream parameters differ from this segment's does not start a
+                // segment: the reference drops that frame (restart header and all) and decodes on with
+                // the state it has (src/mlp.c:449-460) -- the walk goes through it (a bounded number of
+                // times: the candidate there walks on its own and must not run to the stream's end)
+                if (((packed_sync_at(bytes, p) ^ r.sync) & SYNC_PARAMS) == 0 || r.ndrop >= MAX_DROP)
+                    break;
+                r.ndrop++;
+            }
         }
         r.nframes = n;
         r.end = p;
     }
     seg[i] = r;
-    seg_frames[i] = r.nframes;
+    seg_frames[i] = r.nframes - r.ndrop;        // access units that yield PCM
     // the first candidate of a stream registers itself
     bool first = (i == 0);
     if (!first) {
@@ -355,6 +374,10 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     if (first) {
         streams[s].first_seg = i;
         streams[s].sync = r.sync;
+        // which decode kernels this batch needs: one lane per segment (one substream) / a lane pair
+        const uint32_t S = (r.sync >> 24) & 0xFu;
+        if (S == 1 || S == 2)
+            cls[S - 1] = 1u;
     }
 }
 
@@ -367,7 +390,8 @@ constexpr uint32_t SEG_DEAD = 1u << 24;   // DVDA_ST_FALSE_SYNC: candidate insid
 __global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ stream_off,
                                                    const uint64_t *__restrict__ stream_len,
                                                    const uint32_t *__restrict__ n_cand_ptr, uint32_t max_cand,
-                                                   SegRec *__restrict__ seg, uint32_t *__restrict__ seg_frames)
+                                                   SegRec *__restrict__ seg, uint32_t *__restrict__ seg_frames,
+                                                   const StreamRec *__restrict__ streams)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_cand = *n_cand_ptr;
@@ -379,18 +403,25 @@ __global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ 
     const uint64_t off = seg[i].off;
     if (seg[i - 1].stream != s)
         return;                                   // first candidate of its stream
+    // only a candidate that announces the stream's own parameters can start a segment, and only the walk
+    // of such a candidate says where segments start: a major sync with other parameters is a frame the
+    // reference drops (src/mlp.c:449-460) -- its own walk (which ends at the next sync like itself) counts
+    // for nothing, and it is retired here when an earlier walk went through it
+    const uint32_t want = streams[s].sync & SYNC_PARAMS;
+    const bool foreign = (seg[i].sync & SYNC_PARAMS) != want;
     // does a chain land exactly here?
-    for (uint32_t q = i; q-- > 0 && i - q <= 3 && seg[q].stream == s;)
-        if (seg[q].end == off)
-            return;
+    if (!foreign)
+        for (uint32_t q = i; q-- > 0 && i - q <= MAX_DROP + 1 && seg[q].stream == s;)
+            if (seg[q].end == off && (seg[q].sync & SYNC_PARAMS) == want)
+                return;
     // nobody lands here: is it inside the span of an earlier chain that lands later (or at the end)?
     const uint64_t s_end = stream_off[s] + stream_len[s];
-    for (uint32_t q = i; q-- > 0 && i - q <= 3 && seg[q].stream == s;) {
+    for (uint32_t q = i; q-- > 0 && i - q <= MAX_DROP + 1 && seg[q].stream == s;) {
         const uint64_t e = seg[q].end;
-        if (e <= off || seg[q].nframes == 0)
+        if (e <= off || seg[q].nframes == 0 || (seg[q].sync & SYNC_PARAMS) != want)
             continue;
         bool lands = (e == s_end) || (seg[q].flags & (1u << 21));          // ran to the (truncated) end
-        for (uint32_t j = i + 1; !lands && j < n_cand && j <= i + 3 && seg[j].stream == s; j++)
+        for (uint32_t j = i + 1; !lands && j < n_cand && j <= i + MAX_DROP + 1 && seg[j].stream == s; j++)
             lands = seg[j].off == e;
         if (lands) {
             seg[i].flags |= SEG_DEAD;
@@ -408,14 +439,21 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
                                               const uint32_t *__restrict__ n_cand_ptr,
                                               uint32_t max_cand, SegRec *__restrict__ seg,
                                               const uint32_t *__restrict__ seg_fbase,
-                                              StreamRec *__restrict__ streams)
+                                              StreamRec *__restrict__ streams, uint32_t n_streams)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_cand = *n_cand_ptr;
+    const bool overflow = n_cand > max_cand;
     if (n_cand > max_cand)
         n_cand = max_cand;
     if (i >= n_cand)
         return;
+    if (overflow && i == n_cand - 1) {
+        // more candidates than the context was created for: the list was cut here, so this stream and
+        // every one behind it is incomplete -- say so instead of returning short PCM with a clean status
+        for (uint32_t t = seg[i].stream; t < n_streams; t++)
+            atomicOr(&streams[t].status, 1u << 22);     // DVDA_ST_CAPACITY
+    }
     SegRec r = seg[i];
     if (r.flags & SEG_DEAD)
         return;
@@ -431,10 +469,13 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
         st |= 1u << 0; // DVDA_ST_NO_SYNC: data before the first major sync
     if (!last && seg[j].off != r.end)
         st |= 1u << 16; // chain does not land on the next candidate
-    if (r.sync != streams[s].sync) {
-        // reference compares the five stream parameters (src/mlp.c:450-455) and
-        // keeps the first substream count
-        st |= 1u << 1;
+    if (r.ndrop)
+        st |= 1u << 1;      // DVDA_ST_SYNC_CHANGE: frames dropped as the reference drops them (informational)
+    if ((r.sync ^ streams[s].sync) & SYNC_PARAMS) {
+        // reference compares the five stream parameters (src/mlp.c:450-455) and keeps the first
+        // substream count.  A live segment that starts on such a sync was not walked through by the one
+        // before it (more than MAX_DROP in a row): reported, not decoded
+        st |= (1u << 1) | (1u << 16);
     }
     if (st != r.flags) {
         r.flags = st;

@@ -138,6 +138,10 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
         *channels = 0;
     if (!d || (len && !data))
         return 0;
+    /* a decoder that has hit what makes the reference assert() stays stopped: nothing more is queued
+       (the queue cannot grow without bound behind an error) */
+    if (d->status & ~(unsigned)DVDA_ST_BENIGN)
+        return 0;
     /* ---- enqueue everything (src/mlp.c:349-351) */
     if (d->qlen + len > d->qcap) {
         size_t nc = d->qcap ? d->qcap : 8192;
@@ -170,8 +174,12 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
                 memcpy(d->sync_params, p, 4);
                 d->have_sync = 1;
             } else if (memcmp(d->sync_params, p, 3) != 0) {
-                d->status |= DVDA_ST_SYNC_CHANGE;   /* reference drops such frames (src/mlp.c:450-455) */
-                return 0;
+                /* the reference drops such a frame and decodes on with the state it has
+                   (src/mlp.c:450-455): it starts no segment; the batch tier walks through it */
+                d->status |= DVDA_ST_SYNC_CHANGE;
+                pos += size;
+                complete_end = pos;
+                continue;
             }
             n_sync++;
             last_sync = pos;
@@ -207,8 +215,24 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
     meta[3] = 0;
     if (hipMemcpy(d->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
         return 0;
-    if (dvda_mlp_hip_index(d->ctx, d->d_bytes, padded, d->d_meta, d->d_meta + 1, 1, NULL) ||
-        dvda_mlp_hip_stream_info(d->ctx, &info, 1, NULL))
+    for (;;) {
+        uint32_t n_dev = 0;
+        int rc;
+        if (dvda_mlp_hip_index(d->ctx, d->d_bytes, padded, d->d_meta, d->d_meta + 1, 1, NULL))
+            return 0;
+        rc = dvda_mlp_hip_segment_count(d->ctx, &n_dev, NULL);
+        if (rc == DVDA_HIP_OK)
+            break;
+        if (rc != DVDA_HIP_ECAPACITY)
+            return 0;
+        /* sync patterns inside payload bytes count as candidates too: a larger context */
+        dvda_mlp_hip_destroy(d->ctx);
+        d->ctx = NULL;
+        d->ctx_segments = 2 * n_dev + 64;
+        if (dvda_mlp_hip_create(&d->ctx, d->device, 1, d->ctx_segments) != DVDA_HIP_OK)
+            return 0;
+    }
+    if (dvda_mlp_hip_stream_info(d->ctx, &info, 1, NULL))
         return 0;
     if (info.status & ~DVDA_ST_BENIGN) {
         d->status |= info.status;

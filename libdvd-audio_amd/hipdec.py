@@ -13,10 +13,12 @@ from . import _build
 ST = dict(NO_SYNC=1 << 0, SYNC_CHANGE=1 << 1, PARITY=1 << 2, CRC=1 << 3, EOF=1 << 4, RESTART=1 << 5,
           PARAMS=1 << 6, HUFFMAN=1 << 7, FILTER=1 << 8, ENVELOPE=1 << 9, IRREGULAR=1 << 16,
           TIMING=1 << 17, MIDFRAME=1 << 18, CHAINED=1 << 19, OVERFLOW=1 << 20, TRUNCATED=1 << 21,
-          CAPACITY=1 << 22, GENERAL=1 << 23)
-# bits that do not invalidate the decoded PCM: the three conditions the fast pass defers are
-# informational once the general pass has decoded them (any failure there sets an error bit)
-ST_BENIGN = ST["TRUNCATED"] | ST["CHAINED"] | ST["MIDFRAME"] | ST["TIMING"] | ST["GENERAL"]
+          CAPACITY=1 << 22, GENERAL=1 << 23, FALSE_SYNC=1 << 24, SEQ=1 << 25)
+# bits that do not invalidate the decoded PCM: the conditions the fast pass defers are informational
+# once the passes behind it have decoded them (any failure there sets an error bit); a dropped
+# access unit (later major sync with other stream parameters) is what the reference does too
+ST_BENIGN = (ST["TRUNCATED"] | ST["CHAINED"] | ST["MIDFRAME"] | ST["TIMING"] | ST["GENERAL"] | ST["SEQ"] |
+             ST["SYNC_CHANGE"])
 
 
 class StreamInfo(ctypes.Structure):
@@ -37,7 +39,8 @@ _lib = None
 
 EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
            "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
-           "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_set_lanes_per_segment",
+           "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_selftest_bits",
+           "dvda_mlp_hip_set_lanes_per_segment",
            "dvda_mlp_hip_set_pcm_layout", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
@@ -106,7 +109,7 @@ PCM_PLANAR, PCM_INTERLEAVED = 0, 1      # DVDA_PCM_* of include/dvda_mlp_hip.h
 class Context:
     """One decode context = one GPU's index workspace (dvda_mlp_hip_create)."""
 
-    def __init__(self, device=0, max_streams=1, max_segments=1024, lanes_per_segment=2, layout=PCM_PLANAR):
+    def __init__(self, device=0, max_streams=1, max_segments=1024, lanes_per_segment=0, layout=PCM_PLANAR):
         self._h = ctypes.c_void_p()
         _check(lib().dvda_mlp_hip_create(ctypes.byref(self._h), device, max_streams, max_segments),
                "dvda_mlp_hip_create")
@@ -169,7 +172,7 @@ def pack_streams(streams):
     return flat, np.asarray(offs, np.uint64), np.asarray(lens, np.uint64)
 
 
-def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2, layout=PCM_PLANAR):
+def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, layout=PCM_PLANAR):
     """Decodes a list of complete MLP byte streams on the GPU.
 
     Returns (pcm, infos): pcm[i] is an int32 array [channels, pcm_frames] in RIFF-WAVE
@@ -194,6 +197,15 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=2, la
         d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), len(streams), st)
+        try:
+            ctx.segment_count(st)
+        except HipError:
+            # more major syncs (sync patterns in payload count too) than the context holds: a larger one
+            v = ctypes.c_uint32()
+            lib().dvda_mlp_hip_segment_count(ctx._h, ctypes.byref(v), st)
+            ctx.close()
+            ctx = Context(device, len(streams), int(v.value) + 64, lanes_per_segment, layout)
+            ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), len(streams), st)
         infos = ctx.stream_info(stream=st)
         rows, nch = [], []
         for inf in infos:

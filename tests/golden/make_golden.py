@@ -42,15 +42,37 @@ FIXTURES = [
 ]
 
 
+# Streams in which later major syncs announce OTHER stream parameters (reference src/mlp.c:449-460: that
+# access unit is dropped, restart header and all, and decoding goes on with the state the decoder has):
+# name -> (indices of the major syncs to change, new group-1 bps code, new channel assignment or None).
+# The expected PCM is whatever the real reference makes of it -- 80 PCM frames fewer per dropped unit.
+SYNC_CHANGES = {
+    "sync_change_6ch": ((2, 4, 5), 1, None),
+    "sync_change_2ch_2ss": ((1, 2, 3), 0, 3),
+}
+FIXTURES += [
+    ("sync_change_6ch", 12, 1, 1, 28, 0, 0, 21, 4),
+    ("sync_change_2ch_2ss", 1, 1, 2, 30, 0, 0, 22, 5),
+]
+
+
 def main():
     assert oracle_lib.Reference.available(), "build oracle/_ref first: make -C oracle ref"
+    from tests import stream_tools
     ref = oracle_lib.Reference()
     here = os.path.dirname(os.path.abspath(__file__))
+    only_missing = "--all" not in sys.argv
     for name, asg, rate, S, naus, prof, feat, seed, ri in FIXTURES:
+        if only_missing and os.path.exists(os.path.join(here, name + ".npz")):
+            continue
         cfg = syn.make_cfg(assignment=asg, rate_code=rate, n_substreams=S, n_aus=naus, profile=prof,
                            features=feat, restart_interval=ri)
         data, frames = syn.stream(cfg, seed)
-        pcm, r = ref.decode(data, asg, rate, cfg.bps_code, frames, chunk=2013)
+        if name in SYNC_CHANGES:
+            which, bps, new_asg = SYNC_CHANGES[name]
+            data, _ = stream_tools.change_sync_params(data, which, g1_bps=bps, assignment=new_asg)
+            frames -= len(which) * syn.rows_per_au(rate)
+        pcm, r = ref.decode(data, asg, rate, cfg.bps_code, frames + 400, chunk=2013)
         assert r == frames, (name, r, frames)
         np.savez_compressed(os.path.join(here, name + ".npz"), mlp=data, pcm=pcm,
                             meta=np.array([asg, rate, S, naus, prof, feat, seed, ri, cfg.bps_code],

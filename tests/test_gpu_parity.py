@@ -488,3 +488,160 @@ def test_config3_1024_independent_access_units(pkg, oracle, S):
     assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(1024))
     loads = np.array([sizes[p].sum() for p in parts])
     assert loads.max() - loads.min() <= sizes.max()
+
+
+def test_device_bit_reader_known_answers(pkg, oracle):
+    """The kernels' bit reader on the reference's own known answers for the bytes B1 ED 3B C1
+    (src/bitstream.c:4864-4868 unsigned, 4940-4944 signed), through the cold-path read()/read_signed() and
+    through the row loop's branch-free read_resident(); then against the oracle's reader on random fields
+    that cross every dword boundary of a longer buffer."""
+    import ctypes
+    L = pkg.hipdec.lib()
+    L.dvda_mlp_hip_selftest_bits.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+
+    def dev(data, widths, resident=0):
+        b = np.ascontiguousarray(data, np.uint8)
+        w = np.asarray(widths, np.int32)
+        out = np.zeros(len(w), np.int64)
+        assert L.dvda_mlp_hip_selftest_bits(0, b.ctypes.data, len(b), w.ctypes.data, len(w), out.ctypes.data,
+                                            resident) == 0
+        return out.tolist()
+
+    kat = [0xB1, 0xED, 0x3B, 0xC1]
+    assert dev(kat, [2, 3, 5, 3, 19]) == [2, 6, 7, 5, 0x53BC1]
+    assert dev(kat, [2, 3, 5, 3, 19], resident=1) == [2, 6, 7, 5, 0x53BC1]
+    assert dev(kat, [-2, -3, -5, -3, -19]) == [-2, -2, 7, -3, -181311]
+    assert dev(kat, [0, 8, 0, 24]) == [0, 0xB1, 0, 0xED3BC1]
+    assert dev(kat, [32]) == [0xB1ED3BC1]
+    ol = oracle.lib
+    ol.mlp_oracle_test_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int),
+                                        ctypes.c_int, ctypes.POINTER(ctypes.c_long)]
+    rng = np.random.RandomState(5)
+    data = rng.randint(0, 256, size=600).astype(np.uint8)
+    for resident in (0, 1):
+        widths, total = [], 0
+        while total < 4500:
+            w = int(rng.randint(0, 32 if resident else 33))
+            if not resident and rng.randint(0, 3) == 0 and w:
+                w = -w
+            widths.append(w)
+            total += abs(w)
+        cw = (ctypes.c_int * len(widths))(*widths)
+        want = (ctypes.c_long * len(widths))()
+        assert ol.mlp_oracle_test_read(data.ctypes.data, len(data), cw, len(widths), want) == 0
+        assert dev(data, widths, resident) == list(want)
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_changed_major_syncs_are_dropped_like_the_reference(pkg, oracle, S):
+    """Later major syncs with other stream parameters (reference src/mlp.c:449-460): the index walks through
+    them, the decode drops those access units and goes on with the state it has -- batch tier in both
+    layouts, next to an untouched stream, and packet by packet through the streaming tier.  (The two
+    sync_change_* golden vectors pin the same against PCM produced by the real reference.)"""
+    from tests import stream_tools
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=48, restart_interval=4)
+    clean, frames = syn.stream(cfg, 606 + S)
+    one, _ = stream_tools.change_sync_params(clean, (3,), g1_bps=0)
+    runs, _ = stream_tools.change_sync_params(clean, (1, 2, 5, 6, 7, 8, 11), assignment=3)
+    pcm, infos = _both(hip, [one, clean, runs])
+    for b, got, inf, drops in ((one, pcm[0], infos[0], 1), (clean, pcm[1], infos[1], 0), (runs, pcm[2], infos[2], 7)):
+        want, r, st = oracle.decode(b, 6, frames)
+        assert r == frames - 80 * drops and st == (2 if drops else 0)
+        assert inf.status & ~hip.ST_BENIGN == 0, hex(inf.status)
+        assert bool(inf.status & hip.ST["SYNC_CHANGE"]) == bool(drops)
+        assert inf.pcm_frames == r and np.array_equal(got, want)
+    # five in a row are more than one segment walks through: reported, never passed as clean
+    five, _ = stream_tools.change_sync_params(clean, (2, 3, 4, 5, 6), g1_bps=0)
+    _, inf5 = hip.decode_streams([five])
+    assert inf5[0].status & hip.ST["IRREGULAR"]
+    # streaming tier, PES-payload sized packets
+    dec = hip.MLPDecoder(2, 2, 1, 1, 12)
+    samples = [[] for _ in range(6)]
+    for off in range(0, len(runs), 2013):
+        dec.decode_packet(np.ascontiguousarray(runs[off:off + 2013]), samples)
+        assert dec.status & ~hip.ST_BENIGN == 0, hex(dec.status)
+    dec.close()
+    want, r, st = oracle.decode(runs, 6, frames)
+    assert np.array_equal(np.asarray(samples, np.int32), want)
+
+
+def test_thousands_of_chains_and_midframe_segments_in_one_batch(pkg, oracle):
+    """More deferred work than any fixed pool of frame buffers could hold (round 1 stopped at 2 048 run
+    heads with DVDA_ST_CAPACITY): 4 500 chained titles + 700 with mid-frame parameter changes + 300 plain
+    ones in one batch, every one of them against the oracle."""
+    syn, hip = pkg.synth, pkg.hipdec
+    SF = syn.SF
+    specs = [(syn.make_cfg(assignment=12, rate_code=1, n_aus=6, profile=1, features=SF["CHAINED"] | SF["FIRRAND"],
+                           restart_interval=2), 4500, 11000),
+             (syn.make_cfg(assignment=1, rate_code=0, n_aus=6, profile=1,
+                           features=SF["MIDMATRIX"] | SF["PARAMBLOCKS"] | SF["MATRIXRAND"] | SF["VARBLOCK"] | SF["QSS"],
+                           restart_interval=3), 700, 22000),
+             (syn.make_cfg(assignment=12, rate_code=1, n_aus=6), 300, 33000)]
+    streams, meta = [], []
+    for cfg, n, seed0 in specs:
+        flat, offs, sizes, frames = syn.batch(cfg, seed0, n)
+        for o, z, f in zip(offs, sizes, frames):
+            streams.append(flat[int(o):int(o + z)])
+            meta.append((syn.channels(cfg.assignment), int(f)))
+    pcm, infos = hip.decode_streams(streams, layout=hip.PCM_INTERLEAVED)
+    n_chained = sum(1 for inf in infos if inf.status & hip.ST["CHAINED"])
+    n_mid = sum(1 for inf in infos if inf.status & hip.ST["MIDFRAME"])
+    assert n_chained >= 4400 and n_mid >= 100, (n_chained, n_mid)
+    for i, (b, (nch, f)) in enumerate(zip(streams, meta)):
+        want, r, st = oracle.decode(b, nch, f)
+        assert st == 0 and r == f
+        assert infos[i].status & ~hip.ST_BENIGN == 0, "stream %d status %#x" % (i, infos[i].status)
+        assert infos[i].pcm_frames == f and np.array_equal(pcm[i], want), "stream %d differs" % i
+
+
+def test_mixed_batch_picks_the_kernels_itself(pkg, oracle):
+    """One- and two-substream streams in ONE batch with nothing said about lanes (the default): the library
+    runs the one-lane kernel for the former and the two-wave kernel for the latter; forcing one lane makes a
+    two-substream stream an envelope error as documented."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfgs = [syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=24),
+            syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24),
+            syn.make_cfg(assignment=1, rate_code=0, n_substreams=1, n_aus=40),
+            syn.make_cfg(assignment=0x14, rate_code=2, n_substreams=2, n_aus=12, profile=1, features=syn.SF_ALL,
+                         restart_interval=3),
+            syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=24, profile=1,
+                         features=syn.SF["CHAINED"] | syn.SF["FIRRAND"], restart_interval=4)]
+    streams = [syn.stream(c, 5150 + i) for i, c in enumerate(cfgs)]
+    pcm, infos = _both(hip, [b for b, _ in streams])
+    for (b, f), c, got, inf in zip(streams, cfgs, pcm, infos):
+        want, r, st = oracle.decode(b, syn.channels(c.assignment), f)
+        assert st == 0 and r == f
+        assert inf.status & ~hip.ST_BENIGN == 0 and inf.substreams == c.n_substreams
+        assert np.array_equal(got, want)
+    _, forced = hip.decode_streams([b for b, _ in streams], lanes_per_segment=1)
+    assert forced[1].status & hip.ST["ENVELOPE"] and forced[0].status == 0
+
+
+def test_too_small_a_context_is_reported_not_truncated(pkg, oracle):
+    """more major syncs than max_segments used to come back as short PCM with status 0."""
+    import torch
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=64, restart_interval=2)       # 32 segments per title
+    streams = [syn.stream(cfg, 8800 + i)[0] for i in range(3)]
+    flat, offs, lens = hip.pack_streams(streams)
+    dev = torch.device("cuda", 0)
+    d_bytes = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    ctx = hip.Context(0, 3, 40)                     # holds the first title and a quarter of the second
+    try:
+        ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), 3, 0)
+        with pytest.raises(hip.HipError):
+            ctx.segment_count()
+        infos = ctx.stream_info()
+        assert infos[0].status == 0 and infos[0].mlp_frames == 64
+        assert infos[1].status & hip.ST["CAPACITY"] and infos[2].status & hip.ST["CAPACITY"]
+    finally:
+        ctx.close()
+    # decode_streams grows the context by itself
+    pcm, infos = hip.decode_streams(streams, max_segments=40)
+    for b, got, inf in zip(streams, pcm, infos):
+        want, r, st = oracle.decode(b, 6, 64 * 80)
+        assert inf.status == 0 and np.array_equal(got, want)

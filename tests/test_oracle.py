@@ -23,7 +23,10 @@ def test_oracle_matches_golden(oracle, path, chunk):
     z = np.load(path)
     want = z["pcm"]
     got, frames, status = oracle.decode(z["mlp"], want.shape[0], want.shape[1], chunk=chunk)
-    assert status == 0
+    # bit 1 is information: later major syncs with other stream parameters were dropped, as the reference
+    # drops them (src/mlp.c:449-460) -- the sync_change_* vectors are exactly that, produced by the reference
+    assert status & ~2 == 0
+    assert bool(status & 2) == os.path.basename(path).startswith("sync_change")
     assert frames == want.shape[1]
     assert np.array_equal(got, want)
 
@@ -124,3 +127,33 @@ def test_oracle_flags_corruption(oracle, pkg):
     # empty input
     _, r, st = oracle.decode(data[:0], 6, 16)
     assert r == 0 and st == 0
+
+
+@pytest.mark.skipif(not oracle_lib.Reference.available(), reason="compiled reference not present")
+@pytest.mark.parametrize("S", [1, 2])
+def test_oracle_vs_reference_on_changed_major_syncs(oracle, pkg, S):
+    """reference src/mlp.c:449-460: an access unit whose major sync announces other stream parameters
+    than the first one is dropped (restart header and all) and decoding goes on with the state the decoder
+    has.  The restatement must do exactly that: same PCM, 80 frames fewer per dropped unit.  (The reference
+    runs in a child process: should it assert() on such a stream the test fails instead of the session.)"""
+    import subprocess
+    import sys
+    import tempfile
+    from tests import stream_tools
+    syn = pkg.synth
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=40, restart_interval=4)
+    data, frames = syn.stream(cfg, 4040 + S)
+    changed, _ = stream_tools.change_sync_params(data, (1, 4, 5, 6, 9), g1_bps=0, assignment=None)
+    want_frames = frames - 5 * 80
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "in.npy"), changed)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from tests import oracle_lib; "
+                "d = np.load(%r); pcm, r = oracle_lib.Reference().decode(d, 12, 1, 2, %d, chunk=1999); "
+                "np.save(%r, pcm)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                      os.path.join(tmp, "in.npy"), frames, os.path.join(tmp, "out.npy")))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        want = np.load(os.path.join(tmp, "out.npy"))
+    assert want.shape == (6, want_frames)
+    got, r2, st = oracle.decode(changed, 6, frames)
+    assert st == 2 and r2 == want_frames and np.array_equal(got, want)
