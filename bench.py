@@ -97,6 +97,28 @@ def launch_ranks(args):
 
 
 # ----------------------------------------------------------------------------- CPU side (checker + baseline)
+def usable_cpus():
+    """-> (threads worth starting, logical CPUs in the affinity mask, cgroup quota in CPUs or None).  A
+    container may see every logical CPU of the host and still be limited to a few CPUs' worth of time
+    (cgroup cpu.max): more threads than that only add throttling."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = logical if quota is None else max(1, min(logical, int(quota + 0.5)))
+    return n, logical, quota
+
+
 def cpu_legs(flat, offs, sizes, frames, assignment, rate_code, nch, budget_s, n_threads):
     """Decodes the unique titles on the host with the CPU decoder the GPU result is compared with and timed
     against: the compiled reference (oracle/_ref/libdvda_ref.so, kind 'reference') when it travelled with
@@ -352,18 +374,46 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     flat, offs, sizes, frames = syn.batch(cfg1, 1, args.streams)
     run("stereo_c2", flat, offs, sizes, frames, np.full(len(sizes), 2), nseg, args.replicas, "planar", 0,
         note="BASELINE configs[1] shape (2ch/96k/24b), planar layout")
-    # ---- heterogeneous batches: fuzz-profile titles, mixed layouts / rates / restart intervals -- header
-    #      parses diverge inside the waves.  "heterogeneous": what varies from disc to disc (block splits,
-    #      code books per channel, quant step sizes, output shifts, Huffman offsets, flag bytes, parameter
-    #      updates on any block, random FIR orders/coefficients, no check data on some streams);
-    #      "heterogeneous_all_features" adds what DVD-Audio discs rarely carry: IIR taps with transmitted
-    #      state (cold workspace path) and up to 6 random matrices
+    # ---- heterogeneous batches: header parses diverge inside the waves (the headline batch is ONE shape:
+    #      every lane of a wave reaches every block and frame header in the same loop turn).
+    #      "heterogeneous": regular titles as an encoder writes them, but eight different kinds in one batch
+    #      (6/2/5/1-ch, 48/96/192 kHz, 1-5 blocks per access unit, restart every 4-16 units, FIR order 4-8, all
+    #      three code books, 0-2 matrices, different lengths);
+    #      "fuzz_fast_features": the test generator's fuzz profile -- parameters change on a third of all
+    #      blocks, random block splits, per-channel code books ... (no IIR, the recipe's 2 matrices);
+    #      "fuzz_all_features" adds what DVD-Audio discs rarely carry: IIR taps with transmitted state (cold
+    #      workspace path) and up to 6 random matrices
+    kinds = [dict(assignment=12, rate_code=1, restart_interval=8, blocks_per_au=2, fir_order=8, codebook=1,
+                  huffman_lsbs=12, n_matrices=2, n_aus=64),
+             dict(assignment=1, rate_code=1, restart_interval=16, blocks_per_au=1, fir_order=4, codebook=2,
+                  huffman_lsbs=10, n_matrices=1, n_aus=72),
+             dict(assignment=12, rate_code=2, restart_interval=8, blocks_per_au=4, fir_order=8, codebook=3,
+                  huffman_lsbs=14, n_matrices=2, n_aus=40),
+             dict(assignment=0x12, rate_code=0, restart_interval=8, blocks_per_au=1, fir_order=6, codebook=1,
+                  huffman_lsbs=8, n_matrices=2, n_aus=96),
+             dict(assignment=12, rate_code=0, restart_interval=12, blocks_per_au=2, fir_order=8, codebook=2,
+                  huffman_lsbs=12, n_matrices=0, n_aus=80),
+             dict(assignment=6, rate_code=1, restart_interval=8, blocks_per_au=2, fir_order=5, codebook=1,
+                  huffman_lsbs=11, n_matrices=2, n_aus=64),
+             dict(assignment=0, rate_code=2, restart_interval=4, blocks_per_au=2, fir_order=8, codebook=1,
+                  huffman_lsbs=16, n_matrices=0, n_aus=48),
+             dict(assignment=12, rate_code=1, restart_interval=10, blocks_per_au=5, fir_order=8, codebook=1,
+                  huffman_lsbs=13, n_matrices=2, n_aus=56)]
+    specs = [(syn.make_cfg(n_substreams=1, **k), 512) for k in kinds]
+    flat, offs, sizes, frames, nchs, nseg_h = gen_mixed(syn, specs, 70000)
+    # interleave the kinds title by title: neighbouring lanes of a wave then hold different kinds
+    order = np.arange(len(sizes)).reshape(len(kinds), -1).T.ravel()
+    flat2, offs2, lens2 = hip.pack_streams([flat[int(offs[i]):int(offs[i] + sizes[i])] for i in order])
+    run("heterogeneous", flat2, offs2.astype(np.int64), lens2.astype(np.int64), frames[order], nchs[order], nseg_h * 4, 4,
+        "planar", 0, note="8 kinds of regular titles interleaved title by title (6/2/5/1-ch, 48/96/192 kHz, 1-5 blocks "
+                          "per access unit, restart every 4-16 units, FIR 4-8 taps, code books 1-3, 0-2 matrices), "
+                          "16 384 titles of 40-96 access units")
     shapes = [(12, 1, 8), (1, 1, 5), (12, 2, 16), (0x12, 0, 3), (12, 0, 8), (6, 1, 4), (0, 2, 8), (12, 1, 2)]
     SF = syn.SF
     common = syn.SF_FAST & ~(SF["IIR"] | SF["MATRIXRAND"])
     for name, feats, note in (
-            ("heterogeneous", common, "no IIR, the recipe's 2 matrices"),
-            ("heterogeneous_all_features", syn.SF_FAST, "IIR taps and up to 6 random matrices on top")):
+            ("fuzz_fast_features", common, "no IIR, the recipe's 2 matrices"),
+            ("fuzz_all_features", syn.SF_FAST, "IIR taps and up to 6 random matrices on top")):
         specs = [(syn.make_cfg(assignment=asg, rate_code=rc, n_substreams=1, n_aus=64, profile=1, features=feats,
                                restart_interval=ri), 512) for asg, rc, ri in shapes]
         flat, offs, sizes, frames, nchs, nseg_h = gen_mixed(syn, specs, 90000)
@@ -597,7 +647,7 @@ def main():
     checked = 0
     full = (not args.no_cpu) and world == 1 and args.workload == "c3"
     if full:
-        n_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        n_threads, logical_cpus, cpu_quota = usable_cpus()
         cpu, ref_pcm = cpu_legs(flat, offs, sizes, frames.astype(np.int64), assignment, rate_code, nch,
                                 args.cpu_seconds, n_threads)
         per = b.samples // b.R
@@ -682,9 +732,18 @@ def main():
         if cpu:
             out["cpu_baseline"] = cpu[0]
             out["cpu_baseline_all_cores"] = cpu[1]
+            cpu[1]["host_logical_cpus"] = logical_cpus
+            cpu[1]["cgroup_cpu_quota"] = cpu_quota
             out["speedup_vs_cpu"] = {"vs_1_core": round(value / cpu[0]["value"], 1),
-                                     "vs_all_%d_cores" % cpu[1]["cores"]: round(value / cpu[1]["value"], 1),
+                                     "vs_%d_cores_usable_here" % cpu[1]["cores"]: round(value / cpu[1]["value"], 1),
                                      "n_gpus": world}
+            if cpu_quota is not None and logical_cpus > n_threads:
+                # the container is limited to `cores` CPUs of a bigger host: what the whole host would do if
+                # the measured per-thread rate held on every logical CPU (an upper bound: SMT siblings share a
+                # core) -- stated as an extrapolation, not a measurement
+                per_thread = cpu[1]["value"] / cpu[1]["cores"]
+                out["speedup_vs_cpu"]["vs_all_%d_host_cpus_extrapolated" % logical_cpus] = round(
+                    value / (per_thread * logical_cpus), 1)
         out["host"] = {"gen_seconds": round(t_gen, 2), "cpus": os.cpu_count()}
         if world == 1 and not args.no_sub and args.workload == "c3" and args.substreams == 1 and assignment == 12:
             sub_steps = max(5, min(args.steps, 20))

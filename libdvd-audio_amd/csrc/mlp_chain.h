@@ -335,30 +335,44 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
                         P[row] = fir_step_one(h, c, shift, qmask, P[row]);
                         row++;
                     }
-                    // sixteen PCM frames per turn, the next sixteen already on their way
+                    // sixteen PCM frames per turn, the next thirty-two already on their way (a lane streams its
+                    // own plane and has nothing else to hide the memory latency behind: at ~70 cycles per
+                    // frame that is about one HBM round trip of cover)
                     if (row + 16 <= run_end) {
-                        int4 v0 = *reinterpret_cast<const int4 *>(P + row), v1 = *reinterpret_cast<const int4 *>(P + row + 4),
-                             v2 = *reinterpret_cast<const int4 *>(P + row + 8), v3 = *reinterpret_cast<const int4 *>(P + row + 12);
+                        const int4 *Q = reinterpret_cast<const int4 *>(P + row);
+                        int4 v0 = Q[0], v1 = Q[1], v2 = Q[2], v3 = Q[3];
+                        int4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+                        if (row + 32 <= run_end) {
+                            n0 = Q[4];
+                            n1 = Q[5];
+                            n2 = Q[6];
+                            n3 = Q[7];
+                        }
                         while (row + 16 <= run_end) {
-                            int4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-                            const bool more = row + 32 <= run_end;
-                            if (more) {
-                                n0 = *reinterpret_cast<const int4 *>(P + row + 16);
-                                n1 = *reinterpret_cast<const int4 *>(P + row + 20);
-                                n2 = *reinterpret_cast<const int4 *>(P + row + 24);
-                                n3 = *reinterpret_cast<const int4 *>(P + row + 28);
+                            int4 m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+                            if (row + 48 <= run_end) {
+                                const int4 *N = reinterpret_cast<const int4 *>(P + row + 32);
+                                m0 = N[0];
+                                m1 = N[1];
+                                m2 = N[2];
+                                m3 = N[3];
                             }
                             fir_step8(h, c, shift, qmask, v0, v1);
                             fir_step8(h, c, shift, qmask, v2, v3);
-                            *reinterpret_cast<int4 *>(P + row) = v0;
-                            *reinterpret_cast<int4 *>(P + row + 4) = v1;
-                            *reinterpret_cast<int4 *>(P + row + 8) = v2;
-                            *reinterpret_cast<int4 *>(P + row + 12) = v3;
+                            int4 *O = reinterpret_cast<int4 *>(P + row);
+                            O[0] = v0;
+                            O[1] = v1;
+                            O[2] = v2;
+                            O[3] = v3;
                             row += 16;
                             v0 = n0;
                             v1 = n1;
                             v2 = n2;
                             v3 = n3;
+                            n0 = m0;
+                            n1 = m1;
+                            n2 = m2;
+                            n3 = m3;
                         }
                     }
                     while (row + 8 <= run_end) {

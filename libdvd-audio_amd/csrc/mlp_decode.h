@@ -62,6 +62,29 @@ constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
 #define DVDA_OUT_ROWS 4
 #endif
 constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel and flush
+// Experiment, off: the ring holds the stream's dwords already in big-endian value order (swapped once when a
+// 64-byte chunk lands, 16 swaps per ~5 PCM frames) instead of swapping every dword the parser looks at (6+
+// per frame).  Measured neutral (round 2, tools/ab_bench.sh: 4.44 ms either way).
+#ifndef DVDA_RING_SWAPPED
+#define DVDA_RING_SWAPPED 0
+#endif
+// Experiment, off: channel slots a lane does not carry (k >= nslots) hold all-zero parameters (set at every
+// restart header) -- they read no bits and produce 0, so the row loop needs no per-lane "does this lane carry
+// slot k" test, only a wave-uniform "does any lane" one.  Measured (round 2, tools/pmc_valu_ab.sh): the
+// unconditional history moves cost the register allocator more copies than the selects they replace --
+// SQ_INSTS_VALU 2.118e9 vs 2.001e9 per launch, kernel time the same.
+#ifndef DVDA_UNIFORM_SLOTS
+#define DVDA_UNIFORM_SLOTS 0
+#endif
+#if DVDA_RING_SWAPPED
+#define DVDA_RING_IN(x) __builtin_bswap32(x)     // memory dword -> ring dword
+#define DVDA_RING_OUT(x) (x)                     // ring dword -> stream-order value
+#define DVDA_RING_BYTE(v, i) (((v) >> (24 - 8 * (i))) & 0xFFu)   // i-th byte of the stream in a ring dword
+#else
+#define DVDA_RING_IN(x) (x)
+#define DVDA_RING_OUT(x) __builtin_bswap32(x)
+#define DVDA_RING_BYTE(v, i) (((v) >> (8 * (i))) & 0xFFu)
+#endif
 // (8 frames = whole 32-byte sectors and half the write requests, 16 = whole 64-byte writes, which the
 //  memory side takes 4 x faster than partial ones -- tools/fetch_calib.hip.  Neither fits: four
 //  2-wave workgroups share a CU only up to ~31 KB of LDS each (measured: 30 208 B fits, 32 256 B
@@ -219,11 +242,11 @@ __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, cons
 {
     // dst = slot of the chunk's first dword; the chunk is 16-dword aligned, so no wrap inside it
     if (first_plane)
-        dst[RING_DWORDS * 64] = a.x;
-    dst[0 * 64] = a.x;  dst[1 * 64] = a.y;  dst[2 * 64] = a.z;  dst[3 * 64] = a.w;
-    dst[4 * 64] = b.x;  dst[5 * 64] = b.y;  dst[6 * 64] = b.z;  dst[7 * 64] = b.w;
-    dst[8 * 64] = c.x;  dst[9 * 64] = c.y;  dst[10 * 64] = c.z; dst[11 * 64] = c.w;
-    dst[12 * 64] = d.x; dst[13 * 64] = d.y; dst[14 * 64] = d.z; dst[15 * 64] = d.w;
+        dst[RING_DWORDS * 64] = DVDA_RING_IN(a.x);
+    dst[0 * 64] = DVDA_RING_IN(a.x);  dst[1 * 64] = DVDA_RING_IN(a.y);  dst[2 * 64] = DVDA_RING_IN(a.z);  dst[3 * 64] = DVDA_RING_IN(a.w);
+    dst[4 * 64] = DVDA_RING_IN(b.x);  dst[5 * 64] = DVDA_RING_IN(b.y);  dst[6 * 64] = DVDA_RING_IN(b.z);  dst[7 * 64] = DVDA_RING_IN(b.w);
+    dst[8 * 64] = DVDA_RING_IN(c.x);  dst[9 * 64] = DVDA_RING_IN(c.y);  dst[10 * 64] = DVDA_RING_IN(c.z); dst[11 * 64] = DVDA_RING_IN(c.w);
+    dst[12 * 64] = DVDA_RING_IN(d.x); dst[13 * 64] = DVDA_RING_IN(d.y); dst[14 * 64] = DVDA_RING_IN(d.z); dst[15 * 64] = DVDA_RING_IN(d.w);
 }
 
 // ---------------------------------------------------------------- cold helpers
@@ -243,7 +266,7 @@ __device__ __attribute__((noinline)) uint64_t crc_tail(uint32_t v, uint32_t firs
 {
     uint32_t crc = st & 0xFF, fin = (st >> 8) & 0xFF, flags = st >> 16;
     for (uint32_t i = first_byte; i < 4 && rem; i++, rem--) {
-        const uint32_t b = (v >> (8 * i)) & 0xFF;
+        const uint32_t b = DVDA_RING_BYTE(v, i);
         if (rem > 3) {
             par ^= b;
             crc = tab[crc ^ b];
@@ -310,7 +333,7 @@ struct BitReader {
     {
         return ring + ((d & (RING_DWORDS - 1)) << 6);
     }
-    __device__ __forceinline__ uint32_t ld(uint32_t d) const { return __builtin_bswap32(*slot(d)); }
+    __device__ __forceinline__ uint32_t ld(uint32_t d) const { return DVDA_RING_OUT(*slot(d)); }
     __device__ __forceinline__ void filled()
     {
         fillpos += CHUNK_DWORDS;
@@ -333,8 +356,8 @@ struct BitReader {
                 crc_pos++;
                 // slicing-by-4: only the first lookup depends on the running state
                 const uint32_t c = crc_st & 0xFF;
-                const uint32_t n = crc_tab[768 + ((c ^ v) & 0xFF)] ^ crc_tab[512 + ((v >> 8) & 0xFF)] ^
-                                   crc_tab[256 + ((v >> 16) & 0xFF)] ^ crc_tab[v >> 24];
+                const uint32_t n = crc_tab[768 + (c ^ DVDA_RING_BYTE(v, 0))] ^ crc_tab[512 + DVDA_RING_BYTE(v, 1)] ^
+                                   crc_tab[256 + DVDA_RING_BYTE(v, 2)] ^ crc_tab[DVDA_RING_BYTE(v, 3)];
                 crc_st = (crc_st & ~0xFFu) | n;
                 par ^= v;
             }
@@ -347,8 +370,8 @@ struct BitReader {
             crc_pos++;
             if (__builtin_expect(crc_rem >= 7, 1)) {
                 const uint32_t c = crc_st & 0xFF;
-                const uint32_t n = crc_tab[768 + ((c ^ v) & 0xFF)] ^ crc_tab[512 + ((v >> 8) & 0xFF)] ^
-                                   crc_tab[256 + ((v >> 16) & 0xFF)] ^ crc_tab[v >> 24];
+                const uint32_t n = crc_tab[768 + (c ^ DVDA_RING_BYTE(v, 0))] ^ crc_tab[512 + DVDA_RING_BYTE(v, 1)] ^
+                                   crc_tab[256 + DVDA_RING_BYTE(v, 2)] ^ crc_tab[DVDA_RING_BYTE(v, 3)];
                 crc_st = (crc_st & ~0xFFu) | n;
                 par ^= v;
                 crc_rem -= 4;
@@ -540,6 +563,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     constexpr int WAVES = THREADS / 64;
     constexpr int GROUPS = WSPEC ? WAVES / 2 : 1;
     constexpr int TP = PARSE ? 8 : 6;                             // staged planes: channels (+ bypassed LSBs, seed)
+    // (the sequential pass keeps the per-lane test: a lane there walks on through segments whose channel
+    //  ranges may differ, and a channel's history outlives the segments that do not carry it)
+    constexpr bool USLOT = DVDA_UNIFORM_SLOTS && !GENERAL;
     __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
     __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
     __shared__ int32_t s_xch[SIDE ? WAVES : 1][MAXCH][SIDE ? 64 : 1];
@@ -734,8 +760,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #pragma unroll
         for (int j = 0; j < 4; j++)
             cf[k][j] = 0;
-        pk[k] = 24u << 2;             // codebook 0, 24 LSBs
-        sho[k] = -(1 << 23);
+        pk[k] = USLOT ? 0u : 24u << 2;            // codebook 0, 24 LSBs (USLOT: nothing carried yet -- a restart
+        sho[k] = USLOT ? 0 : -(1 << 23);          // header sets every slot it carries)
     }
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -758,6 +784,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t par_seen = 0, par_pub = 0;   // WS_BAL: version of the published parameters (taken / written)
     const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
     uint32_t nslots = 0;
+    uint32_t slots_w = 2;             // wave-uniform: slots some lane of the wave carries (slots 0, 1 always run)
     bool have_restart = false;
     uint32_t iir_any = 0;             // bit k: slot k has IIR order > 0
 
@@ -998,6 +1025,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             rd.read(8);                            // checksum: ignored
                             nslots = max_ch - min_ch + 1;
                             have_restart = true;
+                            if constexpr (USLOT) {
+                                // slots beyond the substream's channels: no bits, no taps, value 0
+#pragma unroll
+                                for (int kk = 0; kk < NS; kk++)
+                                    if ((uint32_t)kk >= nslots) {
+                                        pk[kk] = 0;
+                                        sho[kk] = 0;
+#pragma unroll
+                                        for (int j = 0; j < 4; j++)
+                                            cf[kk][j] = 0;
+                                    }
+                                iir_any &= (1u << nslots) - 1u;
+                            }
                         }
                         if (blocks_in_frame)
                             matrix_class_change = true;            // seed / matrix defaults change mid-frame
@@ -1344,6 +1384,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
+        if (USLOT && __builtin_expect(__any(hdr_parsed), 0)) {
+            uint32_t sw = 2;
+#pragma unroll
+            for (int k = 2; k < NS; k++)
+                if (__any(active && nslots > (uint32_t)k))
+                    sw = k + 1;
+            slots_w = sw;
+        }
         if (!WSPEC && !__any(active))
             break;                     // (two-wave layout: the block leaves together, at the exchange)
         DVDA_STAMP(0);
@@ -1422,19 +1470,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             for (int k = 0; k < NS; k++) {
                 // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
-                const bool in = (uint32_t)k < nslots;
-                if (k >= 2 && !__any(in)) {
+                const bool in = (USLOT && !WSPEC) ? true : (uint32_t)k < nslots;   // (two-wave layout: whose channel it is)
+                if (k >= 2 && (USLOT ? (uint32_t)k >= slots_w : !__any(in))) {
                     if constexpr (!WSPEC)
                         val[k] = 0;
                     continue;
                 }
-                const uint32_t pkk = in ? pk[k] : 0u;
+                const uint32_t pkk = USLOT ? pk[k] : (in ? pk[k] : 0u);
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
                 const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
                 // the two dwords behind the window: one address, one two-address LDS read (mirror plane)
                 const uint32_t *look = rd.slot(rd.next);
-                const uint32_t cand1 = __builtin_bswap32(look[0]), cand2 = __builtin_bswap32(look[64]);
+                const uint32_t cand1 = DVDA_RING_OUT(look[0]), cand2 = DVDA_RING_OUT(look[64]);
                 const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
                 const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);      // bit 8 of the 9-bit peek
@@ -1501,11 +1549,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 const int32_t ssum = (int32_t)(acc >> shift);
                 value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
-                // history moves only for channels this lane really carries
+                if constexpr (USLOT) {
+                    // (a slot the lane does not carry runs on zeros: its history is 0 and stays 0)
 #pragma unroll
-                for (int j = 7; j > 0; j--)
-                    st[k][j] = in ? st[k][j - 1] : st[k][j];
-                st[k][0] = in ? value : st[k][0];
+                    for (int j = 7; j > 0; j--)
+                        st[k][j] = st[k][j - 1];
+                    st[k][0] = value;
+                } else {
+                    // history moves only for channels this lane really carries
+#pragma unroll
+                    for (int j = 7; j > 0; j--)
+                        st[k][j] = in ? st[k][j - 1] : st[k][j];
+                    st[k][0] = in ? value : st[k][0];
+                }
                 if (__builtin_expect(wave_iir, 0)) {
                     if (iir_on)
                         iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
@@ -1516,7 +1572,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     if (in)
                         xw_mine[k * 64] = value;          // straight to the exchange tile
                 } else {
-                    val[k] = in ? value : 0;
+                    val[k] = USLOT ? value : (in ? value : 0);
                 }
             }
             if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {

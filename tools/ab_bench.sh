@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for v in "$@"; do
   if [ "$v" = base ]; then unset DVDA_MLP_HIP_LIB; else export DVDA_MLP_HIP_LIB=$ROOT/libdvd-audio_amd/exp_$v.so; fi
   for rep in 1 2; do
-    python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu --verify 0 ${BENCH_ARGS} 2>/dev/null | python3 -c "
+    python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu --no-sub --verify 0 ${BENCH_ARGS} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

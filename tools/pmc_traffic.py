@@ -18,10 +18,12 @@ pmc, bench = sys.argv[1], sys.argv[2]
 vals = defaultdict(list)
 for f in glob.glob(os.path.join(pmc, "*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
             name = row["Kernel_Name"]
             m = re.search(r"k_decode<\s*\d+\s*,\s*(\w+)\s*,\s*(\w+)", name)      # <NS, PAIRED, GENERAL[, ILV]>
-            key = "decode_fast" if (m and m.group(2) == "false") else \
+            # the one-lane fast-pass kernel (the two-wave kernel of the same launch sequence exits at once on a
+            # batch without two-substream streams and would halve the mean)
+            key = "decode_fast" if (m and m.group(1) == "false" and m.group(2) == "false") else \
                   "sync_mask" if "k_sync_mask" in name else None
             if key:
                 vals[(key, row["Counter_Name"])].append(float(row["Counter_Value"]))
@@ -45,5 +47,14 @@ out = {
     "algorithmic_bytes": j["roofline"]["algorithmic_bytes_per_launch"],
     "source": os.path.basename(pmc.rstrip("/")),
 }
+# instruction-issue side of the same launch (wave instructions; the bench's "issue" roofline uses them)
+if vals.get(("decode_fast", "SQ_INSTS_VALU")):
+    out["valu_insts_per_launch"] = int(mean(("decode_fast", "SQ_INSTS_VALU")))
+if vals.get(("decode_fast", "SQ_INSTS_SALU")):
+    out["salu_insts_per_launch"] = int(mean(("decode_fast", "SQ_INSTS_SALU")))
+if vals.get(("decode_fast", "GRBM_GUI_ACTIVE")) and j["roofline"].get("kernel_ms"):
+    # shader clock during the kernel = busy cycles / its duration (the profiled run's own duration would be
+    # better; the bench's kernel_ms of the same build is what is at hand)
+    out["gui_active_cycles_per_launch"] = int(mean(("decode_fast", "GRBM_GUI_ACTIVE")))
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out))
