@@ -399,15 +399,25 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
                   huffman_lsbs=16, n_matrices=0, n_aus=48),
              dict(assignment=12, rate_code=1, restart_interval=10, blocks_per_au=5, fir_order=8, codebook=1,
                   huffman_lsbs=13, n_matrices=2, n_aus=56)]
+    # (a) long titles, as on a disc: a title's segments are neighbouring lanes, so most waves hold one kind
+    specs = [(syn.make_cfg(n_substreams=1, **dict(k, n_aus=512)), 256) for k in kinds]
+    flat, offs, sizes, frames, nchs, nseg_h = gen_mixed(syn, specs, 60000)
+    order = np.arange(len(sizes)).reshape(len(kinds), -1).T.ravel()
+    flat2, offs2, lens2 = hip.pack_streams([flat[int(offs[i]):int(offs[i] + sizes[i])] for i in order])
+    run("heterogeneous", flat2, offs2.astype(np.int64), lens2.astype(np.int64), frames[order], nchs[order], nseg_h * 2, 2,
+        "planar", 0, note="8 kinds of regular titles interleaved title by title (6/2/5/1-ch, 48/96/192 kHz, 1-5 blocks "
+                          "per access unit, restart every 4-16 units, FIR 4-8 taps, code books 1-3, 0-2 matrices), "
+                          "4 096 titles of 512 access units: 32-128 segments per title, so a wave holds one or two kinds")
+    # (b) the same kinds as short titles (5-12 segments each): every wave holds ~8 different kinds and every
+    #     block / frame / restart header of every lane is a divergent parse for the whole wave
     specs = [(syn.make_cfg(n_substreams=1, **k), 512) for k in kinds]
     flat, offs, sizes, frames, nchs, nseg_h = gen_mixed(syn, specs, 70000)
     # interleave the kinds title by title: neighbouring lanes of a wave then hold different kinds
     order = np.arange(len(sizes)).reshape(len(kinds), -1).T.ravel()
     flat2, offs2, lens2 = hip.pack_streams([flat[int(offs[i]):int(offs[i] + sizes[i])] for i in order])
-    run("heterogeneous", flat2, offs2.astype(np.int64), lens2.astype(np.int64), frames[order], nchs[order], nseg_h * 4, 4,
-        "planar", 0, note="8 kinds of regular titles interleaved title by title (6/2/5/1-ch, 48/96/192 kHz, 1-5 blocks "
-                          "per access unit, restart every 4-16 units, FIR 4-8 taps, code books 1-3, 0-2 matrices), "
-                          "16 384 titles of 40-96 access units")
+    run("heterogeneous_short_titles", flat2, offs2.astype(np.int64), lens2.astype(np.int64), frames[order], nchs[order],
+        nseg_h * 4, 4, "planar", 0,
+        note="the same 8 kinds as 16 384 titles of 40-96 access units (5-12 segments each), interleaved title by title")
     shapes = [(12, 1, 8), (1, 1, 5), (12, 2, 16), (0x12, 0, 3), (12, 0, 8), (6, 1, 4), (0, 2, 8), (12, 1, 2)]
     SF = syn.SF
     common = syn.SF_FAST & ~(SF["IIR"] | SF["MATRIXRAND"])
@@ -417,7 +427,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         specs = [(syn.make_cfg(assignment=asg, rate_code=rc, n_substreams=1, n_aus=64, profile=1, features=feats,
                                restart_interval=ri), 512) for asg, rc, ri in shapes]
         flat, offs, sizes, frames, nchs, nseg_h = gen_mixed(syn, specs, 90000)
-        run(name, flat, offs, sizes, frames, nchs, nseg_h * 4, 4, "planar", 0,
+        run(name, flat, offs, sizes, frames, nchs, nseg_h * 4, 4, "planar", 0, benign=hip.ST_BENIGN,
             note="8 fuzz-profile configurations (6/2/5/1-ch, 48/96/192 kHz, restart every 2..16 AUs; %s), "
                  "16 384 titles of 64 access units" % note)
     # ---- chained titles: no raw lead-in after a title's first segment, the FIR history runs through

@@ -81,14 +81,16 @@ extern "C" {
 #define DVDA_ST_GENERAL      (1u << 23)  /* segment was decoded by a pass behind the fast pass (informational) */
 #define DVDA_ST_FALSE_SYNC   (1u << 24)  /* segment-level only: a sync pattern inside another segment's
                                             frame chain (payload / padding bytes), resolved and skipped */
-#define DVDA_ST_SEQ          (1u << 25)  /* IIR taps, a restart header inside an access unit, or very dense
-                                            parameter changes in a chained segment: stream decoded in order
-                                            by the sequential pass                                        */
-/* DVDA_ST_CHAINED, _MIDFRAME, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
+#define DVDA_ST_SEQ          (1u << 25)  /* a restart header inside an access unit, or very dense parameter
+                                            changes in a segment of the chain passes: stream decoded in
+                                            order by the sequential pass                                  */
+#define DVDA_ST_COLD         (1u << 26)  /* IIR taps, or more than two matrices: the fused row loop keeps
+                                            neither in registers -- segment decoded by the chain passes   */
+/* DVDA_ST_CHAINED, _MIDFRAME, _COLD, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
  * the passes behind it (chain passes: parse in parallel, the filter recursion alone per channel, rematrix
  * in parallel; or the sequential pass); they stay set as information.  Bits that do not invalidate the PCM: */
 #define DVDA_ST_BENIGN (DVDA_ST_TRUNCATED | DVDA_ST_CHAINED | DVDA_ST_MIDFRAME | DVDA_ST_TIMING | DVDA_ST_GENERAL | \
-                        DVDA_ST_SEQ | DVDA_ST_SYNC_CHANGE)
+                        DVDA_ST_SEQ | DVDA_ST_SYNC_CHANGE | DVDA_ST_COLD)
 
 typedef struct dvda_mlp_hip_ctx dvda_mlp_hip_ctx;
 

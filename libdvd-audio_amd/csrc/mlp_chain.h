@@ -63,7 +63,7 @@ __device__ __forceinline__ bool chain_deferred(const ChainArgs &a, uint32_t i)
     if ((r.flags & (SEG_DEAD | ST_FATAL_INDEX)) || r.nframes == 0)
         return false;
     const uint32_t ss = a.seg_status[i];
-    if (!(ss & (ST_CHAINED | ST_MIDFRAME)) || (ss & ~ST_INFO))
+    if (!(ss & ST_CHAIN) || (ss & ~ST_INFO))
         return false;
     return (a.streams[r.stream].status & (ST_TIMING | ST_SEQ)) == 0;
 }
@@ -226,6 +226,26 @@ __device__ __forceinline__ int32_t fir_step_one(int32_t (&h)[8], const int32_t (
     return v;
 }
 
+// the same with IIR taps (src/mlp.c:1289-1291, 1299): their history takes value - prediction
+__device__ __forceinline__ int32_t iir_step_one(int32_t (&h)[8], const int32_t (&c)[8], int32_t (&ih)[8],
+                                                const int32_t (&ic)[8], uint32_t shift, uint32_t qmask, int32_t residual)
+{
+    int64_t acc = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; j--)
+        acc += (int64_t)c[j] * (int64_t)h[j] + (int64_t)ic[j] * (int64_t)ih[j];
+    const int32_t ss = (int32_t)(acc >> shift);
+    const int32_t v = (int32_t)(((uint32_t)ss + (uint32_t)residual) & qmask);
+#pragma unroll
+    for (int j = 7; j > 0; j--) {
+        h[j] = h[j - 1];
+        ih[j] = ih[j - 1];
+    }
+    h[0] = v;
+    ih[0] = (int32_t)((uint32_t)v - (uint32_t)ss);
+    return v;
+}
+
 __device__ __forceinline__ void fir_step8(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask, int4 &p,
                                           int4 &q)
 {
@@ -259,6 +279,9 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
 
     int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t ih[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // IIR history / taps (rare; cleared by every restart header,
+    int32_t ic[8] = {0, 0, 0, 0, 0, 0, 0, 0};       //  so nothing of them crosses a segment boundary)
+    bool iir = false;
     uint32_t shift = 0, qmask = 0xFFFFFFFFu;
     uint32_t prev_meta = 0;                         // channel range of the segment the history comes from
     uint32_t fail = 0;                              // why the chain stops (status bits for what follows)
@@ -275,7 +298,7 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
             const uint32_t p = chain_prev_live(a, seg, sr.first_seg);
             const uint32_t ps = a.seg_status[p] | (a.seg[p].flags & ST_FATAL_INDEX);
             prev_meta = a.seg_meta[(size_t)p * 2 + sub];
-            if ((ps & ~ST_INFO) || (ps & (ST_CHAINED | ST_MIDFRAME)) || !(prev_meta & 0x100u)) {
+            if ((ps & ~ST_INFO) || (ps & ST_CHAIN) || !(prev_meta & 0x100u)) {
                 fail = (ps & ~ST_INFO) ? (ps & ~ST_INFO) : ST_ENVELOPE;     // nothing to continue from
             } else {
 #pragma unroll
@@ -309,15 +332,17 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
             const uint4 pl = a.plan[seg];
             if (k <= max_ch - min_ch) {
                 int32_t *P = a.res + (size_t)pl.x * 8u + (size_t)(min_ch + k) * R;
-                const uint32_t *rp = a.brec + 2ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
+                const uint32_t *rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
                 uint32_t row = 0;
                 uint32_t next_row = rp[0];
                 while (row < R) {
                     while (next_row == row) {
                         // ---- a block that sets filter parameters starts here (src/mlp.c:1033-1068, 1260-1270)
-                        const uint32_t mask = rp[1];
+                        const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
                         if ((mask >> k) & 1u) {
-                            const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & ((1u << k) - 1u));
+                            const uint32_t below = (1u << k) - 1u;
+                            const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) +
+                                                BREC_IIR_WORDS * __popc(imask & below);
                             const uint32_t pk = w[0];
                             shift = pk & 0xFu;
                             qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
@@ -326,11 +351,29 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
                                 c[2 * j] = lo16(w[1 + j]);
                                 c[2 * j + 1] = hi16(w[1 + j]);
                             }
+                            if (pk & (1u << 16)) {
+                                // the block (re)sets the IIR: taps and the history it starts from, or none
+                                iir = ((pk >> 12) & 0xFu) != 0;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    ic[2 * j] = iir ? lo16(w[5 + j]) : 0;
+                                    ic[2 * j + 1] = iir ? hi16(w[5 + j]) : 0;
+                                }
+#pragma unroll
+                                for (int j = 0; j < 8; j++)
+                                    ih[j] = iir ? (int32_t)w[9 + j] : 0;
+                            }
                         }
-                        rp += 2 + BREC_SLOT_WORDS * __popc(mask);
+                        rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
                         next_row = rp[0];
                     }
                     const uint32_t run_end = (next_row > row && next_row < R) ? next_row : R;
+                    if (__builtin_expect(iir, 0)) {
+                        while (row < run_end) {
+                            P[row] = iir_step_one(h, c, ih, ic, shift, qmask, P[row]);
+                            row++;
+                        }
+                    }
                     while (row < run_end && (row & 3u)) {
                         P[row] = fir_step_one(h, c, shift, qmask, P[row]);
                         row++;

@@ -142,13 +142,14 @@ constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_R
                    ST_PARAMS = 1u << 6, ST_HUFFMAN = 1u << 7, ST_FILTER = 1u << 8,
                    ST_ENVELOPE = 1u << 9, ST_IRREGULAR = 1u << 16, ST_TIMING = 1u << 17,
                    ST_MIDFRAME = 1u << 18, ST_CHAINED = 1u << 19, ST_OVERFLOW = 1u << 20,
-                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23, ST_SEQ = 1u << 25;
+                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23, ST_SEQ = 1u << 25, ST_COLD = 1u << 26;
 constexpr uint32_t ST_SYNC_CHANGE = 1u << 1, ST_TRUNCATED = 1u << 21;
 constexpr uint32_t ST_FATAL_INDEX = (1u << 0) | ST_EOF | ST_IRREGULAR;
-// conditions the fast pass only reports.  ST_CHAINED / ST_MIDFRAME segments are decoded by the three
-// chain passes (parse -> filter recurrence -> rematrix, mlp_chain.h); a stream with ST_TIMING or ST_SEQ
-// is decoded in order by the sequential pass (k_decode<.., GENERAL = true>)
-constexpr uint32_t ST_DEFERRED = ST_CHAINED | ST_MIDFRAME | ST_TIMING | ST_SEQ;
+// conditions the fast pass only reports.  ST_CHAINED / ST_MIDFRAME / ST_COLD segments are decoded by the
+// three chain passes (parse -> filter recurrence -> rematrix, mlp_chain.h); a stream with ST_TIMING or
+// ST_SEQ is decoded in order by the sequential pass (k_decode<.., GENERAL = true>)
+constexpr uint32_t ST_CHAIN = ST_CHAINED | ST_MIDFRAME | ST_COLD;
+constexpr uint32_t ST_DEFERRED = ST_CHAIN | ST_TIMING | ST_SEQ;
 // bits that are information, not errors
 constexpr uint32_t ST_INFO = ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | ST_TRUNCATED | ST_SYNC_CHANGE;
 constexpr int FB_ROWS = 1024;                   // PCM frames one access unit may hold in the general pass
@@ -163,14 +164,16 @@ struct DecodeSummary {
     uint32_t pad[3];
 };
 constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
-constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs
-// block-record dwords one (segment, substream) may use: one full record (2 header words + 6 slots) per 32
-// PCM frames on average -- the BASELINE recipe needs a tenth of that; a stream that changes parameters
-// more often than that is decoded by the sequential pass instead (ST_SEQ)
-__host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return rows + 64u; }
+constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs ...
+constexpr int BREC_IIR_WORDS = 12; // ... + when the block (re)sets the slot's IIR: 4 coefficient pairs + 8 history values
+// block-record dwords one (segment, substream) may use: four per PCM frame -- a block that sets the FIR of all
+// six slots needs 32, one that also loads six IIRs 104, and a block has at least 8 frames; the BASELINE recipe
+// uses 1 % of that.  A segment that changes parameters more densely still is decoded by the sequential pass
+// instead (ST_SEQ)
+__host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return 4u * rows + 64u; }
 // where the chain workspaces of a deferred segment start, from its ChainPlan entry (rows / deferred
 // segments before it): planes at res + 8 * rows_before; block records (two substreams) at
-// brec + 2 * rows_before + 128 * segs_before; per-access-unit records at frec[rows_before / 40 + unit]
+// brec + 8 * rows_before + 128 * segs_before; per-access-unit records at frec[rows_before / 40 + unit]
 // (40 = the shortest access unit: a segment's rows / 40 is at least its number of units)
 
 struct DecodeArgs {
@@ -707,7 +710,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         row0 = 0;
         row_limit = seg_R;
         const uint32_t cap = brec_capacity(seg_R);
-        brec = a.brec + 2ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap;
+        brec = a.brec + 8ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap;
         brec_end = brec + cap - 2u;                 // room for the terminator
         frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
         (void)st_j;
@@ -843,7 +846,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             one_matrix(mreg[0], mnoise[0], 0, matrix_len > 0);
         if (__any(matrix_len > 1))
             one_matrix(mreg[1], mnoise[1], 1, matrix_len > 1);
-        if (__builtin_expect(__any(matrix_len > 2), 0)) {
+        if (GENERAL && __builtin_expect(__any(matrix_len > 2), 0)) {   // (fast pass: such a segment is ST_COLD)
             for (uint32_t m = 2; m < matrix_len; m++) {    // cold: matrices 2.. live in the workspace
                 DVDA_COV(9);
                 uint32_t mc[4];
@@ -989,7 +992,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 uint32_t err = ST_PARAMS;
                 bool matrix_class_change = false;
                 bool hdr_restart = false;
-                uint32_t chg_mask = 0, chg_cnt = 0;        // chain parse pass: slots whose filter parameters this block sets
+                uint32_t chg_mask = 0, iir_mask = 0, rec_words = 0;   // chain parse pass: slots whose filter parameters this block sets
                 bool seq_needed = false;                   // ... and what only the sequential pass decodes
                 if (rd.read(1)) {
                     const bool restart = rd.read(1) != 0;
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             uint32_t lsbs = lb_old + q_old;
                             int32_t hoff = sho_old + huff_center(codebook, lb_old);
                             bool touched = qss_changed;
-                            bool new_fir = false;
+                            bool new_fir = false, new_iir = false;
                             uint32_t ncf[4] = {0, 0, 0, 0};
                             if (rd.read(1)) {
                                 touched = true;
@@ -1207,6 +1210,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                 }
                                 if (ok && (flags & 0x20u) && rd.read(1)) {         // flags[2]
                                     // ---- IIR (src/mlp.c:1075-1119): cold storage in the workspace
+                                    new_iir = true;
                                     iir_order = rd.read(4);
                                     if (iir_order > 8) {
                                         ok = false;
@@ -1245,6 +1249,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                         }
                                     }
                                 } else if (restart) {
+                                    new_iir = true;
                                     iir_order = 0;
                                     iir_shift = 0;
                                 }
@@ -1260,6 +1265,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                 touched = true;
                                 fir_order = fir_shift = iir_order = iir_shift = 0;
                                 new_fir = true;
+                                new_iir = true;
                                 hoff = 0;
                                 codebook = 0;
                                 lsbs = 24;
@@ -1308,19 +1314,32 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                         }
                                     iir_any = (iir_any & ~(1u << k)) | ((iir_order ? 1u : 0u) << k);
                                     if (PARSE) {
-                                        // ---- what the filter pass needs of this slot from this row on
-                                        if (iir_order)
-                                            seq_needed = true;      // IIR taps: the sequential pass has them
-                                        uint32_t *w = brec + 2 + BREC_SLOT_WORDS * chg_cnt;
-                                        if (w + BREC_SLOT_WORDS > brec_end) {
+                                        // ---- what the filter pass needs of this slot from this row on:
+                                        //      shift | quant step | orders, the FIR taps, and -- when this block
+                                        //      (re)sets the slot's IIR -- its taps and the history it starts from
+                                        //      (most recent first, as the header parse left them in the workspace)
+                                        const bool with_iir = new_iir && iir_order != 0;
+                                        uint32_t *w = brec + 2 + rec_words;
+                                        if (w + BREC_SLOT_WORDS + (with_iir ? BREC_IIR_WORDS : 0) > brec_end) {
                                             seq_needed = true;      // more parameter changes than the records hold
                                         } else {
-                                            w[0] = shift | (q << 4) | (fir_order << 8);
+                                            w[0] = shift | (q << 4) | (fir_order << 8) | (iir_order << 12) |
+                                                   (new_iir ? 1u << 16 : 0u);
 #pragma unroll
                                             for (int j = 0; j < 4; j++)
                                                 w[1 + j] = new_fir ? ncf[j] : cf_old[j];
                                             chg_mask |= 1u << k;
-                                            chg_cnt++;
+                                            rec_words += BREC_SLOT_WORDS;
+                                            if (with_iir) {
+                                                const int32_t *ws = a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl;
+                                                for (uint32_t j = 0; j < 4; j++)
+                                                    w[5 + j] = ((uint32_t)ws[(size_t)(2 * j) * a.total_lanes] & 0xFFFFu) |
+                                                               ((uint32_t)ws[(size_t)(2 * j + 1) * a.total_lanes] << 16);
+                                                for (uint32_t j = 0; j < 8; j++)
+                                                    w[9 + j] = (uint32_t)ws[(size_t)(8 + j) * a.total_lanes];
+                                                iir_mask |= 1u << k;
+                                                rec_words += BREC_IIR_WORDS;
+                                            }
                                         }
                                     }
                                 }
@@ -1335,12 +1354,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 hdr_parsed = true;
                 if (PARSE && ok && chg_mask) {
                     brec[0] = rows_done;                // first PCM frame (of the segment) the record applies to
-                    brec[1] = chg_mask;
-                    brec += 2 + BREC_SLOT_WORDS * chg_cnt;
+                    brec[1] = chg_mask | (iir_mask << 8);
+                    brec += 2 + rec_words;
                 }
                 if (PARSE && ok && (seq_needed || (hdr_restart && blocks_in_frame))) {
-                    // IIR taps, a restart header inside a frame (the noise seed of the frame's earlier rows
-                    // changes under it), or more parameter changes than the records hold: the whole stream
+                    // a restart header inside a frame (the noise seed of the frame's earlier rows changes under
+                    // it), or more parameter changes than the records hold: the whole stream
                     // goes through the sequential pass
                     status |= ST_SEQ;
                     active = false;
@@ -1376,6 +1395,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (PARSE && !active) {
                     // (ST_SEQ above)
+                } else if (!GENERAL && !PARSE && (iir_any != 0 || matrix_len > 2)) {
+                    // IIR taps (their coefficients and history live in a memory workspace) or more than the
+                    // two register-resident matrices: the chain passes decode such a segment -- the fused row
+                    // loop keeps neither in its registers
+                    status |= ST_COLD;
+                    active = false;
                 } else if (!GENERAL && !PARSE && (status & ST_CHAINED)) {
                     active = false;            // left to the chain passes (needs the previous history)
                 } else {
@@ -1452,7 +1477,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 // matrices 0 and 1 (the ones every real stream uses) directly, the rest in a cold loop
                 const uint32_t b0 = bypass_mask & 1u, b1 = (bypass_mask >> 1) & 1u;
                 bypass_bits = (b0 & (field >> ((cnt - 1u) & 31u))) | ((b1 & (field >> ((cnt - 1u - b0) & 31u))) << 1);
-                if (__builtin_expect(__any((bypass_mask >> 2) != 0), 0)) {
+                if ((GENERAL || PARSE) && __builtin_expect(__any((bypass_mask >> 2) != 0), 0)) {
                     if (bypass_mask >> 2)
                         DVDA_COV(10);            // bypassed LSBs of matrices 2..5
                     uint32_t rank = b0 + b1;
@@ -1465,7 +1490,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
             uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
-            const bool wave_iir = __any(iir_any != 0); // IIR taps anywhere in the wave (rare)
+            // IIR taps anywhere in the wave (sequential pass only: in the fast pass such a segment is ST_COLD)
+            const bool wave_iir = GENERAL && __any(iir_any != 0);
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
@@ -1922,7 +1948,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             const uint32_t old = atomicOr(&a.seg_status[segi], status);
             if (!GENERAL && !PARSE) {
                 // ---- what the passes behind the fast pass will have to do (the host reads the summary)
-                constexpr uint32_t CH = ST_CHAINED | ST_MIDFRAME;
+                constexpr uint32_t CH = ST_CHAIN;
                 if ((status & CH) && !(old & CH)) {
                     const uint32_t rows = (sr.nframes - sr.ndrop) * rpa;
                     atomicAdd(&a.summary->chain_segs, 1u);

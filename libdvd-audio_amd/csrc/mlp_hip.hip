@@ -459,7 +459,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         if (rows >> 32)
             return DVDA_HIP_ECAPACITY;          // plan entries are 32-bit (137 GB of planes)
         if ((rc = grow(&c->d_res, &c->res_cap, rows * 8 + 64)) != 0 ||
-            (rc = grow(&c->d_brec, &c->brec_cap, 2 * rows + 128ull * segs + 64)) != 0 ||
+            (rc = grow(&c->d_brec, &c->brec_cap, 8 * rows + 128ull * segs + 64)) != 0 ||
             (rc = grow(&c->d_frec, &c->frec_cap, (rows / 40 + segs + 1) * FREC_WORDS)) != 0)
             return rc;
         ChainArgs ca;

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--tracks", type=int, default=8)
     ap.add_argument("--aus", type=int, default=16384)
     ap.add_argument("--tmp", default=None)
+    ap.add_argument("--no-tier-b", action="store_true")
     a = ap.parse_args()
     syn, disc = pkg.synth, pkg.disc
     tool = pkg._build.build_tool()
@@ -65,6 +66,23 @@ def main():
             outs[name] = digest(out)
         if len(outs) == 2:
             res["identical_files"] = outs["gpu"] == outs["reference"]
+        # tier B, "dvda2wav links unchanged": the reference's own dvda2wav + dvd-audio.c with only src/mlp.c
+        # replaced by integration/mlp_hip_shim.c -- one small GPU batch and synchronous copies per <= 2 KB PES
+        # payload.  Compatibility, not throughput: first track only, stated plainly.
+        shim = os.path.join(ROOT, "oracle", "_ref", "dvda2wav_hip")
+        if os.path.exists(shim) and not a.no_tier_b:
+            out = os.path.join(tmp, "tier_b")
+            os.makedirs(out)
+            t0 = time.time()
+            r = subprocess.run([shim, "-A", ats, "-T", "1", "-t", "1", "-d", out], capture_output=True, text=True, env=env)
+            dt = time.time() - t0
+            assert r.returncode == 0, r.stderr[-2000:]
+            one = tracks[0]["pcm_frames"] * 6
+            res["tier_b_first_track_seconds"] = round(dt, 3)
+            res["tier_b_msamples_per_s"] = round(one / dt / 1e6, 2)
+            if "reference" in outs:
+                res["tier_b_identical_to_reference"] = digest(out) == {k: v for k, v in outs["reference"].items()
+                                                                        if k in os.listdir(out)}
         print(json.dumps(res))
 
 
