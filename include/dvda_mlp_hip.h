@@ -86,11 +86,13 @@ extern "C" {
                                             order by the sequential pass                                  */
 #define DVDA_ST_COLD         (1u << 26)  /* IIR taps, or more than two matrices: the fused row loop keeps
                                             neither in registers -- segment decoded by the chain passes   */
-/* DVDA_ST_CHAINED, _MIDFRAME, _COLD, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
+#define DVDA_ST_YIELD        (1u << 27)  /* the segment in front of a chained one, decoded with it by the chain
+                                            passes instead of alone by the fast pass (informational)     */
+/* DVDA_ST_CHAINED, _MIDFRAME, _COLD, _YIELD, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
  * the passes behind it (chain passes: parse in parallel, the filter recursion alone per channel, rematrix
  * in parallel; or the sequential pass); they stay set as information.  Bits that do not invalidate the PCM: */
 #define DVDA_ST_BENIGN (DVDA_ST_TRUNCATED | DVDA_ST_CHAINED | DVDA_ST_MIDFRAME | DVDA_ST_TIMING | DVDA_ST_GENERAL | \
-                        DVDA_ST_SEQ | DVDA_ST_SYNC_CHANGE | DVDA_ST_COLD)
+                        DVDA_ST_SEQ | DVDA_ST_SYNC_CHANGE | DVDA_ST_COLD | DVDA_ST_YIELD)
 
 typedef struct dvda_mlp_hip_ctx dvda_mlp_hip_ctx;
 

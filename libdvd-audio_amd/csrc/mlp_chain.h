@@ -331,13 +331,17 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
             const uint32_t R = (r.nframes - r.ndrop) * rpa;
             const uint4 pl = a.plan[seg];
             if (k <= max_ch - min_ch) {
-                int32_t *P = a.res + (size_t)pl.x * 8u + (size_t)(min_ch + k) * R;
+                // the segment's planes: element (row, plane) at res_index() -- four rows of all eight planes share
+                // a 128-byte line, so the lanes of a chain (one per channel) read and write the same lines together
+                int32_t *const P = a.res + (size_t)pl.x * 8u;
+                const uint32_t plane = min_ch + k;
+                int4 *const Q = reinterpret_cast<int4 *>(P) + plane;         // group g (4 rows) of this plane: Q[g * 8]
                 const uint32_t *rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
                 uint32_t row = 0;
                 uint32_t next_row = rp[0];
-                while (row < R) {
+                // ---- a block that sets filter parameters starts at `row` (src/mlp.c:1033-1068, 1260-1270)
+                auto apply_records = [&]() {
                     while (next_row == row) {
-                        // ---- a block that sets filter parameters starts here (src/mlp.c:1033-1068, 1260-1270)
                         const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
                         if ((mask >> k) & 1u) {
                             const uint32_t below = (1u << k) - 1u;
@@ -367,66 +371,80 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
                         rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
                         next_row = rp[0];
                     }
+                };
+                while (row < R) {
+                    apply_records();
                     const uint32_t run_end = (next_row > row && next_row < R) ? next_row : R;
                     if (__builtin_expect(iir, 0)) {
                         while (row < run_end) {
-                            P[row] = iir_step_one(h, c, ih, ic, shift, qmask, P[row]);
+                            int32_t *e = P + res_index(row, plane);
+                            *e = iir_step_one(h, c, ih, ic, shift, qmask, *e);
                             row++;
                         }
                     }
                     while (row < run_end && (row & 3u)) {
-                        P[row] = fir_step_one(h, c, shift, qmask, P[row]);
+                        int32_t *e = P + res_index(row, plane);
+                        *e = fir_step_one(h, c, shift, qmask, *e);
                         row++;
                     }
-                    // sixteen PCM frames per turn, the next thirty-two already on their way (a lane streams its
-                    // own plane and has nothing else to hide the memory latency behind: at ~70 cycles per
-                    // frame that is about one HBM round trip of cover)
+                    // Sixteen PCM frames per turn, the next thirty-two already on their way (a lane has nothing
+                    // else to hide the memory latency behind).  Three register sets take turns as "in work",
+                    // "next" and "being loaded" -- by position in the unrolled loop, not by copying: a move out
+                    // of a register whose load is still in flight waits for it, which is how a first version of
+                    // this loop waited for every load it had just issued (vmcnt(0) per turn: 9.6 ms instead of
+                    // 6.6 ms on 4 096 chained titles).  (Letting the loads run on across the rows where blocks
+                    // change parameters was tried too: the row-by-row path it needs inside the turn costs the
+                    // compiler 240 bytes of scratch per lane and the kernel a factor of two.)
                     if (row + 16 <= run_end) {
-                        const int4 *Q = reinterpret_cast<const int4 *>(P + row);
-                        int4 v0 = Q[0], v1 = Q[1], v2 = Q[2], v3 = Q[3];
-                        int4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-                        if (row + 32 <= run_end) {
-                            n0 = Q[4];
-                            n1 = Q[5];
-                            n2 = Q[6];
-                            n3 = Q[7];
-                        }
-                        while (row + 16 <= run_end) {
-                            int4 m0 = n0, m1 = n1, m2 = n2, m3 = n3;
-                            if (row + 48 <= run_end) {
-                                const int4 *N = reinterpret_cast<const int4 *>(P + row + 32);
-                                m0 = N[0];
-                                m1 = N[1];
-                                m2 = N[2];
-                                m3 = N[3];
+                        int4 *G = Q + (size_t)(row >> 2) * 8u;
+                        int4 s0[4], s1[4], s2[4];
+                        auto load = [&](int4 (&d)[4], uint32_t ahead) {      // rows [row + ahead, row + ahead + 16)
+                            if (row + ahead + 16 <= run_end) {
+                                const int4 *N = G + (ahead >> 2) * 8u;
+                                d[0] = N[0];
+                                d[1] = N[8];
+                                d[2] = N[16];
+                                d[3] = N[24];
                             }
-                            fir_step8(h, c, shift, qmask, v0, v1);
-                            fir_step8(h, c, shift, qmask, v2, v3);
-                            int4 *O = reinterpret_cast<int4 *>(P + row);
-                            O[0] = v0;
-                            O[1] = v1;
-                            O[2] = v2;
-                            O[3] = v3;
+                        };
+                        auto work = [&](int4 (&d)[4]) {
+                            fir_step8(h, c, shift, qmask, d[0], d[1]);
+                            fir_step8(h, c, shift, qmask, d[2], d[3]);
+                            G[0] = d[0];
+                            G[8] = d[1];
+                            G[16] = d[2];
+                            G[24] = d[3];
                             row += 16;
-                            v0 = n0;
-                            v1 = n1;
-                            v2 = n2;
-                            v3 = n3;
-                            n0 = m0;
-                            n1 = m1;
-                            n2 = m2;
-                            n3 = m3;
+                            G += 32;
+                        };
+                        load(s0, 0);
+                        load(s1, 16);
+                        for (;;) {
+                            load(s2, 32);
+                            work(s0);
+                            if (row + 16 > run_end)
+                                break;
+                            load(s0, 32);
+                            work(s1);
+                            if (row + 16 > run_end)
+                                break;
+                            load(s1, 32);
+                            work(s2);
+                            if (row + 16 > run_end)
+                                break;
                         }
                     }
                     while (row + 8 <= run_end) {
-                        int4 v0 = *reinterpret_cast<const int4 *>(P + row), v1 = *reinterpret_cast<const int4 *>(P + row + 4);
+                        int4 *G = Q + (size_t)(row >> 2) * 8u;
+                        int4 v0 = G[0], v1 = G[8];
                         fir_step8(h, c, shift, qmask, v0, v1);
-                        *reinterpret_cast<int4 *>(P + row) = v0;
-                        *reinterpret_cast<int4 *>(P + row + 4) = v1;
+                        G[0] = v0;
+                        G[8] = v1;
                         row += 8;
                     }
                     while (row < run_end) {
-                        P[row] = fir_step_one(h, c, shift, qmask, P[row]);
+                        int32_t *e = P + res_index(row, plane);
+                        *e = fir_step_one(h, c, shift, qmask, *e);
                         row++;
                     }
                 }
@@ -480,14 +498,14 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     if (row >= R)
         return;
     const uint4 pl = a.plan[seg];
-    const int32_t *P = a.res + (size_t)pl.x * 8u + row;
+    const int32_t *P = a.res + (size_t)pl.x * 8u + res_index(row, 0);
     int32_t ch[MAXCH];
 #pragma unroll
     for (int c = 0; c < 6; c++)
-        ch[c] = P[(size_t)c * R];
+        ch[c] = P[c * 4];
     ch[6] = ch[7] = 0;
-    const uint32_t bypass_bits = (uint32_t)P[(size_t)6 * R];
-    const uint32_t seed = (uint32_t)P[(size_t)7 * R];
+    const uint32_t bypass_bits = (uint32_t)P[6 * 4];
+    const uint32_t seed = (uint32_t)P[7 * 4];
     const uint32_t *F = a.frec + ((size_t)(pl.x / 40u) + row / rpa) * FREC_WORDS;
     const uint32_t w0 = F[0];
     const uint32_t noise_shift = w0 & 0xFFu, matrix_len = (w0 >> 8) & 0xFFu, mmc = w0 >> 16;

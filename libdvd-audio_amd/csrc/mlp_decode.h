@@ -73,6 +73,12 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 // slot k" test, only a wave-uniform "does any lane" one.  Measured (round 2, tools/pmc_valu_ab.sh): the
 // unconditional history moves cost the register allocator more copies than the selects they replace --
 // SQ_INSTS_VALU 2.118e9 vs 2.001e9 per launch, kernel time the same.
+#ifndef DVDA_YIELD_CHECK
+#define DVDA_YIELD_CHECK 1
+#endif
+#ifndef DVDA_YIELD_ASK
+#define DVDA_YIELD_ASK 1
+#endif
 #ifndef DVDA_UNIFORM_SLOTS
 #define DVDA_UNIFORM_SLOTS 0
 #endif
@@ -142,13 +148,17 @@ constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_R
                    ST_PARAMS = 1u << 6, ST_HUFFMAN = 1u << 7, ST_FILTER = 1u << 8,
                    ST_ENVELOPE = 1u << 9, ST_IRREGULAR = 1u << 16, ST_TIMING = 1u << 17,
                    ST_MIDFRAME = 1u << 18, ST_CHAINED = 1u << 19, ST_OVERFLOW = 1u << 20,
-                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23, ST_SEQ = 1u << 25, ST_COLD = 1u << 26;
+                   ST_CAPACITY = 1u << 22, ST_GENERAL = 1u << 23, ST_SEQ = 1u << 25, ST_COLD = 1u << 26,
+                   ST_YIELD = 1u << 27;
 constexpr uint32_t ST_SYNC_CHANGE = 1u << 1, ST_TRUNCATED = 1u << 21;
 constexpr uint32_t ST_FATAL_INDEX = (1u << 0) | ST_EOF | ST_IRREGULAR;
 // conditions the fast pass only reports.  ST_CHAINED / ST_MIDFRAME / ST_COLD segments are decoded by the
 // three chain passes (parse -> filter recurrence -> rematrix, mlp_chain.h); a stream with ST_TIMING or
 // ST_SEQ is decoded in order by the sequential pass (k_decode<.., GENERAL = true>)
-constexpr uint32_t ST_CHAIN = ST_CHAINED | ST_MIDFRAME | ST_COLD;
+// (ST_YIELD: the segment BEFORE a chained one, handed to the chain passes by its own fast-pass lane when the
+//  chained lane asked for it early enough -- the chain then starts there and the fast pass does not spend a
+//  whole segment's latency on one lane per title first)
+constexpr uint32_t ST_CHAIN = ST_CHAINED | ST_MIDFRAME | ST_COLD | ST_YIELD;
 constexpr uint32_t ST_DEFERRED = ST_CHAIN | ST_TIMING | ST_SEQ;
 // bits that are information, not errors
 constexpr uint32_t ST_INFO = ST_DEFERRED | ST_OVERFLOW | ST_GENERAL | ST_TRUNCATED | ST_SYNC_CHANGE;
@@ -171,6 +181,11 @@ constexpr int BREC_IIR_WORDS = 12; // ... + when the block (re)sets the slot's I
 // uses 1 % of that.  A segment that changes parameters more densely still is decoded by the sequential pass
 // instead (ST_SEQ)
 __host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return 4u * rows + 64u; }
+// element (row, plane) of a segment's planes: four rows of all eight planes share a 128-byte line
+__host__ __device__ inline size_t res_index(uint32_t row, uint32_t plane)
+{
+    return (size_t)(row >> 2) * 32u + plane * 4u + (row & 3u);
+}
 // where the chain workspaces of a deferred segment start, from its ChainPlan entry (rows / deferred
 // segments before it): planes at res + 8 * rows_before; block records (two substreams) at
 // brec + 8 * rows_before + 128 * segs_before; per-access-unit records at frec[rows_before / 40 + unit]
@@ -198,9 +213,12 @@ struct DecodeArgs {
     const int32_t *init_fir;       // optional: FIR history a stream starts with, [stream][2][48] (streaming tier)
     DecodeSummary *summary;        // what the fast pass leaves to the passes behind it (read by the host)
     uint32_t interleaved;          // PCM layout: 0 planar, 1 frame-major (see k_decode)
+    const uint32_t *hetero;        // != 0: the batch mixes stream shapes and lane_seg[] deals the segments to the
+    const uint32_t *lane_seg;      //       fast pass's lanes by shape (k_stream_rank / k_lane_perm, mlp_index.h)
     const uint32_t *cls;           // [2]: the batch holds streams with one / two substreams (set by the index)
     uint32_t only_S;               // fast pass: decode only streams with this many substreams (0 = all)
     uint32_t *seg_meta;            // per workspace lane: min_ch | max_ch << 4 at the segment's end
+    uint32_t *yield_req;           // per segment: the next segment of the stream continues this one's FIR history
     // sequential pass: lane pair j decodes stream list[list_base + j] from its first segment on
     // chain parse pass: lane (pair) j parses deferred segment list[list_base + j]
     const uint32_t *list;
@@ -607,6 +625,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     const uint32_t item = WSPEC ? (blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
     uint32_t segi = item;
     bool active = segi < n_seg;
+    if (!GENERAL && !PARSE && active && *a.hetero)
+        segi = a.lane_seg[item];                  // lanes packed by stream shape
     if (GENERAL || PARSE) {
         active = item < a.list_n && (!PARSE || item < a.plan[n_seg].y);
         segi = 0;
@@ -626,6 +646,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     sr.flags = 0;
     sr.sync = 0;
     sr.ndrop = 0;
+    sr.prev = 0xFFFFFFFFu;
     uint32_t fbase = 0, stream_sync = 0, stream_first = 0;
     if (active) {
         sr = a.seg[segi];
@@ -985,6 +1006,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         cur = frame_end;
                     }
                 }
+            }
+            // (looked at on the segment's first few block headers only: the request comes within the first loop
+            //  turn of the lane behind this one, or -- that lane's wave starting late -- not in time at all)
+            if (DVDA_YIELD_CHECK && !GENERAL && !PARSE && active && frames_done < 2 && (frames_done | blocks_in_frame) != 0 &&
+                __hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                status |= ST_YIELD;            // the next segment chains to this one: both go to the chain passes
+                active = false;
             }
             if (active) {
                 // ---- block header (src/mlp.c:748-771)
@@ -1403,6 +1431,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (!GENERAL && !PARSE && (status & ST_CHAINED)) {
                     active = false;            // left to the chain passes (needs the previous history)
+                    // ... which start one segment earlier if that segment's lane hears of it in time: it is
+                    // decoding a whole segment on its own (one lane of many per title) only to hand over its
+                    // last eight values, and the parse pass would then wait for it
+                    // (device-scope accesses on both sides: a plain load may be hoisted out of the loop or served
+                    //  from a stale L1 line)
+                    if (DVDA_YIELD_ASK && sr.prev != 0xFFFFFFFFu)
+                        __hip_atomic_store(&a.yield_req[sr.prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     rows_left = block_size;
                     blocks_in_frame++;
@@ -1891,15 +1926,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
         }
         if (PARSE && flush) {
-            // ---- chain parse pass: the segment's eight planes, four PCM frames each (rows per segment are a
-            //      multiple of 40, the planes start 16-byte aligned)
+            // ---- chain parse pass: four PCM frames of all eight planes are ONE 128-byte line of the segment's
+            //      workspace ([row / 4][plane][row % 4], res_index()): the lane writes it whole, the filter pass's
+            //      lanes of a chain read it together, the rematrix pass reads it once
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
+            int32_t *dst = a.res + out_base + (flush_row >> 2) * 32u;
 #pragma unroll
-            for (int c = 0; c < TP; c++) {
-                int32_t *dst = a.res + out_base + (uint64_t)c * out_stride + flush_row;
-                DVDA_STORE_V4(dst, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane], T[c][2][GENERAL ? 0 : lane],
-                              T[c][3][GENERAL ? 0 : lane]);
-            }
+            for (int c = 0; c < TP; c++)
+                DVDA_STORE_V4_AT(dst, 16 * c, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane],
+                                 T[c][2][GENERAL ? 0 : lane], T[c][3][GENERAL ? 0 : lane]);
         }
         if (!GENERAL && !PARSE && !ILV && flush) {
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
@@ -1943,20 +1978,35 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st[k][j];
         a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8);
     }
-    if (segi < n_seg) {
-        if (status) {
-            const uint32_t old = atomicOr(&a.seg_status[segi], status);
-            if (!GENERAL && !PARSE) {
-                // ---- what the passes behind the fast pass will have to do (the host reads the summary)
-                constexpr uint32_t CH = ST_CHAIN;
-                if ((status & CH) && !(old & CH)) {
-                    const uint32_t rows = (sr.nframes - sr.ndrop) * rpa;
-                    atomicAdd(&a.summary->chain_segs, 1u);
-                    atomicAdd(&a.summary->chain_rows, (unsigned long long)rows);
-                    atomicMax(&a.summary->chain_max_rows, rows);
-                }
+    // ---- what the passes behind the fast pass will have to do (the host reads the summary): summed over the
+    //      wave first -- every lane of a chained batch reports here, and 10^5 atomics on one address are
+    //      milliseconds
+    uint32_t my_rows = 0;
+    if (segi < n_seg && status) {
+        const uint32_t old = atomicOr(&a.seg_status[segi], status);
+        if (!GENERAL && !PARSE && (status & ST_CHAIN) && !(old & ST_CHAIN))
+            my_rows = (sr.nframes - sr.ndrop) * rpa;
+    }
+    if (!GENERAL && !PARSE) {
+        const uint64_t counted = __ballot(my_rows != 0);
+        if (counted) {                                  // wave-uniform
+            uint32_t lo = my_rows, hi = 0, mx = my_rows;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64), m2 = __shfl_xor(mx, o, 64);
+                const uint32_t sum = lo + l2;
+                hi += h2 + (sum < lo ? 1u : 0u);
+                lo = sum;
+                mx = mx > m2 ? mx : m2;
+            }
+            if (lane == 0) {
+                atomicAdd(&a.summary->chain_segs, (uint32_t)__popcll(counted));
+                atomicAdd(&a.summary->chain_rows, ((unsigned long long)hi << 32) | lo);
+                atomicMax(&a.summary->chain_max_rows, mx);
             }
         }
+    }
+    if (segi < n_seg) {
         if (!GENERAL && !PARSE && owner && sub < S && mine)
             a.seg_rows[segi] = rows_written;
     }

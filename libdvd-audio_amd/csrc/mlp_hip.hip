@@ -71,7 +71,13 @@ struct dvda_mlp_hip_ctx {
     unsigned long long *d_dbg;
     int32_t *d_fir;
     uint32_t *d_seg_meta;      // [iir_lanes]: channel range per (segment, substream) at the segment's end
-    uint32_t *d_cls;           // [2]: streams with one / two substreams in the batch
+    uint32_t *d_yield;         // [max_segments]: yield requests of the fast pass (mlp_decode.h, ST_YIELD)
+    uint32_t *d_cls;           // [2]: streams with one / two substreams in the batch; [2] = the batch mixes shapes
+    uint32_t *d_shape_key;     // [max_streams]
+    uint32_t *d_rank;          // [max_streams]
+    uint32_t *d_sorted_cnt;    // [max_streams + 1]
+    uint32_t *d_sorted_base;   // [max_streams + 1]
+    uint32_t *d_lane_seg;      // [max_segments]
     DecodeSummary *d_summary;
     DecodeSummary *h_summary;  // pinned
     uint32_t *d_seq_list;      // [max_streams]: streams for the sequential pass
@@ -124,7 +130,13 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_dbg);
     (void)hipFree(c->d_fir);
     (void)hipFree(c->d_seg_meta);
+    (void)hipFree(c->d_yield);
     (void)hipFree(c->d_cls);
+    (void)hipFree(c->d_shape_key);
+    (void)hipFree(c->d_rank);
+    (void)hipFree(c->d_sorted_cnt);
+    (void)hipFree(c->d_sorted_base);
+    (void)hipFree(c->d_lane_seg);
     (void)hipFree(c->d_summary);
     if (c->h_summary)
         (void)hipHostFree(c->h_summary);
@@ -189,7 +201,13 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_dbg, 16 * sizeof(unsigned long long));
     alloc((void **)&c->d_fir, (size_t)c->iir_lanes * 6 * 8 * sizeof(int32_t));
     alloc((void **)&c->d_seg_meta, (size_t)c->iir_lanes * sizeof(uint32_t));
-    alloc((void **)&c->d_cls, 2 * sizeof(uint32_t));
+    alloc((void **)&c->d_yield, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_cls, 4 * sizeof(uint32_t));
+    alloc((void **)&c->d_shape_key, (size_t)max_streams * sizeof(uint32_t));
+    alloc((void **)&c->d_rank, (size_t)max_streams * sizeof(uint32_t));
+    alloc((void **)&c->d_sorted_cnt, ((size_t)max_streams + 1) * sizeof(uint32_t));
+    alloc((void **)&c->d_sorted_base, ((size_t)max_streams + 1) * sizeof(uint32_t));
+    alloc((void **)&c->d_lane_seg, ns * sizeof(uint32_t));
     alloc((void **)&c->d_summary, sizeof(DecodeSummary));
     alloc((void **)&c->d_seq_list, (size_t)max_streams * sizeof(uint32_t));
     alloc((void **)&c->d_plan, (ns + 1) * sizeof(uint4));
@@ -242,7 +260,10 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
         c->masks_cap = chunks;
     }
     {
-        const uint64_t need = ((tiles > c->max_segments ? tiles : c->max_segments) + 1023) / 1024 + 2;
+        uint64_t most = tiles > c->max_segments ? tiles : c->max_segments;
+        if (c->max_streams > most)
+            most = c->max_streams;
+        const uint64_t need = (most + 1023) / 1024 + 2;
         if (need > c->scan_tmp_cap) {
             (void)hipFree(c->d_scan_tmp);
             c->d_scan_tmp = nullptr;
@@ -286,12 +307,14 @@ static void exscan(dvda_mlp_hip_ctx *c, hipStream_t st, const uint32_t *in, uint
 
 // one dispatch for the three things an index call starts from: empty stream records, and the
 // per-segment status / row counters at zero
-__global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, uint32_t *seg_rows, uint32_t n_seg)
+__global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, uint32_t *seg_rows, uint32_t *yield_req,
+                               uint32_t n_seg)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_seg) {
         seg_status[i] = 0;
         seg_rows[i] = 0;
+        yield_req[i] = 0;
     }
     if (i < n) {
         StreamRec r;
@@ -332,11 +355,11 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     c->d_n_cand = c->d_tile_base + tiles;
     const uint32_t ms = c->max_segments;
 
-    HIP_TRY(hipMemsetAsync(c->d_cls, 0, 2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(c->d_cls, 0, 4 * sizeof(uint32_t), st));
     {
         const uint32_t n_init = n_streams > ms ? n_streams : ms;
         hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
-                           n_streams, c->d_seg_status, c->d_seg_rows, ms);
+                           n_streams, c->d_seg_status, c->d_seg_rows, c->d_yield, ms);
     }
     hipLaunchKernelGGL(k_sync_mask, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, d_bytes,
                        total_bytes, c->d_masks, c->d_tile_count);
@@ -350,7 +373,13 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
                        c->d_n_cand, ms, c->d_seg, c->d_seg_frames, c->d_streams);
     exscan(c, st, c->d_seg_frames, c->d_seg_fbase, 0u, c->d_n_cand, ms);
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
-                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams, n_streams);
+                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams, n_streams, c->d_shape_key, c->d_cls + 2);
+    // lane packing by stream shape (identity, and next to free, when the batch has one shape)
+    hipLaunchKernelGGL(k_stream_rank, dim3((n_streams + 255) / 256), dim3(256), 0, st, c->d_shape_key, c->d_streams,
+                       n_streams, c->d_rank, c->d_sorted_cnt, c->d_cls + 2);
+    exscan(c, st, c->d_sorted_cnt, c->d_sorted_base, n_streams, nullptr, n_streams);
+    hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, st, c->d_seg, c->d_streams, c->d_n_cand, ms,
+                       c->d_rank, c->d_sorted_base, c->d_cls + 2, c->d_lane_seg);
     HIP_TRY(hipGetLastError());
     c->indexed = true;
     return DVDA_HIP_OK;
@@ -411,7 +440,10 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.summary = c->d_summary;
     a.interleaved = c->pcm_layout == DVDA_PCM_INTERLEAVED;
     a.cls = c->d_cls;
+    a.hetero = c->d_cls + 2;
+    a.lane_seg = c->d_lane_seg;
     a.seg_meta = c->d_seg_meta;
+    a.yield_req = c->d_yield;
     HIP_TRY(hipMemsetAsync(c->d_summary, 0, sizeof(DecodeSummary), st));
     // which kernels: one lane per segment for the streams with one substream, the two-wave layout for those
     // with two -- both unless the caller forced one; a kernel whose class is absent from the batch (the

@@ -24,7 +24,7 @@ struct SegRec {
     uint32_t sync;      // packed major sync: g0bps | g1bps<<4 | g0rate<<8 | g1rate<<12 | assignment<<16 | substreams<<24
     uint32_t ndrop;     // access units among nframes that carry a major sync with OTHER stream parameters: the
                         // reference drops such a frame and decodes on (src/mlp.c:449-460); they yield no PCM
-    uint32_t pad;
+    uint32_t prev;      // previous live segment of the same stream (0xFFFFFFFF: none), filled by k_link
 };
 constexpr uint32_t SYNC_PARAMS = 0x00FFFFFFu;   // the five stream parameters of a packed sync (dvda_params_equal)
 constexpr uint32_t MAX_DROP = 4;                // mismatching major syncs one segment walks through
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     r.nframes = 0;
     r.sync = 0;
     r.ndrop = 0;
-    r.pad = 0;
+    r.prev = 0xFFFFFFFFu;
     uint64_t p = off;
     if (off >= s_end || ((off - s_begin) & 1) || !sync_frame_at(bytes, off, s_end)) {
         // candidate in inter-stream padding, at an odd stream offset, or cut by
@@ -432,6 +432,13 @@ __global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ 
     }
 }
 
+// a stream's shape for the lane packing: PCM frames of its first segment, then sample rate and assignment
+__device__ __forceinline__ uint32_t stream_shape_key(const SegRec &r)
+{
+    const uint32_t rows = (r.nframes - r.ndrop) * rows_per_au((r.sync >> 8) & 0xFu);
+    return ((rows > 0xFFFFu ? 0xFFFFu : rows) << 16) | (((r.sync >> 8) & 0xFu) << 8) | ((r.sync >> 16) & 0x1Fu);
+}
+
 // Pass 4 (after the exclusive scan of seg_frames): per-stream totals and the
 // landing check.  One lane per segment.
 __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ stream_off,
@@ -439,7 +446,8 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
                                               const uint32_t *__restrict__ n_cand_ptr,
                                               uint32_t max_cand, SegRec *__restrict__ seg,
                                               const uint32_t *__restrict__ seg_fbase,
-                                              StreamRec *__restrict__ streams, uint32_t n_streams)
+                                              StreamRec *__restrict__ streams, uint32_t n_streams,
+                                              uint32_t *__restrict__ shape_key, uint32_t *__restrict__ hetero)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_cand = *n_cand_ptr;
@@ -464,7 +472,31 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
     while (j < n_cand && seg[j].stream == s && (seg[j].flags & SEG_DEAD))
         j++;
     const bool last = (j == n_cand) || (seg[j].stream != s);
+    {
+        uint32_t p = i;                           // previous live candidate of the stream
+        uint32_t prev = 0xFFFFFFFFu;
+        while (p > streams[s].first_seg) {
+            p--;
+            if (!(seg[p].flags & SEG_DEAD)) {
+                prev = p;
+                break;
+            }
+        }
+        seg[i].prev = prev;
+    }
     uint32_t st = r.flags;
+    if (streams[s].first_seg == i) {
+        // the stream's shape for the lane packing (k_stream_rank): PCM frames of its first segment, then
+        // sample rate and channel assignment -- segments of one stream are alike, streams differ
+        shape_key[s] = stream_shape_key(r);
+        // does the batch mix shapes at all?  (compared with the first stream that has a segment at all --
+        // its record is final since k_chase; a batch of one shape skips the ranking altogether)
+        uint32_t t = 0;
+        while (t < n_streams && streams[t].first_seg == 0xFFFFFFFFu)
+            t++;
+        if (t < n_streams && stream_shape_key(seg[streams[t].first_seg]) != shape_key[s])
+            *hetero = 1u;
+    }
     if (streams[s].first_seg == i && r.off != s_begin)
         st |= 1u << 0; // DVDA_ST_NO_SYNC: data before the first major sync
     if (!last && seg[j].off != r.end)
@@ -489,6 +521,68 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
         streams[s].frames = seg_fbase[j] - seg_fbase[streams[s].first_seg];
         (void)s_end;
     }
+}
+
+// ---- lane packing for heterogeneous batches.  A wave advances its 64 segments in lockstep: segments of
+// different lengths leave lanes idle, segments of different shapes make every header parse a divergent one.
+// Streams are therefore dealt to the lanes in order of their shape key (longest segments first, then by
+// rate / assignment; equal keys keep their order, so a batch of one shape keeps the identity and pays one
+// flag test).  Sorting streams, not segments: a stream's segments are alike and stay neighbours.
+//   k_link        : shape_key[s]; *hetero = 1 when a stream's key differs from the first stream's
+//   k_stream_rank : rank[s] by counting (n_streams^2 comparisons of 32-bit keys, tiled through LDS),
+//                   sorted_cnt[rank] = segments of the stream
+//   (exclusive scan of sorted_cnt -> sorted_base)
+//   k_lane_perm   : lane_seg[sorted_base[rank[stream]] + (segment - first segment of the stream)] = segment
+__global__ __launch_bounds__(256) void k_stream_rank(const uint32_t *__restrict__ shape_key,
+                                                     const StreamRec *__restrict__ streams, uint32_t n_streams,
+                                                     uint32_t *__restrict__ rank, uint32_t *__restrict__ sorted_cnt,
+                                                     const uint32_t *__restrict__ hetero)
+{
+    __shared__ uint32_t s_key[1024];
+    if (*hetero == 0)
+        return;                                   // one shape (k_link looked): lanes keep the index order
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = s < n_streams;
+    // streams without a segment sort last (key 0) and take no lanes
+    const uint32_t mine = live && streams[s].first_seg != 0xFFFFFFFFu ? shape_key[s] : 0u;
+    uint32_t before = 0;
+    for (uint32_t t0 = 0; t0 < n_streams; t0 += 1024) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+            const uint32_t t = t0 + i;
+            s_key[i] = t < n_streams && streams[t].first_seg != 0xFFFFFFFFu ? shape_key[t] : 0u;
+        }
+        __syncthreads();
+        const uint32_t lim = n_streams - t0 < 1024u ? n_streams - t0 : 1024u;
+        for (uint32_t i = 0; i < lim; i++) {
+            const uint32_t k = s_key[i];
+            before += (k > mine || (k == mine && t0 + i < s)) ? 1u : 0u;
+        }
+    }
+    if (!live)
+        return;
+    rank[s] = before;
+    sorted_cnt[before] = streams[s].first_seg != 0xFFFFFFFFu ? streams[s].n_seg : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_lane_perm(const SegRec *__restrict__ seg, const StreamRec *__restrict__ streams,
+                                                   const uint32_t *__restrict__ n_cand_ptr, uint32_t max_cand,
+                                                   const uint32_t *__restrict__ rank, const uint32_t *__restrict__ sorted_base,
+                                                   const uint32_t *__restrict__ hetero, uint32_t *__restrict__ lane_seg)
+{
+    if (*hetero == 0)
+        return;                                   // one shape: lane = segment
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = *n_cand_ptr;
+    if (n_cand > max_cand)
+        n_cand = max_cand;
+    if (i >= n_cand)
+        return;
+    const uint32_t s = seg[i].stream;
+    const uint32_t first = streams[s].first_seg;
+    if (first == 0xFFFFFFFFu || i < first || i - first >= streams[s].n_seg)
+        return;                                   // (cannot happen: every candidate lies in its stream's run)
+    lane_seg[sorted_base[rank[s]] + (i - first)] = i;
 }
 
 } // namespace mlp

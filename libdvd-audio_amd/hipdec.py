@@ -13,12 +13,12 @@ from . import _build
 ST = dict(NO_SYNC=1 << 0, SYNC_CHANGE=1 << 1, PARITY=1 << 2, CRC=1 << 3, EOF=1 << 4, RESTART=1 << 5,
           PARAMS=1 << 6, HUFFMAN=1 << 7, FILTER=1 << 8, ENVELOPE=1 << 9, IRREGULAR=1 << 16,
           TIMING=1 << 17, MIDFRAME=1 << 18, CHAINED=1 << 19, OVERFLOW=1 << 20, TRUNCATED=1 << 21,
-          CAPACITY=1 << 22, GENERAL=1 << 23, FALSE_SYNC=1 << 24, SEQ=1 << 25, COLD=1 << 26)
+          CAPACITY=1 << 22, GENERAL=1 << 23, FALSE_SYNC=1 << 24, SEQ=1 << 25, COLD=1 << 26, YIELD=1 << 27)
 # bits that do not invalidate the decoded PCM: the conditions the fast pass defers are informational
 # once the passes behind it have decoded them (any failure there sets an error bit); a dropped
 # access unit (later major sync with other stream parameters) is what the reference does too
 ST_BENIGN = (ST["TRUNCATED"] | ST["CHAINED"] | ST["MIDFRAME"] | ST["TIMING"] | ST["GENERAL"] | ST["SEQ"] |
-             ST["SYNC_CHANGE"] | ST["COLD"])
+             ST["SYNC_CHANGE"] | ST["COLD"] | ST["YIELD"])
 
 
 class StreamInfo(ctypes.Structure):
