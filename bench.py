@@ -180,7 +180,8 @@ class Batch:
                  n_segments):
         hip = pkg.hipdec
         self.hip, self.torch, self.dev = hip, torch, dev
-        self.layout = hip.PCM_INTERLEAVED if layout == "interleaved" else hip.PCM_PLANAR
+        self.layout = {"interleaved": hip.PCM_INTERLEAVED, "planar": hip.PCM_PLANAR, "wav24": hip.PCM_WAV24}[layout]
+        self.out_bytes = 3 if layout == "wav24" else 4          # per sample
         unique_bytes = int(len(flat) - 64)
         R = max(1, replicas)
         self.unique, self.R = len(sizes), R
@@ -198,13 +199,16 @@ class Batch:
         self.comp_bytes = int(self.all_len.sum())
         self.rows_total = int(self.all_frames.sum())
         self.samples = int((self.all_frames * self.all_nch).sum())
+        # (offsets in int32 units; a packed WAV payload takes 3/4 of them, every stream starts on 16 bytes)
+        words = (self.all_frames * self.all_nch * self.out_bytes + 15) // 16 * 4
         self.out_off = np.zeros(self.n_streams, np.int64)
-        self.out_off[1:] = np.cumsum(self.all_frames[:-1] * self.all_nch[:-1])
+        self.out_off[1:] = np.cumsum(words[:-1])
+        self.pcm_words = int(words.sum())
         self.d_off = torch.from_numpy(self.all_off).to(dev)
         self.d_len = torch.from_numpy(self.all_len).to(dev)
         self.d_out_off = torch.from_numpy(self.out_off).to(dev)
         self.d_stride = torch.from_numpy(self.all_frames).to(dev)
-        self.d_pcm = torch.empty(max(self.samples, 1), dtype=torch.int32, device=dev)
+        self.d_pcm = torch.empty(max(self.pcm_words, 1), dtype=torch.int32, device=dev)
         self.n_segments = n_segments
         self.ctx = hip.Context(local_rank, self.n_streams, n_segments, lanes_per_segment=lanes, layout=self.layout)
         self.stream = torch.cuda.current_stream(dev).cuda_stream
@@ -256,8 +260,13 @@ class Batch:
             b = flat[int(offs[u]):int(offs[u] + sizes[u])]
             want, r, st = ora.decode(b, int(self.all_nch[i]), int(self.all_frames[i]))
             o, n = int(self.out_off[i]), int(self.all_frames[i] * self.all_nch[i])
-            host = self.d_pcm[o:o + n].cpu().numpy()
             f, c = int(self.all_frames[i]), int(self.all_nch[i])
+            if self.layout == self.hip.PCM_WAV24:
+                host = self.d_pcm[o:o + (n * 3 + 3) // 4].cpu().numpy().view(np.uint8)[:n * 3]
+                if st != 0 or r != f or host.tobytes() != ora.wav_pack(want, 24):
+                    return False
+                continue
+            host = self.d_pcm[o:o + n].cpu().numpy()
             got = host.reshape(f, c).T if self.layout == self.hip.PCM_INTERLEAVED else host.reshape(c, f)
             if st != 0 or r != f or not np.array_equal(got, want):
                 return False
@@ -265,7 +274,7 @@ class Batch:
 
     def replicas_equal(self):
         """the R device-side copies of the unique set decode to the same PCM (compared on the device)"""
-        per = self.samples // self.R
+        per = self.pcm_words // self.R
         first = self.d_pcm[:per]
         return all(bool(self.torch.equal(first, self.d_pcm[r * per:(r + 1) * per])) for r in range(1, self.R))
 
@@ -339,7 +348,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         rec = {"value": round(b.samples * steps / dt / 1e6, 1), "unit": "Msamples/s",
                "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(kms, 4), "titles": b.n_streams,
                "samples_per_step": b.samples, "compressed_bytes": b.comp_bytes,
-               "algorithmic_bytes_per_launch": b.comp_bytes + 4 * b.samples,
+               "algorithmic_bytes_per_launch": b.comp_bytes + b.out_bytes * b.samples,
                "bit_exact_sample": ok}
         if note:
             rec["note"] = note
@@ -355,6 +364,10 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     nseg = args.streams * args.replicas * ((args.aus + cfg.restart_interval - 1) // cfg.restart_interval)
     run("planar_layout", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, "planar", 0,
         note="same titles as the headline, PCM written planar [channel][frame] (reference decode_packet order)")
+    # ---- the output stage fused into the decode: interleaved packed 24-bit WAV payload, 3 B per sample out
+    run("wav24_output", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, "wav24", 0,
+        note="same titles, d_pcm receives the little-endian 24-bit WAV payload dvda2wav writes (write_signed): "
+             "algorithmic bytes = compressed in + 3 B per sample out")
     # ---- batch-size sweep on the headline layout (non-multiples of the 2 048 resident waves included)
     sweep = []
     for n in (64, 512, 1000, 1536, 2500, 4096):
@@ -660,7 +673,7 @@ def main():
         n_threads, logical_cpus, cpu_quota = usable_cpus()
         cpu, ref_pcm = cpu_legs(flat, offs, sizes, frames.astype(np.int64), assignment, rate_code, nch,
                                 args.cpu_seconds, n_threads)
-        per = b.samples // b.R
+        per = b.pcm_words // b.R
         host = b.d_pcm[:per].cpu().numpy()
         bit_exact = True
         for i in range(len(sizes)):

@@ -147,6 +147,14 @@ int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d
  * counts: a few per cent slower than planar -- DESIGN.md section 4). */
 #define DVDA_PCM_PLANAR      0u
 #define DVDA_PCM_INTERLEAVED 1u
+/* The output stage fused into the decode: d_pcm receives the interleaved little-endian
+ * WAV payload dvda2wav writes -- frame-major like DVDA_PCM_INTERLEAVED, every value as write_signed(24) /
+ * write_signed(16) (reference utils/dvda2wav.c:326-334, src/bitstream.c:2846-2857: low bits - 1 bits plus a
+ * sign bit taken from v < 0).  Stream i's payload starts at byte 4 * d_out_off[i] of d_pcm (d_out_off stays in
+ * int32 units, so every stream starts dword-aligned) and holds pcm_frames * channels * (3 | 2) bytes;
+ * d_out_stride[i] stays the capacity in PCM frames.  Same bytes as dvda_mlp_hip_pack_wav() of the int32 PCM. */
+#define DVDA_PCM_WAV24       2u
+#define DVDA_PCM_WAV16       3u
 int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *ctx, uint32_t layout);
 
 /* Blocks until the work enqueued on `stream` is done and copies the per-stream

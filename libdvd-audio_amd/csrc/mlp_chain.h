@@ -48,6 +48,7 @@ struct ChainArgs {
     const uint64_t *out_off;
     const uint64_t *out_stride;
     uint32_t interleaved;
+    uint32_t wav_bits;             // 0, or 16 / 24: packed WAV payload instead of int32 values
 };
 
 __device__ __forceinline__ uint32_t chain_n_seg(const ChainArgs &a)
@@ -490,57 +491,95 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     const uint32_t row = blockIdx.y * 256u + threadIdx.x;
     const uint64_t row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
     const uint64_t out_stride = a.out_stride[r.stream];
+    if (blockIdx.y * 256u >= R)
+        return;                                     // (the grid is sized for the longest segment)
     if (row == 0) {
         a.seg_rows[seg] = R;
         if (row0 + R > out_stride)
             atomicOr(&a.seg_status[seg], ST_OVERFLOW);          // rows = the size needed
     }
-    if (row >= R)
-        return;
-    const uint4 pl = a.plan[seg];
-    const int32_t *P = a.res + (size_t)pl.x * 8u + res_index(row, 0);
-    int32_t ch[MAXCH];
-#pragma unroll
-    for (int c = 0; c < 6; c++)
-        ch[c] = P[c * 4];
-    ch[6] = ch[7] = 0;
-    const uint32_t bypass_bits = (uint32_t)P[6 * 4];
-    const uint32_t seed = (uint32_t)P[7 * 4];
-    const uint32_t *F = a.frec + ((size_t)(pl.x / 40u) + row / rpa) * FREC_WORDS;
-    const uint32_t w0 = F[0];
-    const uint32_t noise_shift = w0 & 0xFFu, matrix_len = (w0 >> 8) & 0xFFu, mmc = w0 >> 16;
-    const uint32_t outch_pack = F[1], qss_pack = F[2], oshift_pack = F[3];
-    const uint32_t shifted = (seed >> 7) & 0xFFFFu;
-    const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
-    const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
-    for (uint32_t m = 0; m < matrix_len; m++) {
-        const uint32_t *M = F + 4 + m * 5;
-        const uint32_t nz = M[4];
-        int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            const uint32_t w = M[c >> 1];
-            acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(w) : lo16(w));
-        }
-        const uint32_t oc = nib(outch_pack, m);
-        const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) + ((bypass_bits >> m) & 1u));
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-            ch[c] = (uint32_t)c == oc ? nv : ch[c];
-    }
-    if (oshift_pack) {
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-            if ((uint32_t)c <= mmc)
-                ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
-    }
-    const uint64_t orow = row0 + row;
-    if (orow >= out_stride)
-        return;
     const uint32_t assignment = (sr.sync >> 16) & 0x1F;
     const uint32_t nch_out = channel_count(assignment);
     const uint32_t wavepk = wave_pack(assignment);
+    // packed WAV payload (a.wav_bits): the block's rows are assembled as bytes in LDS and leave as consecutive
+    // dwords -- a row is 18 (24-bit, 6-ch) bytes, not a whole number of dwords; a block starts dword-aligned
+    // (256 rows, and a segment's first row is a multiple of 40)
+    __shared__ uint8_t s_b[256 * 6 * 3];
+    const uint4 pl = a.plan[seg];
+    int32_t ch[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++)
+        ch[c] = 0;
+    if (row < R) {
+        const int32_t *P = a.res + (size_t)pl.x * 8u + res_index(row, 0);
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            ch[c] = P[c * 4];
+        const uint32_t bypass_bits = (uint32_t)P[6 * 4];
+        const uint32_t seed = (uint32_t)P[7 * 4];
+        const uint32_t *F = a.frec + ((size_t)(pl.x / 40u) + row / rpa) * FREC_WORDS;
+        const uint32_t w0 = F[0];
+        const uint32_t noise_shift = w0 & 0xFFu, matrix_len = (w0 >> 8) & 0xFFu, mmc = w0 >> 16;
+        const uint32_t outch_pack = F[1], qss_pack = F[2], oshift_pack = F[3];
+        const uint32_t shifted = (seed >> 7) & 0xFFFFu;
+        const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
+        const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
+        for (uint32_t m = 0; m < matrix_len; m++) {
+            const uint32_t *M = F + 4 + m * 5;
+            const uint32_t nz = M[4];
+            int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const uint32_t w = M[c >> 1];
+                acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(w) : lo16(w));
+            }
+            const uint32_t oc = nib(outch_pack, m);
+            const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) + ((bypass_bits >> m) & 1u));
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                ch[c] = (uint32_t)c == oc ? nv : ch[c];
+        }
+        if (oshift_pack) {
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                if ((uint32_t)c <= mmc)
+                    ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
+        }
+    }
+    const uint64_t orow = row0 + row;
     int32_t *out = a.pcm + a.out_off[r.stream];
+    if (a.wav_bits) {
+        const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
+        const uint64_t blk_row0 = row0 + (uint64_t)blockIdx.y * 256u;            // first output row of the block
+        uint32_t nvalid = R - blockIdx.y * 256u < 256u ? R - blockIdx.y * 256u : 256u;
+        if (blk_row0 >= out_stride)
+            nvalid = 0;
+        else if (blk_row0 + nvalid > out_stride)
+            nvalid = (uint32_t)(out_stride - blk_row0);
+        if (threadIdx.x < nvalid) {
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                if ((uint32_t)c < nch_out) {
+                    const uint32_t u = wav_signed(ch[c], a.wav_bits);
+                    uint8_t *e = s_b + threadIdx.x * spf + nib(wavepk, c) * nb;
+                    e[0] = (uint8_t)u;
+                    e[1] = (uint8_t)(u >> 8);
+                    if (nb == 3u)
+                        e[2] = (uint8_t)(u >> 16);
+                }
+        }
+        __syncthreads();
+        const uint32_t nbytes = nvalid * spf;
+        uint8_t *ob = reinterpret_cast<uint8_t *>(out) + blk_row0 * spf;
+        const uint32_t *sd = reinterpret_cast<const uint32_t *>(s_b);
+        for (uint32_t d = threadIdx.x; d < (nbytes >> 2); d += 256u)
+            reinterpret_cast<uint32_t *>(ob)[d] = sd[d];
+        for (uint32_t b = (nbytes & ~3u) + threadIdx.x; b < nbytes; b += 256u)
+            ob[b] = s_b[b];
+        return;
+    }
+    if (row >= R || orow >= out_stride)
+        return;
 #pragma unroll
     for (int c = 0; c < 6; c++)
         if ((uint32_t)c < nch_out)

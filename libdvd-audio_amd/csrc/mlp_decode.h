@@ -143,6 +143,14 @@ typedef int dvda_v4i __attribute__((ext_vector_type(4)));
     } while (0)
 #endif
 
+// (8-byte store at a constant byte offset: the tail of a 72-byte run of packed 24-bit samples)
+typedef int dvda_v2i __attribute__((ext_vector_type(2)));
+#define DVDA_STORE_V2_AT(dst, off_, a_, b_)                                                         \
+    do {                                                                                            \
+        dvda_v2i v2_ = {(int)(a_), (int)(b_)};                                                      \
+        asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(dst), "v"(v2_), "n"(off_) : "memory"); \
+    } while (0)
+
 // status bits (mirror include/dvda_mlp_hip.h)
 constexpr uint32_t ST_PARITY = 1u << 2, ST_CRC = 1u << 3, ST_EOF = 1u << 4, ST_RESTART = 1u << 5,
                    ST_PARAMS = 1u << 6, ST_HUFFMAN = 1u << 7, ST_FILTER = 1u << 8,
@@ -181,6 +189,29 @@ constexpr int BREC_IIR_WORDS = 12; // ... + when the block (re)sets the slot's I
 // uses 1 % of that.  A segment that changes parameters more densely still is decoded by the sequential pass
 // instead (ST_SEQ)
 __host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return 4u * rows + 64u; }
+// write_signed(bits, v) of the reference's little-endian writer (src/bitstream.c:2846-2857): the low bits - 1
+// bits of v, then a sign bit taken from v < 0 -- NOT plain truncation for values outside the nominal width
+__device__ __forceinline__ uint32_t wav_signed(int32_t v, uint32_t bits)
+{
+    const uint32_t sign = 1u << (bits - 1u);
+    return ((uint32_t)v & (sign - 1u)) | (v < 0 ? sign : 0u);
+}
+// four consecutive 24-bit samples -> three dwords; four 16-bit samples -> two dwords (little-endian payload),
+// by byte selection (v_perm_b32: selector bytes 0..3 take from the second operand, 4..7 from the first)
+__device__ __forceinline__ void wav_pack4(const int32_t (&o)[4], uint32_t bits, uint32_t (&d)[3])
+{
+    const uint32_t s0 = wav_signed(o[0], bits), s1 = wav_signed(o[1], bits), s2 = wav_signed(o[2], bits),
+                   s3 = wav_signed(o[3], bits);
+    if (bits == 24u) {
+        d[0] = __builtin_amdgcn_perm(s1, s0, 0x04020100u);
+        d[1] = __builtin_amdgcn_perm(s2, s1, 0x05040201u);
+        d[2] = __builtin_amdgcn_perm(s3, s2, 0x06050402u);
+    } else {
+        d[0] = __builtin_amdgcn_perm(s1, s0, 0x05040100u);
+        d[1] = __builtin_amdgcn_perm(s3, s2, 0x05040100u);
+        d[2] = 0;
+    }
+}
 // element (row, plane) of a segment's planes: four rows of all eight planes share a 128-byte line
 __host__ __device__ inline size_t res_index(uint32_t row, uint32_t plane)
 {
@@ -213,6 +244,7 @@ struct DecodeArgs {
     const int32_t *init_fir;       // optional: FIR history a stream starts with, [stream][2][48] (streaming tier)
     DecodeSummary *summary;        // what the fast pass leaves to the passes behind it (read by the host)
     uint32_t interleaved;          // PCM layout: 0 planar, 1 frame-major (see k_decode)
+    uint32_t wav_bits;             // 0: int32 values; 16 / 24: frame-major packed little-endian WAV payload (write_signed)
     const uint32_t *hetero;        // != 0: the batch mixes stream shapes and lane_seg[] deals the segments to the
     const uint32_t *lane_seg;      //       fast pass's lanes by shape (k_stream_rank / k_lane_perm, mlp_index.h)
     const uint32_t *cls;           // [2]: the batch holds streams with one / two substreams (set by the index)
@@ -1773,11 +1805,27 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             if (orow >= out_stride) {
                                 status |= ST_OVERFLOW;      // keep counting: rows = size needed
                             } else {
+                                if (a.wav_bits) {
+                                    // packed WAV payload, byte by byte (this is the slow path anyway)
+                                    const uint32_t nb = a.wav_bits >> 3;
+                                    uint8_t *wb = reinterpret_cast<uint8_t *>(a.pcm + out_base) + orow * nch_out * nb;
+                                    for (uint32_t c = 0; c < nch_out && c < 6u; c++) {
+                                        int32_t v = 0;
+#pragma unroll
+                                        for (int cc = 0; cc < 6; cc++)
+                                            if ((uint32_t)cc == c)
+                                                v = ch[cc];
+                                        const uint32_t u = wav_signed(v, a.wav_bits);
+                                        for (uint32_t b = 0; b < nb; b++)
+                                            wb[nib(wavepk, c) * nb + b] = (uint8_t)(u >> (8 * b));
+                                    }
+                                } else {
 #pragma unroll
                                 for (int c = 0; c < 6; c++)
                                     if ((uint32_t)c < nch_out)
                                         a.pcm[out_base + (a.interleaved ? orow * nch_out + nib(wavepk, c)
                                                                         : (uint64_t)nib(wavepk, c) * out_stride + orow)] = ch[c];
+                                }
                             }
                             rows_written++;
                         }
@@ -1887,7 +1935,50 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
             const int32_t *Tl = &s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
-            if (__builtin_expect(ilv_direct, 1)) {
+            if (__builtin_expect(a.wav_bits != 0, 0)) {
+                // ---- the WAV payload itself (SURVEY 8(f-3) fused into the decode): the OUT_ROWS frames are
+                //      OUT_ROWS * channels consecutive samples = `channels` groups of four; a group packs into
+                //      three dwords (24-bit) or two (16-bit); the lane's run is 12 (8) * channels contiguous bytes
+                const uint32_t nb = a.wav_bits >> 3;
+                uint32_t *wd = reinterpret_cast<uint32_t *>(a.pcm + out_base) + (flush_row * nch_out * nb >> 2);
+                if (ilv_direct && a.wav_bits == 24u) {
+                    // six channels in identity order, 24-bit: 24 samples front to back -> 18 dwords = 72 bytes
+                    uint32_t d[18];
+#pragma unroll
+                    for (int g = 0; g < 6; g++) {
+                        const int32_t o[4] = {Tl[(4 * g) * 64], Tl[(4 * g + 1) * 64], Tl[(4 * g + 2) * 64], Tl[(4 * g + 3) * 64]};
+                        uint32_t t[3];
+                        wav_pack4(o, 24u, t);
+                        d[3 * g] = t[0];
+                        d[3 * g + 1] = t[1];
+                        d[3 * g + 2] = t[2];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++)
+                        DVDA_STORE_V4_AT(wd, 16 * v, (int)d[4 * v], (int)d[4 * v + 1], (int)d[4 * v + 2], (int)d[4 * v + 3]);
+                    DVDA_STORE_V2_AT(wd, 64, d[16], d[17]);
+                } else {
+                    uint32_t fi = 0, fw = 0;
+                    for (uint32_t v = 0; v < nch_out; v++) {
+                        int32_t o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            o[j] = ilv_direct ? Tl[(4 * v + j) * 64] : Tl[(nib(wave_inv, fw) * OUT_ROWS + fi) * 64];
+                            fw++;
+                            if (fw == nch_out) {
+                                fw = 0;
+                                fi++;
+                            }
+                        }
+                        uint32_t d[3];
+                        wav_pack4(o, a.wav_bits, d);
+                        wd[nb * v] = d[0];
+                        wd[nb * v + 1] = d[1];
+                        if (nb == 3u)
+                            wd[nb * v + 2] = d[2];
+                    }
+                }
+            } else if (__builtin_expect(ilv_direct, 1)) {
                 // the tile already is in output order: 24 consecutive planes, two per LDS read
 #pragma unroll
                 for (int v = 0; v < (OUT_ROWS * 6) / 4; v++)

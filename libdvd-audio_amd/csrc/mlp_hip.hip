@@ -438,7 +438,8 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.fir_ws = c->d_fir;
     a.init_fir = c->d_init_fir;
     a.summary = c->d_summary;
-    a.interleaved = c->pcm_layout == DVDA_PCM_INTERLEAVED;
+    a.interleaved = c->pcm_layout != DVDA_PCM_PLANAR;
+    a.wav_bits = c->pcm_layout == DVDA_PCM_WAV24 ? 24u : c->pcm_layout == DVDA_PCM_WAV16 ? 16u : 0u;
     a.cls = c->d_cls;
     a.hetero = c->d_cls + 2;
     a.lane_seg = c->d_lane_seg;
@@ -517,6 +518,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         ca.out_off = d_out_off;
         ca.out_stride = d_out_stride;
         ca.interleaved = a.interleaved;
+        ca.wav_bits = a.wav_bits;
         const unsigned sblocks = (unsigned)((ms + 1023) / 1024);
         hipLaunchKernelGGL(k_chain_plan, dim3((unsigned)((ms + 255) / 256)), dim3(256), 0, st, ca);
         hipLaunchKernelGGL(k_scan4_blocks, dim3(sblocks), dim3(1024), 0, st, c->d_plan, c->d_scan4_tmp, c->d_n_cand,
@@ -588,7 +590,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
 
 extern "C" int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *c, uint32_t layout)
 {
-    if (!c || (layout != DVDA_PCM_PLANAR && layout != DVDA_PCM_INTERLEAVED))
+    if (!c || layout > DVDA_PCM_WAV16)
         return DVDA_HIP_EINVAL;
     c->pcm_layout = layout;
     return DVDA_HIP_OK;

@@ -103,7 +103,7 @@ def _check(rc, what):
         raise HipError("%s failed: %s (%d)" % (what, names.get(rc, "?"), rc))
 
 
-PCM_PLANAR, PCM_INTERLEAVED = 0, 1      # DVDA_PCM_* of include/dvda_mlp_hip.h
+PCM_PLANAR, PCM_INTERLEAVED, PCM_WAV24, PCM_WAV16 = 0, 1, 2, 3      # DVDA_PCM_* of include/dvda_mlp_hip.h
 
 
 class Context:
@@ -247,6 +247,49 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, la
                 a = host[out_off[i]:out_off[i] + r * c].reshape(c, r)
             pcm.append(np.ascontiguousarray(a[:, :int(inf.pcm_frames)]))
         return pcm, list(infos)
+    finally:
+        ctx.close()
+
+
+def decode_streams_wav(streams, bits, device=0, lanes_per_segment=0):
+    """Decodes complete MLP byte streams straight into the interleaved little-endian WAV payload dvda2wav
+    writes (DVDA_PCM_WAV24 / DVDA_PCM_WAV16: the output stage fused into the decode kernels).
+    -> (list of uint8 arrays, infos)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise HipError("no GPU visible to torch: the MLP decode path is HIP-only")
+    assert bits in (16, 24)
+    nb = bits // 8
+    dev = torch.device("cuda", device)
+    flat, offs, lens = pack_streams(streams)
+    total = int(len(flat) - 64)
+    ctx = Context(device, len(streams), max(64, total // 64), lanes_per_segment, PCM_WAV24 if bits == 24 else PCM_WAV16)
+    try:
+        d_bytes = torch.from_numpy(flat).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), len(streams), st)
+        infos = ctx.stream_info(stream=st)
+        rows = [int(inf.mlp_frames) * ROWS_PER_AU.get(int(inf.group0_rate), 0) for inf in infos]
+        for attempt in range(2):
+            out_off, pos = [], 0
+            for r, inf in zip(rows, infos):
+                out_off.append(pos)
+                pos += (r * int(inf.channels) * nb + 3) // 4 + 4          # int32 units, dword-aligned starts
+            d_pcm = torch.zeros(max(pos, 1), dtype=torch.int32, device=dev)
+            d_out_off = torch.tensor(out_off, dtype=torch.int64, device=dev)
+            d_stride = torch.tensor(rows, dtype=torch.int64, device=dev)
+            if attempt:
+                ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), len(streams), st)
+            ctx.decode(d_pcm.data_ptr(), d_out_off.data_ptr(), d_stride.data_ptr(), st)
+            infos = ctx.stream_info(stream=st)
+            if not any(inf.status & ST["OVERFLOW"] for inf in infos):
+                break
+            rows = [max(r, int(inf.pcm_frames)) for r, inf in zip(rows, infos)]
+        host = d_pcm.cpu().numpy().view(np.uint8)
+        out = [host[4 * o:4 * o + int(inf.pcm_frames) * int(inf.channels) * nb].copy() for o, inf in zip(out_off, infos)]
+        return out, list(infos)
     finally:
         ctx.close()
 

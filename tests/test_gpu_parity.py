@@ -461,7 +461,7 @@ def test_pcm_layout_argument_is_checked(pkg):
     try:
         L = hip.lib()
         assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, hip.PCM_INTERLEAVED) == 0
-        assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, 2) == -3
+        assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, hip.PCM_WAV16) == 0 and L.dvda_mlp_hip_set_pcm_layout(ctx._h, 4) == -3
         assert L.dvda_mlp_hip_set_pcm_layout(ctx._h, hip.PCM_PLANAR) == 0
         assert L.dvda_mlp_hip_set_pcm_layout(None, hip.PCM_PLANAR) == -3
     finally:
@@ -645,3 +645,40 @@ def test_too_small_a_context_is_reported_not_truncated(pkg, oracle):
     for b, got, inf in zip(streams, pcm, infos):
         want, r, st = oracle.decode(b, 6, 64 * 80)
         assert inf.status == 0 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("bits", [24, 16])
+def test_wav_payload_straight_out_of_the_decode(pkg, oracle, bits):
+    """DVDA_PCM_WAV24 / DVDA_PCM_WAV16: the output stage (dvda_read's interleave + dvda2wav's
+    write_signed, reference src/dvd-audio.c:781-792, utils/dvda2wav.c:326-334, src/bitstream.c:2846-2857) fused
+    into the decode -- fast pass (6-ch identity order, 2-ch, the 5-ch RIFF permutation 0x12, two substreams),
+    chain passes (chained titles), sequential pass (non-standard timing) -- must equal the oracle's packing of the
+    oracle's PCM byte for byte.  16-bit packing of 24-bit content exercises write_signed outside its range (the
+    sign bit is taken from v < 0, not bit 15)."""
+    syn, hip = pkg.synth, pkg.hipdec
+    SF = syn.SF
+    cfgs = [syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=24),
+            syn.make_cfg(assignment=1, rate_code=0, n_substreams=1, n_aus=40),
+            syn.make_cfg(assignment=0x12, rate_code=2, n_substreams=1, n_aus=12),
+            syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24),
+            syn.make_cfg(assignment=0x14, rate_code=1, n_substreams=2, n_aus=16, profile=1, features=syn.SF_FAST,
+                         restart_interval=3),
+            syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=24, profile=1,
+                         features=SF["CHAINED"] | SF["FIRRAND"], restart_interval=4),
+            syn.make_cfg(assignment=6, rate_code=0, n_substreams=1, n_aus=20, profile=1,
+                         features=SF["VARROWS"] | SF["VARBLOCK"], restart_interval=5),
+            syn.make_cfg(assignment=0, rate_code=1, n_substreams=1, n_aus=9)]
+    streams = [syn.stream(c, 7300 + i) for i, c in enumerate(cfgs)]
+    got, infos = hip.decode_streams_wav([b for b, _ in streams], bits)
+    for (b, f), c, payload, inf in zip(streams, cfgs, got, infos):
+        nch = syn.channels(c.assignment)
+        want, r, st = oracle.decode(b, nch, f)
+        assert st == 0 and r == f
+        assert inf.status & ~hip.ST_BENIGN == 0 and inf.pcm_frames == f, hex(inf.status)
+        ref = np.frombuffer(oracle.wav_pack(want, bits), np.uint8)
+        assert len(payload) == len(ref) == f * nch * bits // 8
+        assert np.array_equal(payload, ref), "assignment %#x: first difference at byte %d" % (
+            c.assignment, int(np.argmax(payload != ref)))
+    # and it is what the separate pack kernel makes of the int32 PCM
+    pcm, _ = hip.decode_streams([streams[0][0]])
+    assert np.array_equal(hip.pack_wav(pcm[0], bits), got[0])

@@ -37,7 +37,7 @@ for i in range(n):
     meta.append((i, asg, S, feats, f))
     if len(batch) == 32 or i == n - 1:
         # batches alternate between the two PCM layouts of the C ABI
-        pcm, infos = hip.decode_streams(batch, lanes_per_segment=2,
+        pcm, infos = hip.decode_streams(batch, lanes_per_segment=[0, 2][(i // 64) & 1],   # the library picks the kernels / forced lane pairs
                                         layout=hip.PCM_INTERLEAVED if (i // 32) & 1 else hip.PCM_PLANAR)
         for b, (idx, asg, S, feats, f), p, inf in zip(batch, meta, pcm, infos):
             want, r, st = oracle.decode(b, syn.channels(asg), f)
