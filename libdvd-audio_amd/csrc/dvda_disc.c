@@ -554,6 +554,10 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         uint32_t bad = 0;
         if (dvda_pcm_hip_result(d_work, got, &total, &bad, NULL) != DVDA_HIP_OK)
             goto fail;
+        /* (`bad` also counts the sectors of a following track of the other codec inside the look-ahead window:
+           they contribute no bytes, which is what is wanted of them.  A sector with more audio packets than
+           the kernels keep is refused by scan and gather alike, csrc/pcm_unswizzle.h.) */
+        (void)bad;
         /* workspace words [got, 2*got]: payload offset of every sector, then the total */
         h_base = malloc(((size_t)got + 1) * sizeof(uint32_t));
         if (!h_base)
@@ -741,6 +745,7 @@ static DVDA_Track_Reader *open_pcm(struct aob_set *aobs, const DVDA_Track *k, co
         uint32_t bad = 0;
         if (dvda_pcm_hip_result(d_work, got, &total, &bad, NULL) != DVDA_HIP_OK)
             goto fail;
+        (void)bad;              /* see open_mlp: foreign sectors inside the window count as bad and contribute nothing */
         h_base = malloc(((size_t)got + 1) * sizeof(uint32_t));
         if (!h_base ||
             hipMemcpy(h_base, d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)

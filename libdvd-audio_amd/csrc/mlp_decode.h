@@ -79,6 +79,20 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 #ifndef DVDA_YIELD_ASK
 #define DVDA_YIELD_ASK 1
 #endif
+// Row-loop experiments of round 2 (tools/ab_build.py + tools/ab_bench.sh):
+//   DVDA_SKIP_SCALAR  the "no lane carries slot k" skip tests a wave-uniform slot count kept in an SGPR
+//                     (refreshed after header parses) instead of a per-row v_cmp + ballot + branch on VCC
+//   DVDA_ADV2_FREE    the rare second window step without its wave-uniform branch (three more selects)
+//   DVDA_FIR_SPLIT    keep the two FIR accumulators apart (the compiler folds them into one 8-deep chain)
+#ifndef DVDA_SKIP_SCALAR
+#define DVDA_SKIP_SCALAR 0
+#endif
+#ifndef DVDA_ADV2_FREE
+#define DVDA_ADV2_FREE 0
+#endif
+#ifndef DVDA_FIR_SPLIT
+#define DVDA_FIR_SPLIT 0
+#endif
 #ifndef DVDA_UNIFORM_SLOTS
 #define DVDA_UNIFORM_SLOTS 0
 #endif
@@ -1476,7 +1490,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
-        if (USLOT && __builtin_expect(__any(hdr_parsed), 0)) {
+        if ((USLOT || DVDA_SKIP_SCALAR) && __builtin_expect(__any(hdr_parsed), 0)) {
             uint32_t sw = 2;
 #pragma unroll
             for (int k = 2; k < NS; k++)
@@ -1564,7 +1578,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
                 const bool in = (USLOT && !WSPEC) ? true : (uint32_t)k < nslots;   // (two-wave layout: whose channel it is)
-                if (k >= 2 && (USLOT ? (uint32_t)k >= slots_w : !__any(in))) {
+                if (k >= 2 && ((USLOT || DVDA_SKIP_SCALAR) ? (uint32_t)k >= slots_w : !__any(in))) {
                     if constexpr (!WSPEC)
                         val[k] = 0;
                     continue;
@@ -1602,7 +1616,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nh) : "v"(rd.hi), "v"(rd.lo), "s"(step));
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nl) : "v"(rd.lo), "v"(rd.nx), "s"(step));
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nn) : "v"(rd.nx), "v"(cand1), "s"(step));
-                if (__builtin_expect(__any(adv == 2), 0)) {
+                if (DVDA_ADV2_FREE || __builtin_expect(__any(adv == 2), 0)) {
                     const bool two = adv == 2;
                     if (two && in)
                         DVDA_COV(8);                 // two-dword window step
@@ -1631,6 +1645,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 acc1 += (int64_t)hi16(cf[k][2]) * (int64_t)st[k][5];
                 acc0 += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
                 acc1 += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
+#if DVDA_FIR_SPLIT
+                asm volatile("" : "+v"(acc0), "+v"(acc1));
+#endif
                 int64_t acc = acc0 + acc1;
                 bool iir_on = false;
                 if (__builtin_expect(wave_iir, 0)) {

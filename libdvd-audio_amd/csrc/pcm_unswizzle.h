@@ -75,6 +75,7 @@ template <typename P, typename F> __device__ __forceinline__ bool walk_sector(co
     if ((p[4] >> 6) != 1 || !(p[4] & 4) || !(p[6] & 4) || !(p[8] & 4) || !(p[9] & 1) || (p[12] & 3) != 3)
         return false;                                  // marker bits, src/packet.c:172-176
     uint32_t pos = 14 + (p[13] & 7);
+    uint32_t n_audio = 0;
     while (pos + 6 <= SECTOR) {
         const uint32_t id = p[pos + 3], plen = ((uint32_t)p[pos + 4] << 8) | p[pos + 5];
         if (p[pos] != 0 || p[pos + 1] != 0 || p[pos + 2] != 1 || pos + 6 + plen > SECTOR)
@@ -90,6 +91,11 @@ template <typename P, typename F> __device__ __forceinline__ bool walk_sector(co
             const uint32_t hdr = 7 + pad1 + pad2;      // the 9-byte parameter block sits inside pad_2
             // PCM: the 9-byte parameter block is part of pad_2; MLP: pad_2 is plain padding
             if (codec != want_codec || (want_codec == 0xA0 && pad2 < 9) || hdr > plen)
+                return false;
+            // the gather kernels keep MAX_PACKETS packets per sector (a disc has one or two): a sector with
+            // more is malformed for every kernel alike -- counted and contributing nothing in the scan, never
+            // offsets for bytes that nobody writes
+            if (++n_audio > (uint32_t)MAX_PACKETS)
                 return false;
             f(pos + 6 + hdr, plen - hdr);
         }

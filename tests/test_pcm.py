@@ -159,3 +159,45 @@ def test_gpu_wav_pack_matches_oracle(pkg, bits, ch, frames):
     n = lib.wav_oracle_pack(s.ctypes.data, frames, ch, frames, bits, want.ctypes.data)
     got = pkg.hipdec.pack_wav(s, bits)
     assert len(got) == n and np.array_equal(got, want[:n])
+
+
+@pytest.mark.gpu
+def test_gpu_sector_with_more_audio_packets_than_the_kernels_keep(pkg):
+    """a crafted sector with more than 8 small audio packets used to be counted in full by the scan
+    kernels while the gather kernels kept 8 -- output offsets for bytes nobody writes.  Such a sector is now
+    malformed for every kernel alike: counted as bad, contributing nothing, the sectors around it unaffected
+    (PCM tier and MLP demux)."""
+    import struct
+    disc = pkg.disc
+
+    def many_packets(codec, n, body, params=b""):
+        pes = b""
+        for _ in range(n):
+            payload = b"\x81\x00" + b"\x00" + bytes([codec, 0, 0, len(params)]) + params + body
+            pes += b"\x00\x00\x01\xBD" + struct.pack(">H", len(payload)) + payload
+        room = 2048 - 14 - len(pes)
+        assert room >= 6
+        tail = b"\x00\x00\x01\xBE" + struct.pack(">H", room - 6) + b"\xFF" * (room - 6)
+        return disc._pack_header() + pes + tail
+
+    # ---- PCM: 2-ch / 16-bit, 9 packets of two chunks (4 frames) each between two regular sectors
+    s = _samples(16, 2, 1000, 9)
+    regular = disc.pcm_track_sectors(s, 0, 1, 1)
+    params = bytes([0, 0, 0, 0x00, 0x11, 0, 1, 0, 0])             # 9-byte block: bps codes 0, rate 1, assignment 1
+    crafted = many_packets(0xA0, 9, b"\x01\x02\x03\x04\x05\x06\x07\x08" * 2, params)
+    ok8 = many_packets(0xA0, 8, b"\x01\x02\x03\x04\x05\x06\x07\x08" * 2, params)
+    data = np.frombuffer(regular[0] + crafted + regular[1], np.uint8).copy()
+    got, bad = pkg.hipdec.pcm_decode_sectors(data, 16, 2)
+    per = len(s) if len(regular) == 1 else None
+    assert bad == 1
+    want_a, _ = pkg.hipdec.pcm_decode_sectors(np.frombuffer(regular[0] + regular[1], np.uint8).copy(), 16, 2)
+    assert np.array_equal(got, want_a)                             # the crafted sector contributes nothing
+    got8, bad8 = pkg.hipdec.pcm_decode_sectors(np.frombuffer(regular[0] + ok8 + regular[1], np.uint8).copy(), 16, 2)
+    assert bad8 == 0 and got8.shape[1] == want_a.shape[1] + 8 * 4  # eight packets are still fine
+    # ---- MLP demux
+    mlp = disc.mlp_track_sectors(np.arange(5000, dtype=np.uint32).astype(np.uint8))
+    crafted_m = many_packets(0xA1, 9, b"\xAA" * 20)
+    sec = np.frombuffer(mlp[0] + crafted_m + mlp[1], np.uint8).copy()
+    out, badm = pkg.hipdec.mlp_demux_sectors(sec)
+    ref, _ = pkg.hipdec.mlp_demux_sectors(np.frombuffer(mlp[0] + mlp[1], np.uint8).copy())
+    assert badm == 1 and np.array_equal(out, ref)
