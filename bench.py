@@ -82,7 +82,7 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes.
     Runs before this process has touched the GPU (device_count() does not initialise it) and starts
     the ranks as children -- a process that has initialised HIP is never re-exec'ed."""
-    plumbing = os.environ.get("DVDA_BENCH_PLUMBING") == "1"
+    plumbing = os.environ.get("DVDA_BENCH_PLUMBING") == "1" or os.environ.get("DVDA_BENCH_ONE_GPU") == "1"
     if not plumbing:
         import torch
         have = torch.cuda.device_count()
@@ -595,13 +595,18 @@ def main():
     backend = os.environ.get("DVDA_BENCH_BACKEND", "nccl")
     if os.environ.get("DVDA_BENCH_ONE_GPU") == "1":
         local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the decode path is HIP-only)")
+    # the rank's GPU first, then the process group bound to it: RCCL otherwise picks the device at the first
+    # collective (every rank on GPU 0)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import libdvd_audio_amd as pkg
     syn, hip = pkg.synth, pkg.hipdec
@@ -632,7 +637,10 @@ def main():
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
