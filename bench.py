@@ -338,6 +338,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     out = {}
 
     def run(name, flat, offs, sizes, frames, nchs, nseg, replicas, layout, lanes, benign=0, note=None):
+        t_run = time.perf_counter()
         b = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, replicas, layout, lanes, nseg)
         dt, kms, launches = b.timed(steps, warmup)
         b.check_status(benign=benign)
@@ -353,6 +354,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         if note:
             rec["note"] = note
         out[name] = rec
+        sys.stderr.write("bench: sub-record %s %.1f s\n" % (name, time.perf_counter() - t_run))
         b.close()
         del b
         torch.cuda.empty_cache()
@@ -457,7 +459,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     return out
 
 
-def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, steps):
+def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, steps, wav24=False):
     """Pinned host bytes -> H2D -> index + decode -> D2H -> pinned host PCM, in sub-batches on three HIP
     streams so that the copies of neighbouring sub-batches overlap the decode ('compressed
     bytes resident in pinned host memory -> PCM resident in host memory').  Never `value`."""
@@ -466,7 +468,8 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
     parts = 8 if n >= 64 else 1
     per = n // parts
     nch = 6
-    layout = hip.PCM_INTERLEAVED if args.layout == "interleaved" else hip.PCM_PLANAR
+    layout = hip.PCM_WAV24 if wav24 else (hip.PCM_INTERLEAVED if args.layout == "interleaved" else hip.PCM_PLANAR)
+    out_bytes = 3 if wav24 else 4
     slots = []
     for p in range(parts):
         lo, hi = p * per, (p + 1) * per if p < parts - 1 else n
@@ -474,9 +477,10 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         b1 = int(offs[hi]) if hi < n else int(len(flat) - 64)
         h_in = torch.from_numpy(flat[b0:b1 + 64].copy()).pin_memory()
         rows = frames[lo:hi].astype(np.int64)
+        words = (rows * nch * out_bytes + 15) // 16 * 4            # int32 units per title, 16-byte aligned
         oo = np.zeros(hi - lo, np.int64)
-        oo[1:] = np.cumsum(rows[:-1] * nch)
-        tot = int((rows * nch).sum())
+        oo[1:] = np.cumsum(words[:-1])
+        tot = int(words.sum())
         slots.append(dict(h_in=h_in, nbytes=b1 - b0, off=(offs[lo:hi].astype(np.int64) - b0), len=sizes[lo:hi].astype(np.int64),
                           rows=rows, oo=oo, tot=tot, h_out=torch.empty(tot, dtype=torch.int32).pin_memory()))
     NB = 3
@@ -497,16 +501,30 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         s["d_rows"] = torch.from_numpy(s["rows"]).to(dev)
     torch.cuda.synchronize(dev)
 
-    def one_pass():
-        for i, s in enumerate(slots):
-            bf = bufs[i % NB]
-            with torch.cuda.stream(bf["st"]):
+    # one host thread per stream: dvda_mlp_hip_decode waits for its fast pass (the summary read-back), and a
+    # single thread would stop enqueueing the neighbouring sub-batches' copies while it waits
+    import threading
+
+    def lane(t):
+        bf = bufs[t]
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(bf["st"]):
+            st = bf["st"].cuda_stream
+            for i in range(t, len(slots), NB):
+                s = slots[i]
                 bf["d_in"][:s["nbytes"] + 64].copy_(s["h_in"], non_blocking=True)
-                st = bf["st"].cuda_stream
                 bf["ctx"].index(bf["d_in"].data_ptr(), s["nbytes"], s["d_off"].data_ptr(), s["d_len"].data_ptr(),
                                 len(s["len"]), st)
                 bf["ctx"].decode(bf["d_pcm"].data_ptr(), s["d_oo"].data_ptr(), s["d_rows"].data_ptr(), st)
                 s["h_out"].copy_(bf["d_pcm"][:s["tot"]], non_blocking=True)
+            bf["st"].synchronize()
+
+    def one_pass():
+        ths = [threading.Thread(target=lane, args=(t,)) for t in range(NB)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
 
     one_pass()
     torch.cuda.synchronize(dev)
@@ -515,7 +533,8 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         one_pass()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    samples = sum(s["tot"] for s in slots)
+    samples = sum(int((s["rows"] * nch).sum()) for s in slots)
+    d2h = sum(s["tot"] for s in slots) * 4
     nbytes = sum(s["nbytes"] for s in slots)
     for bf in bufs:
         infos = bf["ctx"].stream_info(stream=bf["st"].cuda_stream)
@@ -530,15 +549,21 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         s = slots[p]
         i = p * per + k
         want, r, st = ora.decode(flat[int(offs[i]):int(offs[i] + sizes[i])], nch, int(frames[i]))
+        if wav24:
+            nb = int(s["rows"][k]) * nch * 3
+            a = s["h_out"].numpy()[int(s["oo"][k]):int(s["oo"][k]) + (nb + 3) // 4].view(np.uint8)[:nb]
+            ok = ok and st == 0 and a.tobytes() == ora.wav_pack(want, 24)
+            continue
         a = s["h_out"].numpy()[int(s["oo"][k]):int(s["oo"][k]) + int(s["rows"][k]) * nch]
         got = a.reshape(-1, nch).T if layout == hip.PCM_INTERLEAVED else a.reshape(nch, -1)
         ok = ok and st == 0 and np.array_equal(got, want)
     if not ok:
         raise SystemExit("host_to_host: PCM in host memory differs from the oracle")
     return {"value": round(samples * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_pass": round(dt / steps * 1e3, 3),
-            "titles": n, "sub_batches": parts, "h2d_bytes": nbytes, "d2h_bytes": samples * 4,
-            "pcie_GBs": round((nbytes + samples * 4) * steps / dt / 1e9, 2), "bit_exact_sample": ok,
-            "note": "pinned host -> H2D -> index+decode -> D2H -> pinned host, %d sub-batches on %d streams" % (parts, NB)}
+            "titles": n, "sub_batches": parts, "h2d_bytes": nbytes, "d2h_bytes": d2h,
+            "pcie_GBs": round((nbytes + d2h) * steps / dt / 1e9, 2), "bit_exact_sample": ok,
+            "note": "pinned host -> H2D -> index+decode -> D2H -> pinned host, %d sub-batches on %d streams%s" % (
+                parts, NB, "; the decode writes the packed 24-bit WAV payload: 3 B per sample go back" if wav24 else "")}
 
 
 # ----------------------------------------------------------------------------- plumbing-only ranks (CPU tests)
@@ -779,8 +804,12 @@ def main():
         if world == 1 and not args.no_sub and args.workload == "c3" and args.substreams == 1 and assignment == 12:
             sub_steps = max(5, min(args.steps, 20))
             out["sub"] = sub_records(pkg, torch, dev, local_rank, args, b, sub_steps, 2)
+            t_h = time.perf_counter()
             out["sub"]["host_to_host"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
                                                       max(3, sub_steps // 4))
+            out["sub"]["host_to_host_wav24"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
+                                                            max(3, sub_steps // 4), wav24=True)
+            sys.stderr.write("bench: host_to_host records %.1f s\n" % (time.perf_counter() - t_h))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
