@@ -9,10 +9,10 @@ import numpy as np, torch
 import libdvd_audio_amd as pkg
 syn, hip = pkg.synth, pkg.hipdec
 cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512)
-flat, offs, sizes, frames = syn.batch(cfg, 1, 512)
+flat, offs, sizes, frames = syn.batch(cfg, 1, 2048)
 dev = torch.device("cuda", 0)
 d_bytes = torch.from_numpy(flat).to(dev)
-n = 512
+n = 2048
 d_off = torch.from_numpy(offs.astype(np.int64)).to(dev); d_len = torch.from_numpy(sizes.astype(np.int64)).to(dev)
 out_off = np.zeros(n, np.int64); out_off[1:] = np.cumsum(frames[:-1].astype(np.int64) * 6)
 d_oo = torch.from_numpy(out_off).to(dev); d_st = torch.from_numpy(frames.astype(np.int64)).to(dev)
