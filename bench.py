@@ -211,7 +211,11 @@ class Batch:
         self.d_pcm = torch.empty(max(self.pcm_words, 1), dtype=torch.int32, device=dev)
         self.n_segments = n_segments
         self.ctx = hip.Context(local_rank, self.n_streams, n_segments, lanes_per_segment=lanes, layout=self.layout)
-        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        # a stream of its own (not the legacy default stream): the library replays the index as a hipGraph when the
+        # same buffers are indexed again, and capture needs a real stream
+        self._tstream = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        self.stream = self._tstream.cuda_stream
 
     def step(self, n_streams=None):
         n = self.n_streams if n_streams is None else n_streams

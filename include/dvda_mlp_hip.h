@@ -125,6 +125,9 @@ void dvda_mlp_hip_destroy(dvda_mlp_hip_ctx *ctx);
  * them, and derives each segment's first output row.  d_bytes must be readable
  * for total_bytes + 64 bytes; stream i occupies
  * [d_stream_off[i], d_stream_off[i] + d_stream_len[i]) and starts 16-byte aligned. */
+/* (A caller that indexes the same buffers again and again -- a pipeline that reuses its staging buffers -- gets
+ * the index's launch sequence replayed as one hipGraph from the third such call on; `stream` must then be a
+ * real stream, not NULL.  DVDA_INDEX_GRAPH=0 in the environment switches that off.) */
 int dvda_mlp_hip_index(dvda_mlp_hip_ctx *ctx, const uint8_t *d_bytes, uint64_t total_bytes,
                        const uint64_t *d_stream_off, const uint64_t *d_stream_len,
                        uint32_t n_streams, void *stream);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -106,6 +107,13 @@ struct dvda_mlp_hip_ctx {
     bool indexed;
     uint32_t lanes_per_seg;
     uint32_t pcm_layout;           // DVDA_PCM_PLANAR / DVDA_PCM_INTERLEAVED
+    // the index's launch sequence as a hipGraph, replayed while a caller indexes the same buffers again and
+    // again (a pipeline that reuses its staging buffers, the bench): one graph launch instead of ~18 launches
+    hipGraphExec_t idx_graph;
+    const void *idx_key[4];    // d_bytes, d_stream_off, d_stream_len, stream of the captured / last call
+    uint64_t idx_key_bytes;
+    uint32_t idx_key_streams;
+    int idx_graph_state;       // 0: off / not yet, 1: the key was seen once (capture on the next match), 2: captured, -1: disabled
     // timing of the fast-pass kernel: a fixed ring of (start, stop) pairs made at create time
     hipEvent_t ev[2 * EV_RING];
     uint32_t ev_made;          // events created
@@ -151,6 +159,8 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_frec);
     for (uint32_t i = 0; i < c->ev_made; i++)
         (void)hipEventDestroy(c->ev[i]);
+    if (c->idx_graph)
+        (void)hipGraphExecDestroy(c->idx_graph);
 }
 
 extern "C" const char *dvda_mlp_hip_version(void) { return "dvda-mlp-hip 0.1 (gfx950)"; }
@@ -176,6 +186,8 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->tiles_cap = 0;
     c->scan_tmp_cap = 0;
     c->indexed = false;
+    c->idx_graph = nullptr;
+    c->idx_graph_state = getenv("DVDA_INDEX_GRAPH") && atoi(getenv("DVDA_INDEX_GRAPH")) == 0 ? -1 : 0;
     c->ev_made = 0;
     c->ev_count = 0;
     c->d_init_fir = nullptr;
@@ -329,33 +341,13 @@ __global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, u
     }
 }
 
-extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, uint64_t total_bytes,
-                                  const uint64_t *d_stream_off, const uint64_t *d_stream_len,
-                                  uint32_t n_streams, void *stream_)
+// the index's kernels, in order, on `st`
+static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_bytes, uint64_t total_bytes,
+                          const uint64_t *d_stream_off, const uint64_t *d_stream_len, uint32_t n_streams)
 {
-    if (!c || !d_bytes || !d_stream_off || !d_stream_len || n_streams == 0 || total_bytes == 0)
-        return DVDA_HIP_EINVAL;
-    if (n_streams > c->max_streams)
-        return DVDA_HIP_ECAPACITY;
-    if (((uintptr_t)d_bytes & 15) != 0)
-        return DVDA_HIP_EINVAL;
-    hipStream_t st = (hipStream_t)stream_;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_byte_ws(c, total_bytes);
-    if (rc)
-        return rc;
-    c->d_bytes = d_bytes;
-    c->total_bytes = total_bytes;
-    c->d_stream_off = d_stream_off;
-    c->d_stream_len = d_stream_len;
-    c->n_streams = n_streams;
-    const uint64_t chunks = (total_bytes + 15) / 16;
-    const uint64_t tiles = (chunks + IDX_TILE_CHUNKS - 1) / IDX_TILE_CHUNKS;
-    c->tiles = tiles;
-    c->d_n_cand = c->d_tile_base + tiles;
+    const uint64_t tiles = c->tiles;
     const uint32_t ms = c->max_segments;
-
-    HIP_TRY(hipMemsetAsync(c->d_cls, 0, 4 * sizeof(uint32_t), st));
+    (void)hipMemsetAsync(c->d_cls, 0, 4 * sizeof(uint32_t), st);
     {
         const uint32_t n_init = n_streams > ms ? n_streams : ms;
         hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
@@ -380,6 +372,79 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     exscan(c, st, c->d_sorted_cnt, c->d_sorted_base, n_streams, nullptr, n_streams);
     hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, st, c->d_seg, c->d_streams, c->d_n_cand, ms,
                        c->d_rank, c->d_sorted_base, c->d_cls + 2, c->d_lane_seg);
+}
+
+extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, uint64_t total_bytes,
+                                  const uint64_t *d_stream_off, const uint64_t *d_stream_len,
+                                  uint32_t n_streams, void *stream_)
+{
+    if (!c || !d_bytes || !d_stream_off || !d_stream_len || n_streams == 0 || total_bytes == 0)
+        return DVDA_HIP_EINVAL;
+    if (n_streams > c->max_streams)
+        return DVDA_HIP_ECAPACITY;
+    if (((uintptr_t)d_bytes & 15) != 0)
+        return DVDA_HIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_byte_ws(c, total_bytes);
+    if (rc)
+        return rc;
+    c->d_bytes = d_bytes;
+    c->total_bytes = total_bytes;
+    c->d_stream_off = d_stream_off;
+    c->d_stream_len = d_stream_len;
+    c->n_streams = n_streams;
+    const uint64_t chunks = (total_bytes + 15) / 16;
+    const uint64_t tiles = (chunks + IDX_TILE_CHUNKS - 1) / IDX_TILE_CHUNKS;
+    c->tiles = tiles;
+    c->d_n_cand = c->d_tile_base + tiles;
+
+    // The launch sequence depends on the call's arguments only.  A caller that indexes the same buffers again
+    // (third call on: seen, captured, replayed) gets it as ONE graph launch; capture needs a real stream (not
+    // the legacy default stream), anything going wrong with it switches the graph off for this context.
+    const bool same = c->idx_graph_state > 0 && c->idx_key[0] == d_bytes && c->idx_key[1] == d_stream_off &&
+                      c->idx_key[2] == d_stream_len && c->idx_key[3] == (const void *)st &&
+                      c->idx_key_bytes == total_bytes && c->idx_key_streams == n_streams;
+    if (c->idx_graph_state == 2 && same) {
+        if (hipGraphLaunch(c->idx_graph, st) == hipSuccess) {
+            c->indexed = true;
+            return DVDA_HIP_OK;
+        }
+        (void)hipGetLastError();
+        c->idx_graph_state = -1;
+    } else if (c->idx_graph_state == 1 && same && st != nullptr) {
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            enqueue_index(c, st, d_bytes, total_bytes, d_stream_off, d_stream_len, n_streams);
+            ok = hipStreamEndCapture(st, &g) == hipSuccess && g != nullptr;
+        }
+        if (ok) {
+            if (c->idx_graph) {
+                (void)hipGraphExecDestroy(c->idx_graph);
+                c->idx_graph = nullptr;
+            }
+            ok = hipGraphInstantiate(&c->idx_graph, g, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (g)
+            (void)hipGraphDestroy(g);
+        if (ok && hipGraphLaunch(c->idx_graph, st) == hipSuccess) {
+            c->idx_graph_state = 2;
+            c->indexed = true;
+            return DVDA_HIP_OK;
+        }
+        (void)hipGetLastError();
+        c->idx_graph_state = -1;                 // direct launches from here on
+    } else if (c->idx_graph_state >= 0) {
+        c->idx_key[0] = d_bytes;
+        c->idx_key[1] = d_stream_off;
+        c->idx_key[2] = d_stream_len;
+        c->idx_key[3] = (const void *)st;
+        c->idx_key_bytes = total_bytes;
+        c->idx_key_streams = n_streams;
+        c->idx_graph_state = 1;
+    }
+    enqueue_index(c, st, d_bytes, total_bytes, d_stream_off, d_stream_len, n_streams);
     HIP_TRY(hipGetLastError());
     c->indexed = true;
     return DVDA_HIP_OK;
