@@ -115,6 +115,9 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 //   DVDA_EXP_NOSTORE  keep PCM values alive but do not store them (prices the write path)
 //   DVDA_EXP_NOCRC    skip the parity/CRC-8 check (prices it)
 //   DVDA_EXP_STAMP    accumulate s_memtime deltas per loop phase into DecodeArgs.dbg
+//   DVDA_EXP_UNDEFPF  leave the prefetch registers of the main loop undefined, as round 1 had them (the form
+//                     that miscompiled the two-wave frame-major instance under unrelated changes);
+//   DVDA_EXP_INITPF   zero them with instructions instead of the empty asm (costs a wait per row)
 #if defined(DVDA_EXP_STAMP)
 #define DVDA_STAMP(i)                                                    \
     do {                                                                 \
@@ -1523,17 +1526,24 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #endif
         // (the chunk this overwrites has been hashed: crc_catchup() above ran up to `next`, and
         //  ahead_now <= 16 puts `next` past it)
-        // deliberately not initialised: only read under the same `pf`.  (Zero-filling them made the
-        // compiler wait for every outstanding memory operation -- the previous row's PCM stores
-        // included -- before it could overwrite the registers.)
+        // Four registers each, written by the loads below and read under the same `pf`.  They must hold a DEFINED
+        // value on the lanes that do not load.  Zero-filling them with instructions made the compiler wait for
+        // every outstanding memory operation -- the previous row's PCM stores included -- before it could
+        // overwrite them; round 1 therefore left them uninitialised outright, and an undefined value is not a
+        // harmless one: the two-wave frame-major instance of this kernel went wrong twice under unrelated source
+        // changes (a loop in the cold branch, one more CRC table) and went right again, each time, as soon as
+        // these registers were defined.  The empty asm defines them -- some value, no instruction, nothing to
+        // wait for -- which is all the code ever needed.
         uint4 p0, p1, p2, p3;
+#if defined(DVDA_EXP_INITPF)
+        p0 = p1 = p2 = p3 = make_uint4(0, 0, 0, 0);
+#elif !defined(DVDA_EXP_UNDEFPF)
+        asm volatile("" : "=v"(p0.x), "=v"(p0.y), "=v"(p0.z), "=v"(p0.w), "=v"(p1.x), "=v"(p1.y), "=v"(p1.z), "=v"(p1.w),
+                          "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
+#endif
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
         uint64_t flush_row = 0;
-#if defined(DVDA_EXP_ALWAYSLOAD)
-        if (pf || active) {      // diagnostic: every lane issues the four loads every row
-#else
         if (pf) {
-#endif
             const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
             const uint4 *src = rd.gsrc + (c >> 2);
             p0 = src[0];
