@@ -176,7 +176,10 @@ int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *la
 /* Which fast-pass kernels run.  0 (default): chosen per batch from the substream counts the index
  * found -- streams with one substream take the one-lane-per-segment kernel, streams with two the
  * two-wave kernel, a mixed batch both (a kernel whose class is absent exits at once).  1 / 2 force one
- * kernel for the whole batch (1: a two-substream stream is then reported as DVDA_ST_ENVELOPE). */
+ * kernel for the whole batch (1: a two-substream stream is then reported as DVDA_ST_ENVELOPE; 2: the
+ * two-wave kernel keeps four channels per substream in registers -- what discs carry is 2 + 4 -- and a
+ * substream with five or six channels is decoded by the passes behind it, DVDA_ST_COLD | DVDA_ST_GENERAL
+ * set, PCM identical). */
 int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
 
 /* Per-segment results of the last decode (blocks on `stream`). */

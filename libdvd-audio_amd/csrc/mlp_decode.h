@@ -46,7 +46,14 @@ namespace mlp {
 constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 // fast pass over two-substream streams: one wave per (64 segments, substream); see k_decode
-constexpr int WS_THREADS = 256;
+#ifndef DVDA_WS_THREADS
+#define DVDA_WS_THREADS 256
+#endif
+constexpr int WS_THREADS = DVDA_WS_THREADS;
+#ifndef DVDA_WS_SLOTS
+#define DVDA_WS_SLOTS 4
+#endif
+constexpr int WS_SLOTS = DVDA_WS_SLOTS;   // channels per substream the two-wave kernel keeps in registers (more: ST_COLD)
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
 #ifndef DVDA_RING_PLANES
@@ -623,10 +630,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // fast pass over two-substream streams: a wave carries ONE substream of 64 segments.  The odd
     // wave of a group has each segment's last substream (the only one of a single-substream stream):
     // it gathers the row's channels, rematrixes, stages and stores.  The even wave has the first
-    // substream of the two-substream streams: its own (typically two) slots and nothing else.  The
-    // pair trades a row's channels through s_xw[row parity], one block barrier per row.  (Measured
-    // on the 2-substream bench shape against the lane-pair layout, which ran every wave through the
-    // long substream's slots and the rematrix; 2-, 4- and 8-wave blocks were tried.)
+    // substream of the two-substream streams: its own (typically two) slots and nothing else.
+    // (Round 1 measured this against the lane-pair layout, which ran every wave through the long
+    //  substream's slots and the rematrix; 2-, 4- and 8-wave blocks were tried.)
+    // Round 2: the pair no longer meets at a barrier every row.  The staging tile is doubled and doubles
+    // as the exchange: the odd wave writes the rows of phase p (OUT_ROWS loop turns) into tile p & 1
+    // while the even wave -- which rematrixes, see WS_BAL -- runs OUT_ROWS rows behind it: it reads the
+    // rows of phase p - 1 from the other tile, adds its own channels, rematrixes in place and flushes
+    // the tile at the phase's last row.  One block barrier per OUT_ROWS rows, and neither wave waits
+    // for the other's row, only for its last four.
     constexpr bool WSPEC = PAIRED && !GENERAL && !PARSE;
     constexpr bool SIDE = PAIRED && !WSPEC;                       // the two lanes of a segment side by side
     constexpr int THREADS = WSPEC ? WS_THREADS : DEC_THREADS;
@@ -637,23 +649,26 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     //  ranges may differ, and a channel's history outlives the segments that do not carry it)
     constexpr bool USLOT = DVDA_UNIFORM_SLOTS && !GENERAL;
     __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
-    __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
+    __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS * 2 : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
+    // two-wave layout, per row of a tile: "the odd wave's channels are there" | version of the rematrix
+    // parameters the row goes with << 8 | its bypassed LSBs
+    __shared__ uint32_t s_tag[WSPEC ? GROUPS : 1][2][OUT_ROWS][WSPEC ? 64 : 1];
     __shared__ int32_t s_xch[SIDE ? WAVES : 1][MAXCH][SIDE ? 64 : 1];
-    __shared__ int32_t s_xw[WSPEC ? 2 : 1][GROUPS][MAXCH][WSPEC ? 64 : 1];
     __shared__ uint32_t s_alive[2][WAVES];
     // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
     // (last substream, odd wave) for the lane that applies them (first substream, even wave)
     constexpr bool WS_BAL = WSPEC && DVDA_WS_BALANCE;
-    // (two copies, by version parity: the reader may still be at the last one when the next is written;
-    //  word 0 of copy 0 is the version of the newest)
-    __shared__ uint32_t s_par[WS_BAL ? GROUPS : 1][2][16][WS_BAL ? 64 : 1];
+    // (two copies, by version parity.  Versions are at least 8 rows apart -- a block has 8 rows or more --
+    //  so at most one is written per phase, and the reader, one phase behind, has taken version v - 1 before
+    //  the phase in which v + 1 overwrites it.  Word 0: a restart header set the noise seed in word 1.)
+    constexpr int SPL = 64;
+    __shared__ uint32_t s_par[WS_BAL ? GROUPS : 1][2][16][WS_BAL ? SPL : 1];
 
     for (int i = threadIdx.x; i < 4 * 256; i += THREADS)
         s_crc[i] = d_crc.t[i];
-    if (WS_BAL) {
-        // plane 7 of the exchange tiles carries "row n of the other lane is there": start from "no row"
-        for (int i = threadIdx.x; i < 2 * GROUPS * 64; i += THREADS)
-            s_xw[WS_BAL ? i / (GROUPS * 64) : 0][WS_BAL ? (i / 64) % GROUPS : 0][7][WS_BAL ? i % 64 : 0] = 0;
+    if (WSPEC) {
+        for (int i = threadIdx.x; i < GROUPS * 2 * OUT_ROWS * 64; i += THREADS)     // "no row there"
+            (&s_tag[0][0][0][0])[WSPEC ? i : 0] = 0;
     }
     __syncthreads();
 
@@ -663,7 +678,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // (the only one of a single-substream stream), the even wave the first substream of the
     // two-substream ones -- so the even waves never rematrix, stage or store PCM
     const uint32_t ws_grp = (uint32_t)wv >> 1;
+#if defined(DVDA_WS_FLIP)
+    // diagnostic: which wave of a pair takes which role alternates, so that a SIMD does not collect one kind
+    const uint32_t ws_last = ((uint32_t)wv ^ ((uint32_t)wv >> 1) ^ (blockIdx.x >> DVDA_WS_FLIP)) & 1u;
+#else
     const uint32_t ws_last = (uint32_t)wv & 1u;
+#endif
     const uint32_t gl0 = blockIdx.x * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
@@ -855,6 +875,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t oshift_pack = 0, qss_pack = 0;
     uint32_t qss_A = 0, mmc_A = 0;    // quant step sizes / max_matrix_channel the rematrix works with
     uint32_t par_seen = 0, par_pub = 0;   // WS_BAL: version of the published parameters (taken / written)
+    uint32_t par_phase = 0;               // ... and the phase + 1 the last one was written in
+    uint32_t it = 0;                      // two-wave layout: loop turn (wave-uniform); phase = it / OUT_ROWS
     const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
     uint32_t nslots = 0;
     uint32_t slots_w = 2;             // wave-uniform: slots some lane of the wave carries (slots 0, 1 always run)
@@ -936,10 +958,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     };
 
 #if defined(DVDA_EXP_STAMP)
-    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = clock64();
 #endif
-    uint32_t rows_iter = 0;            // two-wave layout: parity of the exchange buffer
     for (;;) {
         DVDA_STAMP(5);
         bool hdr_parsed = false;       // this lane parsed a block header in this iteration
@@ -1069,8 +1090,30 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 uint32_t err = ST_PARAMS;
                 bool matrix_class_change = false;
                 bool hdr_restart = false;
+                bool too_wide = false;
                 uint32_t chg_mask = 0, iir_mask = 0, rec_words = 0;   // chain parse pass: slots whose filter parameters this block sets
                 bool seq_needed = false;                   // ... and what only the sequential pass decodes
+                // two-wave layout, the lane that rematrixes with the OTHER substream's parameters: its own
+                // header sets the same variables (the parse below needs them: matrix count, bypass flags); they
+                // are put back when it is through
+                uint32_t keep_m[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, keep_n[2] = {0, 0};
+                uint32_t keep_ns = 0, keep_seed = 0, keep_ml = 0, keep_oc = 0, keep_os = 0;
+                if (adopt) {
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            keep_m[m][j] = mreg[m][j];
+                        keep_n[m] = mnoise[m];
+                    }
+                    keep_ns = noise_shift;
+                    keep_seed = seed;
+                    keep_ml = matrix_len;
+                    keep_oc = outch_pack;
+                    keep_os = oshift_pack;
+                    // (its own matrix count outlives the block; it rides in the upper half of par_seen)
+                    matrix_len = par_seen >> 16;
+                }
                 if (rd.read(1)) {
                     const bool restart = rd.read(1) != 0;
                     hdr_restart = restart;
@@ -1089,7 +1132,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         if (h0 != (0x18F5u << 1) || max_ch < min_ch || max_mat_ch < max_ch) {
                             ok = false;
                             err = ST_RESTART;
-                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= (uint32_t)NS || (!PAIRED && min_ch != 0)) {
+                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= 6u || (!PAIRED && min_ch != 0)) {
                             ok = false;
                             // DVD-Audio layouts stop at 6 channels (src/mlp.c:416-438 has 6 columns,
                             // src/dvd-audio.c:1459-1496 counts at most 6); matrix channels 6 and 7 are
@@ -1104,6 +1147,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                 }
                             rd.read(8);                            // checksum: ignored
                             nslots = max_ch - min_ch + 1;
+                            // more channels in one substream than this instance keeps in registers (the two-wave
+                            // kernel: WS_SLOTS): the header is parsed to its end -- whether the segment needs the
+                            // history before it is decided there -- and the segment goes to the chain passes
+                            if (NS < 6 && nslots > (uint32_t)NS)
+                                too_wide = true;
                             have_restart = true;
                             if constexpr (USLOT) {
                                 // slots beyond the substream's channels: no bits, no taps, value 0
@@ -1445,12 +1493,35 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     qss_A = qss_pack;
                     mmc_A = max_mat_ch;
                 }
+                uint32_t cold_ml = matrix_len;        // (this substream's own matrix count)
+                if (adopt) {
+                    par_seen = (par_seen & 0xFFFFu) | (matrix_len << 16);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            mreg[m][j] = keep_m[m][j];
+                        mnoise[m] = keep_n[m];
+                    }
+                    noise_shift = keep_ns;
+                    seed = keep_seed;
+                    matrix_len = keep_ml;
+                    outch_pack = keep_oc;
+                    oshift_pack = keep_os;
+                }
                 if (lends) {
-                    // ---- the parameters the other wave rematrixes with; the seed only when a restart
-                    //      header set it (the other lane steps its own copy from there)
-                    par_pub += 2u;
-                    uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][(par_pub >> 1) & 1u][0][WS_BAL ? lane : 0];
-                    constexpr int PS = WS_BAL ? 64 : 1;
+                    // ---- the parameters the other wave rematrixes with, from this row on; the seed only when a
+                    //      restart header set it (the other lane steps its own copy from there)
+                    if (par_phase == (it >> 2) + 1u) {
+                        status |= ST_COLD;          // (cannot happen: blocks have 8 rows or more; s_par's note)
+                        ok = false;
+                        err = 0;
+                    }
+                    par_phase = (it >> 2) + 1u;
+                    par_pub = (par_pub + 1u) & 0xFFFFu;
+                    uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][par_pub & 1u][0][WS_BAL ? lane & (SPL - 1) : 0];
+                    constexpr int PS = WS_BAL ? SPL : 1;
+                    P[0] = hdr_restart ? 1u : 0u;
                     P[1 * PS] = seed;
                     P[2 * PS] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
                     P[3 * PS] = outch_pack;
@@ -1463,7 +1534,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             P[(6 + m * 4 + j) * PS] = mreg[m][j];
                         P[(14 + m) * PS] = mnoise[m];
                     }
-                    s_par[WS_BAL ? ws_grp : 0][0][0][WS_BAL ? lane : 0] = par_pub | (hdr_restart ? 1u : 0u);
                 }
                 if (matrix_class_change)
                     status |= ST_MIDFRAME;
@@ -1472,7 +1542,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (PARSE && !active) {
                     // (ST_SEQ above)
-                } else if (!GENERAL && !PARSE && (iir_any != 0 || matrix_len > 2)) {
+                } else if (!GENERAL && !PARSE && (iir_any != 0 || cold_ml > 2 || too_wide)) {
                     // IIR taps (their coefficients and history live in a memory workspace) or more than the
                     // two register-resident matrices: the chain passes decode such a segment -- the fused row
                     // loop keeps neither in its registers
@@ -1542,6 +1612,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                           "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
 #endif
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
+        uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
         uint64_t flush_row = 0;
         if (pf) {
             const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
@@ -1555,9 +1626,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 
         uint32_t bypass_bits = 0;
         int32_t val[WSPEC ? 1 : NS];
-        const uint32_t par = rows_iter & 1u;           // two-wave layout: exchange tile of this row
-        rows_iter++;
-        int32_t *const xw_mine = &s_xw[WSPEC ? par : 0][WSPEC ? ws_grp : 0][0][WSPEC ? lane : 0] + (WSPEC ? min_ch * 64u : 0u);
+        // two-wave layout: this lane's row in the tile pair -- row r lives in tile (r / OUT_ROWS) & 1, for the
+        // wave that writes it and, OUT_ROWS turns later, for the wave that picks it up (wave-uniform: every
+        // active lane of a wave is at the same row)
+        const uint32_t xslot = rows_done & (OUT_ROWS - 1);
+        int32_t *const xtile = &s_out[WSPEC ? ws_grp * 2u + ((rows_done / OUT_ROWS) & 1u) : 0][0][0][WSPEC ? lane : 0];
+        const uint32_t xstride = (ILV && ilv_direct) ? 64u : (uint32_t)OUT_ROWS * 64u;       // channel to channel
+        int32_t *const xrow = xtile + ((ILV && ilv_direct) ? xslot * (6u * 64u) : xslot * 64u);
+        int32_t *const xw_mine = xrow + min_ch * xstride;
         auto row_head = [&]() {
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
             // all of the row's bypassed LSBs (at most one per matrix) are cut from the window at once
@@ -1690,7 +1766,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 if constexpr (WSPEC) {
                     if (in)
-                        xw_mine[k * 64] = value;          // straight to the exchange tile
+                        xw_mine[k * xstride] = value;     // straight into the tile
                 } else {
                     val[k] = USLOT ? value : (in ? value : 0);
                 }
@@ -1730,7 +1806,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     // ---- into the LDS staging tile [channel][frame][lane]; rows advance in lockstep so
                     //      the frame phase is the same in every lane
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
-                    int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
+                    int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] =
+                        s_out[GENERAL ? 0 : (WSPEC ? ws_grp * 2u + ((rows_done / OUT_ROWS) & 1u) : wv)];
+                    if constexpr (WSPEC)
+                        flush_tile = ws_grp * 2u + ((rows_done / OUT_ROWS) & 1u);
                     if (ILV && ilv_direct) {
                         int32_t *Td = &T[0][0][GENERAL ? 0 : lane] + ph * (6 * 64);
 #pragma unroll
@@ -1867,59 +1946,50 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         };
         // ---- the frame's channels 0..7 come together for the rematrix
         int32_t ch[MAXCH];
-        const bool in_row = active;
+        // (two-wave layout: the lane that rematrixes starts OUT_ROWS turns late, for good)
+        const bool in_row = active && (!adopt || it >= (uint32_t)OUT_ROWS);
         if constexpr (WSPEC) {
             if (in_row)
                 row_head();
-            int32_t(*X)[WSPEC ? 64 : 1] = s_xw[WSPEC ? par : 0][WSPEC ? ws_grp : 0];
-            if (WS_BAL && in_row && lends)
-                X[7][lane] = (int32_t)(bypass_bits | (rows_iter << 24));    // + "this row is there"
-            const uint32_t wave_alive = __any(in_row) ? 1u : 0u;     // (over the whole wave: outside the branch)
-            if (lane == 0)
-                s_alive[par][wv] = wave_alive;
-            // LDS only: the chunk in flight and the PCM stores are not waited for
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (!__any(lane < WAVES && s_alive[par][lane < WAVES ? lane : 0] != 0))
-                break;
+            if (lends) {
+                // ---- this turn's row of the other lane's tile: there or not, what it is rematrixed with
+                s_tag[WSPEC ? ws_grp : 0][(it / OUT_ROWS) & 1u][it & (OUT_ROWS - 1)][WSPEC ? lane : 0] =
+                    in_row ? (0x80000000u | (par_pub << 8) | (bypass_bits & 0xFFu)) : 0u;
+            }
             if (in_row) {
+                if (adopt) {
+                    // ---- the other lane's row: is it there at all, its bypassed LSBs, its parameters
+                    const uint32_t tagw = s_tag[WSPEC ? ws_grp : 0][(rows_done / OUT_ROWS) & 1u][xslot][WSPEC ? lane : 0];
+                    bypass_bits = tagw & 0xFFu;
+                    const uint32_t ver = (tagw >> 8) & 0xFFFFu;
+                    if (!(tagw >> 31)) {
+                        active = false;                  // it stopped (its status says why): no more output
+                    } else if (__builtin_expect(ver != (par_seen & 0xFFFFu), 0)) {
+                        const uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][ver & 1u][0][WS_BAL ? lane & (SPL - 1) : 0];
+                        constexpr int PS = WS_BAL ? SPL : 1;
+                        if (P[0])
+                            seed = P[1 * PS];
+                        par_seen = (par_seen & ~0xFFFFu) | ver;
+                        const uint32_t w2 = P[2 * PS];
+                        noise_shift = w2 & 0xFFu;
+                        matrix_len = (w2 >> 8) & 0xFFu;
+                        mmc_A = w2 >> 16;
+                        outch_pack = P[3 * PS];
+                        qss_A = P[4 * PS];
+                        oshift_pack = P[5 * PS];
+#pragma unroll
+                        for (int m = 0; m < 2; m++) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                mreg[m][j] = P[(6 + m * 4 + j) * PS];
+                            mnoise[m] = P[(14 + m) * PS];
+                        }
+                    }
+                }
                 if (owner) {
 #pragma unroll
                     for (int c = 0; c < MAXCH; c++)
-                        ch[c] = X[c][lane];
-                }
-                if (adopt) {
-                    // ---- the other lane's row: its bypassed LSBs, and is it there at all?
-                    const uint32_t tagw = (uint32_t)ch[7];
-                    ch[7] = 0;
-                    bypass_bits = tagw & 0xFFFFFFu;
-                    if ((tagw >> 24) != (rows_iter & 0xFFu)) {
-                        active = false;                  // it stopped (its status says why): no more output
-                    } else {
-                        const uint32_t verw = s_par[WS_BAL ? ws_grp : 0][0][0][WS_BAL ? lane : 0];
-                        if (__builtin_expect((verw & ~1u) != par_seen || hdr_parsed, 0)) {
-                            // ---- new parameters over there, or this lane's own header parse has just
-                            //      overwritten the registers they live in: (re)load them
-                            const uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][(verw >> 1) & 1u][0][WS_BAL ? lane : 0];
-                            constexpr int PS = WS_BAL ? 64 : 1;
-                            if ((verw & 1u) && (verw & ~1u) != par_seen)
-                                seed = P[1 * PS];
-                            par_seen = verw & ~1u;
-                            const uint32_t w2 = P[2 * PS];
-                            noise_shift = w2 & 0xFFu;
-                            matrix_len = (w2 >> 8) & 0xFFu;
-                            mmc_A = w2 >> 16;
-                            outch_pack = P[3 * PS];
-                            qss_A = P[4 * PS];
-                            oshift_pack = P[5 * PS];
-#pragma unroll
-                            for (int m = 0; m < 2; m++) {
-#pragma unroll
-                                for (int j = 0; j < 4; j++)
-                                    mreg[m][j] = P[(6 + m * 4 + j) * PS];
-                                mnoise[m] = P[(14 + m) * PS];
-                            }
-                        }
-                    }
+                        ch[c] = c < 6 ? xrow[(c < 6 ? c : 0) * xstride] : 0;
                 }
                 row_tail(ch);
             }
@@ -1960,7 +2030,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //      here they have a whole row to drain before the next wait
         if (!GENERAL && !PARSE && ILV && flush) {
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
-            const int32_t *Tl = &s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)][0][0][GENERAL ? 0 : lane];
+            const int32_t *Tl = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
             if (__builtin_expect(a.wav_bits != 0, 0)) {
                 // ---- the WAV payload itself (SURVEY 8(f-3) fused into the decode): the OUT_ROWS frames are
@@ -2047,7 +2117,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             // ---- chain parse pass: four PCM frames of all eight planes are ONE 128-byte line of the segment's
             //      workspace ([row / 4][plane][row % 4], res_index()): the lane writes it whole, the filter pass's
             //      lanes of a chain read it together, the rematrix pass reads it once
-            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
             int32_t *dst = a.res + out_base + (flush_row >> 2) * 32u;
 #pragma unroll
             for (int c = 0; c < TP; c++)
@@ -2055,7 +2125,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                  T[c][2][GENERAL ? 0 : lane], T[c][3][GENERAL ? 0 : lane]);
         }
         if (!GENERAL && !PARSE && !ILV && flush) {
-            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : (WSPEC ? wv >> 1 : wv)];
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 if ((uint32_t)c < nch_out) {
@@ -2078,14 +2148,31 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
+        if constexpr (WSPEC) {
+            // ---- end of a phase: the rows written in it are there for the wave behind, the tile flushed in it
+            //      is free for the wave in front; the block leaves together when no wave has a lane left
+            if ((it & (OUT_ROWS - 1)) == OUT_ROWS - 1) {
+                const uint32_t ph = (it / OUT_ROWS) & 1u;
+                const uint32_t wave_alive = __any(active) ? 1u : 0u;
+                if (lane == 0)
+                    s_alive[ph][wv] = wave_alive;
+                // LDS only: the chunk in flight and the PCM stores are not waited for
+                DVDA_STAMP(4);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                DVDA_STAMP(6);      // waiting at the phase barrier
+                if (!__any(lane < WAVES && s_alive[ph][lane < WAVES ? lane : 0] != 0))
+                    break;
+            }
+            it++;
+        }
         DVDA_STAMP(4);
     }
 
 #if defined(DVDA_EXP_STAMP)
     DVDA_STAMP(4);
     if (lane == 0 && a.dbg)
-        for (int i = 0; i < 6; i++)
-            atomicAdd(&a.dbg[i], stamp_acc[i]);
+        for (int i = 0; i < 8; i++)
+            atomicAdd(&a.dbg[i + (WSPEC ? 8 * (int)ws_last : 0)], stamp_acc[i]);      // two-wave layout: per role
 #endif
     if (!GENERAL && !PARSE && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
         // FIR history at the segment's end, for a following segment that depends on it

@@ -534,9 +534,9 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     if (run2) {
         a.only_S = force ? 0u : 2u;
         if (a.interleaved)
-            hipLaunchKernelGGL((k_decode<6, true, false, true>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
+            hipLaunchKernelGGL((k_decode<WS_SLOTS, true, false, true>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
         else
-            hipLaunchKernelGGL((k_decode<6, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
+            hipLaunchKernelGGL((k_decode<WS_SLOTS, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
     }
     HIP_TRY(hipEventRecord(c->ev[2 * slot + 1], st));
     c->ev_count++;

@@ -215,7 +215,9 @@ def test_linearity_free_property_checksum_of_large_batch(pkg, oracle):
     pcm2, infos2 = _both(hip, streams, lanes_per_segment=2)
     for i, b in enumerate(streams):
         want, r, st = oracle.decode(b, 6, 128 * 80)
-        assert st == 0 and infos1[i].status == 0 and infos2[i].status == 0
+        # (forced lane pairs: the two-wave kernel keeps four channels per substream in registers; a six-channel
+        #  substream goes through the chain passes and says so -- an information bit, not an error)
+        assert st == 0 and infos1[i].status == 0 and infos2[i].status & ~hip.ST_BENIGN == 0
         assert int(pcm1[i].astype(np.int64).sum()) == int(want.astype(np.int64).sum())
         assert np.array_equal(pcm1[i], pcm2[i]) and np.array_equal(pcm1[i], want)
 
@@ -617,6 +619,30 @@ def test_mixed_batch_picks_the_kernels_itself(pkg, oracle):
         assert np.array_equal(got, want)
     _, forced = hip.decode_streams([b for b, _ in streams], lanes_per_segment=1)
     assert forced[1].status & hip.ST["ENVELOPE"] and forced[0].status == 0
+
+
+@pytest.mark.parametrize("ss0", [1, 2, 3, 4, 5])
+def test_two_substreams_of_any_split(pkg, oracle, ss0):
+    """The two-wave kernel keeps four channels per substream in registers (two + four is what discs carry).  Any
+    other split of six channels -- one + five, five + one -- must still come out exact: the wide substream's
+    segments are handed to the chain passes (DVDA_ST_COLD, an information bit)."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfgs = [syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0),
+            syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0, profile=1,
+                         features=syn.SF_FAST, restart_interval=5),
+            syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0, profile=1,
+                         features=syn.SF["CHAINED"] | syn.SF["FIRRAND"], restart_interval=4)]
+    streams = [syn.stream(c, 9300 + 10 * ss0 + i) for i, c in enumerate(cfgs)]
+    pcm, infos = _both(hip, [b for b, _ in streams])
+    wide = ss0 < 2 or ss0 > 4
+    for i, ((b, f), got, inf) in enumerate(zip(streams, pcm, infos)):
+        want, r, st = oracle.decode(b, 6, f)
+        assert st == 0 and r == f
+        assert inf.status & ~hip.ST_BENIGN == 0 and inf.substreams == 2
+        assert bool(inf.status & hip.ST["COLD"]) or not wide
+        if i == 0:
+            assert inf.status == (hip.ST["COLD"] | hip.ST["GENERAL"] if wide else 0), hex(inf.status)
+        assert np.array_equal(got, want)
 
 
 def test_too_small_a_context_is_reported_not_truncated(pkg, oracle):

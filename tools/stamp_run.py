@@ -8,7 +8,8 @@ os.environ["DVDA_MLP_HIP_LIB"] = os.path.join(ROOT, "libdvd-audio_amd", "exp_sta
 import numpy as np, torch
 import libdvd_audio_amd as pkg
 syn, hip = pkg.synth, pkg.hipdec
-cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512)
+SS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512, n_substreams=SS)
 flat, offs, sizes, frames = syn.batch(cfg, 1, 2048)
 dev = torch.device("cuda", 0)
 d_bytes = torch.from_numpy(flat).to(dev)
@@ -17,7 +18,7 @@ d_off = torch.from_numpy(offs.astype(np.int64)).to(dev); d_len = torch.from_nump
 out_off = np.zeros(n, np.int64); out_off[1:] = np.cumsum(frames[:-1].astype(np.int64) * 6)
 d_oo = torch.from_numpy(out_off).to(dev); d_st = torch.from_numpy(frames.astype(np.int64)).to(dev)
 d_pcm = torch.empty(int(frames.sum()) * 6, dtype=torch.int32, device=dev)
-ctx = hip.Context(0, n, n * 64, lanes_per_segment=1)
+ctx = hip.Context(0, n, n * 64, lanes_per_segment=0)
 for it in range(2):
     ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), n, 0)
     ctx.decode(d_pcm.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), 0)
@@ -25,8 +26,11 @@ for it in range(2):
     out = (ctypes.c_ulonglong * 16)()
     hip.lib().dvda_mlp_hip_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     hip.lib().dvda_mlp_hip_debug_counters(ctx._h, out)
-v = np.array(list(out)[:6], dtype=np.float64)
-names = ["header phase", "prefetch issue / sync fill", "parse+filter (row)", "rematrix+store", "ring commit", "loop top"]
-for nme, x in zip(names, v):
-    print("%-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / v.sum(), x))
+names = ["header phase", "prefetch issue / sync fill", "parse+filter (row)", "exchange+rematrix+stage", "ring commit+flush",
+         "loop top", "phase barrier", "-"]
+for role in range(2 if SS == 2 else 1):
+    v = np.array(list(out)[8 * role:8 * role + 8], dtype=np.float64)
+    print("role", role, "(two-wave layout: 0 = first substream's wave, rematrixes; 1 = last substream's wave)" if SS == 2 else "")
+    for nme, x in zip(names, v):
+        print("  %-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / max(v.sum(), 1), x))
 print(ctx.kernel_time())
