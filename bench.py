@@ -460,7 +460,113 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     flat, offs, sizes, frames = syn.batch(one, 7, 1)
     run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 512 access units (the low-parallelism case)")
+    out["mixed_corpus_c5"] = mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup)
     return out
+
+
+def mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup):
+    """BASELINE configs[4] on one GPU: 6-ch / 192 kHz / 24-bit MLP titles and 6-ch / 24-bit raw-PCM AOB titles,
+    resident in HBM, decoded at the same time -- the MLP batch on one HIP stream, the PCM sectors
+    (sector walk + AOB byte un-swizzle) on another, each driven by its own host thread.  The
+    record carries the two kinds alone and together, in samples and in algorithmic bytes per second."""
+    import ctypes
+    import threading
+    syn, hip, disc = pkg.synth, pkg.hipdec, pkg.disc
+    t_run = time.perf_counter()
+    cfg = syn.make_cfg(assignment=12, rate_code=2, n_substreams=1, n_aus=256)        # 160 PCM frames per access unit
+    flat, offs, sizes, frames = syn.batch(cfg, 4001, args.streams)
+    nseg = args.streams * args.replicas * ((256 + cfg.restart_interval - 1) // cfg.restart_interval)
+    mlp = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, np.full(len(sizes), 6), args.replicas,
+                "interleaved", 0, nseg)
+    # raw-PCM titles: 2 048 unique sectors of random 24-bit frames, repeated on the device
+    rng = np.random.RandomState(5)
+    unit_frames = 110 * 2048
+    src = rng.randint(-(1 << 23), 1 << 23, size=(unit_frames, 6))
+    unit = np.frombuffer(b"".join(disc.pcm_track_sectors(src, 2, 1, 12)), np.uint8)
+    reps = 128
+    d_sec = torch.from_numpy(unit.copy()).to(dev).repeat(reps)
+    n_sec = d_sec.numel() // 2048
+    cap = n_sec * 110 + 2
+    d_pcm = torch.empty(6 * cap, dtype=torch.int32, device=dev)
+    lib = hip.lib()
+    d_work = torch.zeros(int(lib.dvda_pcm_hip_workspace_words(n_sec)), dtype=torch.int32, device=dev)
+    pstream = torch.cuda.Stream(dev)
+    pcm_samples = n_sec * 110 * 6
+    pcm_bytes = n_sec * 2048 + pcm_samples * 4
+
+    def pcm_step():
+        hip._check(lib.dvda_pcm_hip_decode_sectors(d_sec.data_ptr(), n_sec, 24, 6, d_pcm.data_ptr(), cap,
+                                                   d_work.data_ptr(), pstream.cuda_stream), "pcm")
+
+    def pcm_timed(k):
+        for _ in range(2):
+            pcm_step()
+        pstream.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            pcm_step()
+        pstream.synchronize()
+        return time.perf_counter() - t0
+
+    # each kind alone
+    dt_m, kms, _ = mlp.timed(steps, warmup)
+    k_pcm = steps * 4
+    dt_p = pcm_timed(k_pcm)
+    # both at once: the PCM thread keeps going until the MLP thread is through
+    done = threading.Event()
+    count = [0]
+    t_p = [0.0]
+
+    def pcm_loop():
+        torch.cuda.set_device(dev)
+        t0 = time.perf_counter()
+        while not done.is_set():
+            pcm_step()
+            count[0] += 1
+            if count[0] % 8 == 0:
+                pstream.synchronize()
+        pstream.synchronize()
+        t_p[0] = time.perf_counter() - t0
+
+    th = threading.Thread(target=pcm_loop)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    th.start()
+    dt_both, kms_both, _ = mlp.timed(steps, 1)
+    done.set()
+    th.join()
+    wall = time.perf_counter() - t0
+    mlp.check_status()
+    picks = np.linspace(0, mlp.n_streams - 1, num=4, dtype=np.int64)
+    ok = mlp.verify_sample(flat, offs, sizes, picks)
+    fr, bad = ctypes.c_uint64(), ctypes.c_uint32()
+    lib.dvda_pcm_hip_result(d_work.data_ptr(), n_sec, ctypes.byref(fr), ctypes.byref(bad), pstream.cuda_stream)
+    ok = ok and bad.value == 0 and fr.value == n_sec * 110 and \
+        bool(np.array_equal(d_pcm.view(6, cap)[:, :unit_frames].cpu().numpy(), src.T))
+    if not ok:
+        raise SystemExit("sub-record mixed_corpus_c5: results differ from the oracles")
+    mlp_bytes = mlp.comp_bytes + 4 * mlp.samples
+    both_samples = mlp.samples * steps + pcm_samples * count[0]
+    both_bytes = mlp_bytes * steps + pcm_bytes * count[0]
+    rec = {"unit": "Msamples/s",
+           "mlp_192k_alone": {"value": round(mlp.samples * steps / dt_m / 1e6, 1), "kernel_ms": round(kms, 4),
+                              "GBs": round(mlp_bytes * steps / dt_m / 1e9, 1), "titles": mlp.n_streams},
+           "raw_pcm_alone": {"value": round(pcm_samples * k_pcm / dt_p / 1e6, 1),
+                             "GBs": round(pcm_bytes * k_pcm / dt_p / 1e9, 1), "sectors": n_sec},
+           "together": {"value": round(both_samples / wall / 1e6, 1), "GBs": round(both_bytes / wall / 1e9, 1),
+                        "frac_of_hbm_peak": round(both_bytes / wall / 1e9 / HBM_PEAK_GBS, 4),
+                        "mlp_value": round(mlp.samples * steps / dt_both / 1e6, 1), "mlp_kernel_ms": round(kms_both, 4),
+                        "pcm_value": round(pcm_samples * count[0] / t_p[0] / 1e6, 1), "pcm_passes": count[0],
+                        "seconds": round(wall, 4)},
+           "bit_exact_sample": ok,
+           "note": "BASELINE configs[4] on one GPU: 6-ch/192 kHz MLP titles (256 access units each) on one HIP stream, "
+                   "6-ch/24-bit raw-PCM AOB sectors on another, one host thread each; bytes are algorithmic "
+                   "(compressed or sector bytes in + int32 PCM out)"}
+    sys.stderr.write("bench: sub-record mixed_corpus_c5 %.1f s\n" % (time.perf_counter() - t_run))
+    mlp.close()
+    del mlp, d_sec, d_pcm, d_work
+    torch.cuda.empty_cache()
+    return rec
 
 
 def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, steps, wav24=False):
