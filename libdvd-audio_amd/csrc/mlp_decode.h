@@ -1583,8 +1583,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             if ((int32_t)(rd.fillpos - rd.next) < 12)
                 DVDA_COV(14);                // synchronous ring top-up inside the row loop
             rd.ensure(12);
+            DVDA_STAMP(0);
             rd.crc_catchup(rd.next);
         }
+        DVDA_STAMP(7);      // parity/CRC catch-up
         // both 64-byte halves of a 128-byte line are requested in consecutive rows, while the line
         // is still in L2 (one HBM fetch per line); a new line is started when half the ring is free
         const int32_t ahead_now = (int32_t)(rd.fillpos - rd.next);
