@@ -260,8 +260,13 @@ __device__ __forceinline__ void fir_step8(int32_t (&h)[8], const int32_t (&c)[8]
     q.w = fir_step_rot<7>(h, c, shift, qmask, q.w);
 }
 
+#ifndef DVDA_CHAIN_DEPTH
+#define DVDA_CHAIN_DEPTH 8
+#endif
+constexpr int CHAIN_DEPTH = DVDA_CHAIN_DEPTH;     // units of eight PCM frames a lane of k_chain_filter keeps in flight
+
 // One lane per (chain, substream, channel slot): 16 lanes per chain (2 substreams x 8 slots, 6 used).
-__global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chain_filter(ChainArgs a)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ci = g >> 4, sub = (g >> 3) & 1u, k = g & 7u;
@@ -338,115 +343,199 @@ __global__ __launch_bounds__(64) void k_chain_filter(ChainArgs a)
                 const uint32_t plane = min_ch + k;
                 int4 *const Q = reinterpret_cast<int4 *>(P) + plane;         // group g (4 rows) of this plane: Q[g * 8]
                 const uint32_t *rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
-                uint32_t row = 0;
-                uint32_t next_row = rp[0];
-                // ---- a block that sets filter parameters starts at `row` (src/mlp.c:1033-1068, 1260-1270)
-                auto apply_records = [&]() {
-                    while (next_row == row) {
-                        const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
-                        if ((mask >> k) & 1u) {
+                const uint32_t nu = R >> 3;         // units of eight PCM frames: two 16-byte pieces of this lane's plane
+                                                    // (a segment is a whole number of 40-frame access units)
+                if (meta & 0x200u) {
+                    // ---- some block of this segment runs IIR taps (rare on discs): unit by unit, frame by frame
+                    uint32_t row = 0;
+                    uint32_t next_row = rp[0];
+                    // a block that sets filter parameters starts at `row` (src/mlp.c:1033-1068, 1260-1270)
+                    auto apply_records = [&]() {
+                        while (next_row == row) {
+                            const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
+                            if ((mask >> k) & 1u) {
+                                const uint32_t below = (1u << k) - 1u;
+                                const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) +
+                                                    BREC_IIR_WORDS * __popc(imask & below);
+                                const uint32_t pk = w[0];
+                                shift = pk & 0xFu;
+                                qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    c[2 * j] = lo16(w[1 + j]);
+                                    c[2 * j + 1] = hi16(w[1 + j]);
+                                }
+                                if (pk & (1u << 16)) {
+                                    // the block (re)sets the IIR: taps and the history it starts from, or none
+                                    iir = ((pk >> 12) & 0xFu) != 0;
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) {
+                                        ic[2 * j] = iir ? lo16(w[5 + j]) : 0;
+                                        ic[2 * j + 1] = iir ? hi16(w[5 + j]) : 0;
+                                    }
+#pragma unroll
+                                    for (int j = 0; j < 8; j++)
+                                        ih[j] = iir ? (int32_t)w[9 + j] : 0;
+                                }
+                            }
+                            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
+                            next_row = rp[0];
+                        }
+                    };
+                    auto slow_step = [&](int32_t residual) {
+                        apply_records();
+                        const int32_t v = iir ? iir_step_one(h, c, ih, ic, shift, qmask, residual)
+                                              : fir_step_one(h, c, shift, qmask, residual);
+                        row++;
+                        return v;
+                    };
+                    for (uint32_t u = 0; u < nu; u++) {
+                        int4 *W = Q + (size_t)u * 16u;
+                        int4 x = W[0], y = W[8];
+                        x.x = slow_step(x.x);
+                        x.y = slow_step(x.y);
+                        x.z = slow_step(x.z);
+                        x.w = slow_step(x.w);
+                        y.x = slow_step(y.x);
+                        y.y = slow_step(y.y);
+                        y.z = slow_step(y.z);
+                        y.w = slow_step(y.w);
+                        W[0] = x;
+                        W[8] = y;
+                    }
+                } else {
+                    // ---- FIR taps only.  CHAIN_DEPTH units are in flight per lane: a lane has nothing else to hide
+                    //      the memory latency behind, and there is about one wave per SIMD.  The loads are
+                    //      unconditional (past the segment's end the last unit is asked for again) and whole turns
+                    //      of CHAIN_DEPTH units are straight-line code, so the waits the compiler inserts count
+                    //      exactly the operations issued since -- round 2's first version loaded under per-lane
+                    //      conditions and restarted its pipeline at every block that set parameters (on real
+                    //      streams: every block): 34 instructions per PCM frame and most of the time spent waiting.
+                    //      Here the eight steps of a unit run with the history renamed, not moved (fir_step_rot),
+                    //      a block's parameters wait in registers from the block before it on (five words: shift,
+                    //      quant step, eight taps) and take effect between two steps without the pipeline noticing.
+                    constexpr int D = CHAIN_DEPTH;
+                    uint32_t left = 0;               // PCM frames until the next block that sets parameters
+                    uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nw4 = 0;    // its record for this slot, if it has one
+                    bool n_has = false;
+                    uint32_t tgt = 0;                // the frame it counts down to (records carry absolute frames)
+                    auto preload = [&](uint32_t row_now) {
+                        const uint32_t nr = rp[0];
+                        n_has = false;
+                        tgt = nr;
+                        left = nr - row_now;                                  // (terminator: 0xFFFFFFFF, never reached)
+                        if (nr != 0xFFFFFFFFu) {
+                            const uint32_t m = rp[1];
+                            const uint32_t mask = m & 0xFFu, imask = (m >> 8) & 0xFFu;
                             const uint32_t below = (1u << k) - 1u;
                             const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) +
                                                 BREC_IIR_WORDS * __popc(imask & below);
-                            const uint32_t pk = w[0];
-                            shift = pk & 0xFu;
-                            qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                c[2 * j] = lo16(w[1 + j]);
-                                c[2 * j + 1] = hi16(w[1 + j]);
+                            if ((mask >> k) & 1u) {
+                                n_has = true;
+                                nw0 = w[0];
+                                nw1 = w[1];
+                                nw2 = w[2];
+                                nw3 = w[3];
+                                nw4 = w[4];
                             }
-                            if (pk & (1u << 16)) {
-                                // the block (re)sets the IIR: taps and the history it starts from, or none
-                                iir = ((pk >> 12) & 0xFu) != 0;
+                            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
+                        }
+                    };
+                    (void)ih;
+                    (void)ic;
+                    preload(0);
+                    // a block starts at the frame the countdown has reached: its parameters take effect, the record
+                    // behind it is asked for
+                    // (no loop in here: records are eight frames or more apart -- the parser checks the block size --
+                    //  and a loop around the loads would cost the compiler its count of what is in flight)
+                    auto apply = [&]() {
+                        if (n_has) {
+                            shift = nw0 & 0xFu;
+                            qmask = 0xFFFFFFFFu << ((nw0 >> 4) & 0xFu);
+                            c[0] = lo16(nw1);
+                            c[1] = hi16(nw1);
+                            c[2] = lo16(nw2);
+                            c[3] = hi16(nw2);
+                            c[4] = lo16(nw3);
+                            c[5] = hi16(nw3);
+                            c[6] = lo16(nw4);
+                            c[7] = hi16(nw4);
+                        }
+                        preload(tgt);
+                    };
+                    uint32_t u = 0;
+                    while (u < nu) {
+                        if (left != 0 && left < 8u) {
+                            // ---- a block starts inside this unit (encoders cut blocks at multiples of eight frames;
+                            //      the test generator does not): frame by frame, the history moved, not renamed
+                            int4 *W = Q + (size_t)u * 16u;
+                            int4 x = W[0], y = W[8];
+                            auto one = [&](int32_t residual) {
+                                while (left == 0)
+                                    apply();
+                                left--;
+                                return fir_step_one(h, c, shift, qmask, residual);
+                            };
+                            x.x = one(x.x);
+                            x.y = one(x.y);
+                            x.z = one(x.z);
+                            x.w = one(x.w);
+                            y.x = one(y.x);
+                            y.y = one(y.y);
+                            y.z = one(y.z);
+                            y.w = one(y.w);
+                            W[0] = x;
+                            W[8] = y;
+                            u++;
+                            continue;
+                        }
+                        // ---- units from here to the segment's end, or to the next one a block starts inside of
+                        int4 ua[D], ub[D];
+                        auto fetch = [&](int4 &x, int4 &y, uint32_t w) {
+                            const int4 *N = Q + (size_t)(w < nu ? w : nu - 1u) * 16u;
+                            x = N[0];
+                            y = N[8];
+                        };
 #pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    ic[2 * j] = iir ? lo16(w[5 + j]) : 0;
-                                    ic[2 * j + 1] = iir ? hi16(w[5 + j]) : 0;
+                        for (int i = 0; i < D; i++)
+                            fetch(ua[i], ub[i], u + (uint32_t)i);
+                        bool stop = false;
+                        // (whole turns of D units are straight-line code but for the two tests per unit)
+                        for (; !stop && u + D <= nu; ) {
+#pragma unroll
+                            for (int i = 0; i < D; i++) {
+                                if (left == 0)
+                                    apply();
+                                if (left < 8u) {
+                                    stop = true;
+                                    break;
                                 }
+                                fir_step8(h, c, shift, qmask, ua[i], ub[i]);
+                                left -= 8u;
+                                int4 *W = Q + (size_t)u * 16u;
+                                W[0] = ua[i];
+                                W[8] = ub[i];
+                                fetch(ua[i], ub[i], u + (uint32_t)D);
+                                u++;
+                            }
+                        }
+                        if (!stop) {
 #pragma unroll
-                                for (int j = 0; j < 8; j++)
-                                    ih[j] = iir ? (int32_t)w[9 + j] : 0;
+                            for (int i = 0; i < D; i++) {
+                                if (u < nu) {
+                                    if (left == 0)
+                                        apply();
+                                    if (left < 8u)
+                                        break;
+                                    fir_step8(h, c, shift, qmask, ua[i], ub[i]);
+                                    left -= 8u;
+                                    int4 *W = Q + (size_t)u * 16u;
+                                    W[0] = ua[i];
+                                    W[8] = ub[i];
+                                    u++;
+                                }
                             }
                         }
-                        rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
-                        next_row = rp[0];
-                    }
-                };
-                while (row < R) {
-                    apply_records();
-                    const uint32_t run_end = (next_row > row && next_row < R) ? next_row : R;
-                    if (__builtin_expect(iir, 0)) {
-                        while (row < run_end) {
-                            int32_t *e = P + res_index(row, plane);
-                            *e = iir_step_one(h, c, ih, ic, shift, qmask, *e);
-                            row++;
-                        }
-                    }
-                    while (row < run_end && (row & 3u)) {
-                        int32_t *e = P + res_index(row, plane);
-                        *e = fir_step_one(h, c, shift, qmask, *e);
-                        row++;
-                    }
-                    // Sixteen PCM frames per turn, the next thirty-two already on their way (a lane has nothing
-                    // else to hide the memory latency behind).  Three register sets take turns as "in work",
-                    // "next" and "being loaded" -- by position in the unrolled loop, not by copying: a move out
-                    // of a register whose load is still in flight waits for it, which is how a first version of
-                    // this loop waited for every load it had just issued (vmcnt(0) per turn: 9.6 ms instead of
-                    // 6.6 ms on 4 096 chained titles).  (Letting the loads run on across the rows where blocks
-                    // change parameters was tried too: the row-by-row path it needs inside the turn costs the
-                    // compiler 240 bytes of scratch per lane and the kernel a factor of two.)
-                    if (row + 16 <= run_end) {
-                        int4 *G = Q + (size_t)(row >> 2) * 8u;
-                        int4 s0[4], s1[4], s2[4];
-                        auto load = [&](int4 (&d)[4], uint32_t ahead) {      // rows [row + ahead, row + ahead + 16)
-                            if (row + ahead + 16 <= run_end) {
-                                const int4 *N = G + (ahead >> 2) * 8u;
-                                d[0] = N[0];
-                                d[1] = N[8];
-                                d[2] = N[16];
-                                d[3] = N[24];
-                            }
-                        };
-                        auto work = [&](int4 (&d)[4]) {
-                            fir_step8(h, c, shift, qmask, d[0], d[1]);
-                            fir_step8(h, c, shift, qmask, d[2], d[3]);
-                            G[0] = d[0];
-                            G[8] = d[1];
-                            G[16] = d[2];
-                            G[24] = d[3];
-                            row += 16;
-                            G += 32;
-                        };
-                        load(s0, 0);
-                        load(s1, 16);
-                        for (;;) {
-                            load(s2, 32);
-                            work(s0);
-                            if (row + 16 > run_end)
-                                break;
-                            load(s0, 32);
-                            work(s1);
-                            if (row + 16 > run_end)
-                                break;
-                            load(s1, 32);
-                            work(s2);
-                            if (row + 16 > run_end)
-                                break;
-                        }
-                    }
-                    while (row + 8 <= run_end) {
-                        int4 *G = Q + (size_t)(row >> 2) * 8u;
-                        int4 v0 = G[0], v1 = G[8];
-                        fir_step8(h, c, shift, qmask, v0, v1);
-                        G[0] = v0;
-                        G[8] = v1;
-                        row += 8;
-                    }
-                    while (row < run_end) {
-                        int32_t *e = P + res_index(row, plane);
-                        *e = fir_step_one(h, c, shift, qmask, *e);
-                        row++;
                     }
                 }
             }

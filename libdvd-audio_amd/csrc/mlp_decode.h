@@ -882,6 +882,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t slots_w = 2;             // wave-uniform: slots some lane of the wave carries (slots 0, 1 always run)
     bool have_restart = false;
     uint32_t iir_any = 0;             // bit k: slot k has IIR order > 0
+    bool seg_iir = false;             // chain parse pass: some block of this segment ran IIR taps (seg_meta bit 9)
 
     uint64_t cur = sr.off;            // byte offset of the next frame
     uint64_t ss_end_bit = 0;          // end of this lane's substream data (bits, absolute)
@@ -979,7 +980,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                 a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + seg_lane] = st[k][j];
                     }
                     if (GENERAL || PARSE)
-                        a.seg_meta[seg_lane] = min_ch | (max_ch << 4) | (1u << 8);
+                        a.seg_meta[seg_lane] = min_ch | (max_ch << 4) | (1u << 8) | (seg_iir ? 1u << 9 : 0u);
                     if (PARSE && brec)
                         brec[0] = brec[1] = 0xFFFFFFFFu;         // end of this (segment, substream)'s records
                     bool go_on = false;
@@ -1477,6 +1478,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     err = ST_ENVELOPE;
                 }
                 hdr_parsed = true;
+                if (PARSE && iir_any)
+                    seg_iir = true;
                 if (PARSE && ok && chg_mask) {
                     brec[0] = rows_done;                // first PCM frame (of the segment) the record applies to
                     brec[1] = chg_mask | (iir_mask << 8);
