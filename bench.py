@@ -460,6 +460,12 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     flat, offs, sizes, frames = syn.batch(one, 7, 1)
     run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 512 access units (the low-parallelism case)")
+    long_one = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=8192, profile=1,
+                            features=syn.SF["CHAINED"])
+    flat, offs, sizes, frames = syn.batch(long_one, 9, 1)
+    run("chained_single_long_title", flat, offs, sizes, frames, np.full(1, 6), 8192 // 8 + 2, 1, args.layout, 0,
+        benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 8 192 access units (68 s of 96 kHz audio): the filter "
+                                   "pass's serial recurrence is what bounds it")
     out["mixed_corpus_c5"] = mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup)
     return out
 

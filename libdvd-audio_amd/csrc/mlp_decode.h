@@ -644,7 +644,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     constexpr int THREADS = WSPEC ? WS_THREADS : DEC_THREADS;
     constexpr int WAVES = THREADS / 64;
     constexpr int GROUPS = WSPEC ? WAVES / 2 : 1;
-    constexpr int TP = PARSE ? 8 : 6;                             // staged planes: channels (+ bypassed LSBs, seed)
+    constexpr int TP = 6;                                         // staged planes: the channels (the chain parse pass keeps
+                                                                  // a row's bypassed LSBs and noise seed in registers: with two
+                                                                  // more planes its workgroup was 34 KB of LDS and only three fit a CU)
     // (the sequential pass keeps the per-lane test: a lane there walks on through segments whose channel
     //  ranges may differ, and a channel's history outlives the segments that do not carry it)
     constexpr bool USLOT = DVDA_UNIFORM_SLOTS && !GENERAL;
@@ -894,6 +896,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint64_t row = row0;              // next output PCM frame index
     uint32_t rows_written = 0;
     uint32_t rows_done = 0;           // rows decoded by this lane (lockstep across the wave)
+    int32_t pq_b[OUT_ROWS] = {0, 0, 0, 0}, pq_s[OUT_ROWS] = {0, 0, 0, 0};   // chain parse pass: see TP
     uint32_t au_idx = 0;              // chain parse pass: PCM-yielding access units of the segment so far
     uint32_t drops_seen = 0;          // frames dropped so far (major sync with other stream parameters)
 
@@ -1801,8 +1804,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     if constexpr (PARSE) {
                         // ---- the row's residuals in MLP channel order, its bypassed LSBs and the noise seed it
                         //      is rematrixed with (stepped once per PCM frame, src/mlp.c:1327-1334)
-                        ch[6] = (int32_t)bypass_bits;
-                        ch[7] = (int32_t)seed;
+#pragma unroll
+                        for (int j = 0; j < OUT_ROWS - 1; j++) {
+                            pq_b[j] = pq_b[j + 1];
+                            pq_s[j] = pq_s[j + 1];
+                        }
+                        pq_b[OUT_ROWS - 1] = (int32_t)bypass_bits;
+                        pq_s[OUT_ROWS - 1] = (int32_t)seed;
                         const uint32_t shifted = (seed >> 7) & 0xFFFFu;
                         seed = (seed << 16) ^ shifted ^ (shifted << 5);
                     } else {
@@ -2128,6 +2136,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             for (int c = 0; c < TP; c++)
                 DVDA_STORE_V4_AT(dst, 16 * c, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane],
                                  T[c][2][GENERAL ? 0 : lane], T[c][3][GENERAL ? 0 : lane]);
+            // planes 6 and 7: the four frames' bypassed LSBs and noise seeds (oldest first)
+            DVDA_STORE_V4_AT(dst, 16 * 6, pq_b[0], pq_b[1], pq_b[2], pq_b[3]);
+            DVDA_STORE_V4_AT(dst, 16 * 7, pq_s[0], pq_s[1], pq_s[2], pq_s[3]);
         }
         if (!GENERAL && !PARSE && !ILV && flush) {
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
