@@ -34,12 +34,16 @@ def main():
     ap.add_argument("--aus", type=int, default=16384)
     ap.add_argument("--tmp", default=None)
     ap.add_argument("--no-tier-b", action="store_true")
+    ap.add_argument("--chained", action="store_true",
+                    help="tracks as an encoder writes them: no raw lead-in at the restart points, the FIR history runs "
+                         "through each track (the chain passes decode them)")
     a = ap.parse_args()
     syn, disc = pkg.synth, pkg.disc
     tool = pkg._build.build_tool()
     ref = os.path.join(ROOT, "oracle", "_ref", "dvda2wav_ref")
     with tempfile.TemporaryDirectory(dir=a.tmp) as tmp:
-        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=a.aus)
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=a.aus, profile=1 if a.chained else 0,
+                           features=syn.SF["CHAINED"] if a.chained else 0)
         tracks, samples = [], 0
         for t in range(a.tracks):
             b, f = syn.stream(cfg, 100 + t)
@@ -47,7 +51,7 @@ def main():
             samples += f * 6
         ats = disc.write_disc_titles(tmp, [tracks])
         aob = os.path.getsize(os.path.join(ats, "ATS_01_1.AOB"))
-        res = {"tracks": a.tracks, "samples": samples, "aob_bytes": aob}
+        res = {"tracks": a.tracks, "samples": samples, "aob_bytes": aob, "chained": bool(a.chained)}
         env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "libdvd-audio_amd") + ":/opt/rocm/lib:" +
                    os.environ.get("LD_LIBRARY_PATH", ""))
         outs = {}
