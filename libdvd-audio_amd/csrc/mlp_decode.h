@@ -655,7 +655,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // two-wave layout, per row of a tile: "the odd wave's channels are there" | version of the rematrix
     // parameters the row goes with << 8 | its bypassed LSBs
     __shared__ uint32_t s_tag[WSPEC ? GROUPS : 1][2][OUT_ROWS][WSPEC ? 64 : 1];
-    __shared__ int32_t s_xch[SIDE ? WAVES : 1][MAXCH][SIDE ? 64 : 1];
+    // (the chain parse pass needs no exchange tile: both lanes of a segment put their residuals straight into
+    //  the staging column of the lane that flushes it -- 4 KB less, four workgroups per CU instead of three)
+    constexpr bool XCH = SIDE && !PARSE;
+    __shared__ int32_t s_xch[XCH ? WAVES : 1][MAXCH][XCH ? 64 : 1];
     __shared__ uint32_t s_alive[2][WAVES];
     // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
     // (last substream, odd wave) for the lane that applies them (first substream, even wave)
@@ -1828,7 +1831,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #pragma unroll
                         for (int c = 0; c < 6; c++)
                             Td[c * 64] = ch[c];
-                    } else {
+                    } else if constexpr (!(PARSE && PAIRED)) {       // (chain parse pass in lane pairs: already there)
 #pragma unroll
                         for (int c = 0; c < TP; c++)
                             T[c][ph][GENERAL ? 0 : lane] = ch[c];
@@ -2008,20 +2011,36 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
         } else if (in_row) {
             row_head();
-            if (PAIRED) {
-                // substreams of one segment sit in adjacent lanes; exchange through LDS
-                const int slot0 = PAIRED ? (lane & ~1) : 0;
-                int32_t(*X)[SIDE ? 64 : 1] = s_xch[SIDE ? wv : 0];
+            if (PAIRED && PARSE) {
+                // substreams of one segment sit in adjacent lanes; the residuals go straight into the tile column of
+                // the lane that flushes it (the last substream's: the odd lane of a two-substream segment)
+                const int col = (lane & ~1) + (S == 2u ? 1 : 0);
+                int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
+                const uint32_t ph = rows_done & (OUT_ROWS - 1);
 #pragma unroll
                 for (int k = 0; k < NS; k++)
-                    if ((uint32_t)k < nslots && min_ch + k < MAXCH)
-                        X[min_ch + k][slot0] = val[k];
+                    if ((uint32_t)k < nslots && min_ch + k < (uint32_t)TP)
+                        T[(min_ch + k) < (uint32_t)TP ? min_ch + k : 0][ph][GENERAL ? 0 : col] = val[k];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int c = 0; c < MAXCH; c++)
-                    ch[c] = X[c][slot0];
+                    ch[c] = 0;
+            } else if (PAIRED) {
+                // substreams of one segment sit in adjacent lanes; exchange through LDS
+                const int slot0 = PAIRED ? (lane & ~1) : 0;
+                int32_t(*X)[XCH ? 64 : 1] = s_xch[XCH ? wv : 0];
+#pragma unroll
+                for (int k = 0; k < NS; k++)
+                    if ((uint32_t)k < nslots && min_ch + k < MAXCH)
+                        X[min_ch + k][XCH ? slot0 : 0] = val[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < MAXCH; c++)
+                    ch[c] = X[c][XCH ? slot0 : 0];
             } else {
                 // one lane per segment: the single substream starts at channel 0 (checked at the
                 // restart header)

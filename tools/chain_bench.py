@@ -15,9 +15,10 @@ import libdvd_audio_amd as pkg  # noqa: E402
 
 syn, hip = pkg.synth, pkg.hipdec
 n_titles, n_aus = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 128
+n_ss = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # substreams per title (2: ch 0-1 | ch 2-5, what 6-channel discs carry)
 dev = torch.device("cuda", 0)
 for name, feats in (("independent", 0), ("chained", syn.SF["CHAINED"])):
-    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=n_aus, profile=1 if feats else 0, features=feats)
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=n_ss, n_aus=n_aus, profile=1 if feats else 0, features=feats)
     flat, offs, sizes, frames = syn.batch(cfg, 1, n_titles)
     d_bytes = torch.from_numpy(flat).to(dev)
     d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
@@ -27,7 +28,7 @@ for name, feats in (("independent", 0), ("chained", syn.SF["CHAINED"])):
     d_oo = torch.from_numpy(out_off).to(dev)
     d_st = torch.from_numpy(frames.astype(np.int64)).to(dev)
     d_pcm = torch.empty(int(frames.sum()) * 6, dtype=torch.int32, device=dev)
-    ctx = hip.Context(0, n_titles, n_titles * (n_aus // 8 + 2), lanes_per_segment=1)
+    ctx = hip.Context(0, n_titles, n_titles * (n_aus // 8 + 2), lanes_per_segment=0)
     best = 1e9
     for it in range(3):
         torch.cuda.synchronize()
