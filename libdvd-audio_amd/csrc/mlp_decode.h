@@ -21,8 +21,9 @@
 //   * PCM leaves as 16-byte stores, staged four frames at a time in an LDS tile and issued after
 //     the ring commit so that no s_waitcnt counts them: planar layout = one store per channel into six
 //     places, frame-major layout = one contiguous run per lane (template parameter ILV)
-//   * two-substream streams: one wave per substream in the fast pass, a row's channels cross through
-//     LDS at one workgroup barrier per row (WSPEC)
+//   * two-substream streams: one wave per substream in the fast pass; the wave that rematrixes runs four
+//     rows behind the other, the rows cross through the doubled staging tile, one workgroup barrier per
+//     four rows (WSPEC)
 //   * Huffman codes are decoded arithmetically (the three books share one
 //     structure, mlp_tables.h) -- no table, no LDS latency on the parse chain
 //
