@@ -49,6 +49,7 @@ struct ChainArgs {
     const uint64_t *out_stride;
     uint32_t interleaved;
     uint32_t wav_bits;             // 0, or 16 / 24: packed WAV payload instead of int32 values
+    uint32_t remat_blocks;         // k_chain_rematrix: 256-frame blocks per segment the grid is sized for
 };
 
 __device__ __forceinline__ uint32_t chain_n_seg(const ChainArgs &a)
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
 {
     const uint32_t n = chain_n_seg(a);
-    const uint32_t j = blockIdx.x;
+    // grid: the row blocks of a segment are neighbours (a segment's planes are one run of memory)
+    const uint32_t j = blockIdx.x / a.remat_blocks, by = blockIdx.x % a.remat_blocks;
     if (j >= a.plan[n].y)
         return;
     const uint32_t seg = a.def_list[j];
@@ -577,10 +579,10 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     const StreamRec sr = a.streams[r.stream];
     const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
     const uint32_t R = (r.nframes - r.ndrop) * rpa;
-    const uint32_t row = blockIdx.y * 256u + threadIdx.x;
+    const uint32_t row = by * 256u + threadIdx.x;
     const uint64_t row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
     const uint64_t out_stride = a.out_stride[r.stream];
-    if (blockIdx.y * 256u >= R)
+    if (by * 256u >= R)
         return;                                     // (the grid is sized for the longest segment)
     if (row == 0) {
         a.seg_rows[seg] = R;
@@ -639,8 +641,8 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     int32_t *out = a.pcm + a.out_off[r.stream];
     if (a.wav_bits) {
         const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
-        const uint64_t blk_row0 = row0 + (uint64_t)blockIdx.y * 256u;            // first output row of the block
-        uint32_t nvalid = R - blockIdx.y * 256u < 256u ? R - blockIdx.y * 256u : 256u;
+        const uint64_t blk_row0 = row0 + (uint64_t)by * 256u;            // first output row of the block
+        uint32_t nvalid = R - by * 256u < 256u ? R - by * 256u : 256u;
         if (blk_row0 >= out_stride)
             nvalid = 0;
         else if (blk_row0 + nvalid > out_stride)

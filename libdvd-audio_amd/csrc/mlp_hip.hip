@@ -613,7 +613,8 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         // filter: 16 lanes per chain (at most one chain per deferred segment)
         hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);
         // rematrix: one lane per PCM frame
-        hipLaunchKernelGGL(k_chain_rematrix, dim3(segs, (max_rows + 255) / 256), dim3(256), 0, st, ca);
+        ca.remat_blocks = (max_rows + 255) / 256 ? (max_rows + 255) / 256 : 1;
+        hipLaunchKernelGGL(k_chain_rematrix, dim3(segs * ca.remat_blocks), dim3(256), 0, st, ca);
         HIP_TRY(hipMemsetAsync(&c->d_summary->seq_streams, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
