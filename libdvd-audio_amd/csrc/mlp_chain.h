@@ -49,7 +49,7 @@ struct ChainArgs {
     const uint64_t *out_stride;
     uint32_t interleaved;
     uint32_t wav_bits;             // 0, or 16 / 24: packed WAV payload instead of int32 values
-    uint32_t remat_blocks;         // k_chain_rematrix: 256-frame blocks per segment the grid is sized for
+    uint32_t remat_blocks;         // k_chain_rematrix: workgroups per segment (1 unless segments are very long)
 };
 
 __device__ __forceinline__ uint32_t chain_n_seg(const ChainArgs &a)
@@ -567,8 +567,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
 {
     const uint32_t n = chain_n_seg(a);
-    // grid: the row blocks of a segment are neighbours (a segment's planes are one run of memory)
-    const uint32_t j = blockIdx.x / a.remat_blocks, by = blockIdx.x % a.remat_blocks;
+    // one workgroup per deferred segment (times remat_blocks for very long ones): what it has to look up about the
+    // segment -- five dependent loads -- is looked up once, not once per 256 PCM frames
+    const uint32_t j = blockIdx.x / a.remat_blocks, by0 = blockIdx.x % a.remat_blocks;
     if (j >= a.plan[n].y)
         return;
     const uint32_t seg = a.def_list[j];
@@ -579,12 +580,9 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     const StreamRec sr = a.streams[r.stream];
     const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
     const uint32_t R = (r.nframes - r.ndrop) * rpa;
-    const uint32_t row = by * 256u + threadIdx.x;
     const uint64_t row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
     const uint64_t out_stride = a.out_stride[r.stream];
-    if (by * 256u >= R)
-        return;                                     // (the grid is sized for the longest segment)
-    if (row == 0) {
+    if (by0 == 0 && threadIdx.x == 0) {
         a.seg_rows[seg] = R;
         if (row0 + R > out_stride)
             atomicOr(&a.seg_status[seg], ST_OVERFLOW);          // rows = the size needed
@@ -597,6 +595,9 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     // (256 rows, and a segment's first row is a multiple of 40)
     __shared__ uint8_t s_b[256 * 6 * 3];
     const uint4 pl = a.plan[seg];
+    int32_t *out = a.pcm + a.out_off[r.stream];
+    for (uint32_t by = by0; by * 256u < R; by += a.remat_blocks) {
+    const uint32_t row = by * 256u + threadIdx.x;
     int32_t ch[MAXCH];
 #pragma unroll
     for (int c = 0; c < MAXCH; c++)
@@ -638,7 +639,6 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
         }
     }
     const uint64_t orow = row0 + row;
-    int32_t *out = a.pcm + a.out_off[r.stream];
     if (a.wav_bits) {
         const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
         const uint64_t blk_row0 = row0 + (uint64_t)by * 256u;            // first output row of the block
@@ -667,14 +667,16 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
             reinterpret_cast<uint32_t *>(ob)[d] = sd[d];
         for (uint32_t b = (nbytes & ~3u) + threadIdx.x; b < nbytes; b += 256u)
             ob[b] = s_b[b];
-        return;
+        __syncthreads();                            // (the next block of frames assembles in the same LDS)
+        continue;
     }
     if (row >= R || orow >= out_stride)
-        return;
+        continue;
 #pragma unroll
     for (int c = 0; c < 6; c++)
         if ((uint32_t)c < nch_out)
             out[a.interleaved ? orow * nch_out + nib(wavepk, c) : (uint64_t)nib(wavepk, c) * out_stride + orow] = ch[c];
+    }
 }
 
 } // namespace mlp

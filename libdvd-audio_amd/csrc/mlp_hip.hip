@@ -613,7 +613,9 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         // filter: 16 lanes per chain (at most one chain per deferred segment)
         hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);
         // rematrix: one lane per PCM frame
-        ca.remat_blocks = (max_rows + 255) / 256 ? (max_rows + 255) / 256 : 1;
+        // (a workgroup walks its segment 256 PCM frames at a time; segments of more than 16 such blocks share
+        //  the walk between several workgroups)
+        ca.remat_blocks = (max_rows + 4095) / 4096 ? (max_rows + 4095) / 4096 : 1;
         hipLaunchKernelGGL(k_chain_rematrix, dim3(segs * ca.remat_blocks), dim3(256), 0, st, ca);
         HIP_TRY(hipMemsetAsync(&c->d_summary->seq_streams, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
