@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/soak.py [N] -- long parity soak on the GPU box: N random generator configurations (all
+"""tools/soak.py [N [SEED]] -- long parity soak on the GPU box: N random generator configurations (all
 feature sets, all channel assignments, 1 and 2 substreams, three sample rates), each decoded by the
 batch tier and compared bit for bit with the oracle.  Diagnostic; the committed tests hold a
 fixed subset of the same cases."""
@@ -16,7 +16,8 @@ from tests import oracle_lib  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 oracle = oracle_lib.Oracle()
 syn, hip = pkg.synth, pkg.hipdec
-rng = np.random.RandomState(12345)
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.RandomState(seed0)
 two = [12, 1, 0x14, 6, 9, 3, 17, 20]
 bad = 0
 batch, meta = [], []
@@ -30,7 +31,7 @@ for i in range(n):
                        n_aus=int(rng.randint(4, 40)), profile=1, features=feats,
                        restart_interval=int(rng.randint(1, 9)))
     try:
-        b, f = syn.stream(cfg, 10000 + i)
+        b, f = syn.stream(cfg, 10000 + i + (seed0 - 12345) * 7919)
     except Exception as e:          # generator refuses a combination
         continue
     batch.append(b)
