@@ -2054,6 +2054,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         DVDA_STAMP(3);
 
         // ---- the prefetched chunk lands in the ring
+#if defined(DVDA_EXP_STAMP)
+        if (!WSPEC) {       // (diagnostic: the wait for the chunk as a share of its own)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DVDA_STAMP(6);
+        }
+#endif
         if (pf) {
             ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3, (rd.fillpos & (RING_DWORDS - 1)) == 0);
             rd.filled();

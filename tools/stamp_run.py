@@ -27,7 +27,7 @@ for it in range(2):
     hip.lib().dvda_mlp_hip_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     hip.lib().dvda_mlp_hip_debug_counters(ctx._h, out)
 names = ["header phase", "prefetch issue / sync fill", "parse+filter (row)", "exchange+rematrix+stage", "ring commit+flush",
-         "loop top", "phase barrier", "parity/CRC catch-up"]
+         "loop top", "phase barrier (two-wave) / wait for the chunk (one-lane)", "parity/CRC catch-up"]
 for role in range(2 if SS == 2 else 1):
     v = np.array(list(out)[8 * role:8 * role + 8], dtype=np.float64)
     print("role", role, "(two-wave layout: 0 = first substream's wave, rematrixes; 1 = last substream's wave)" if SS == 2 else "")
