@@ -125,8 +125,10 @@ void dvda_mlp_hip_destroy(dvda_mlp_hip_ctx *ctx);
  * them, and derives each segment's first output row.  d_bytes must be readable
  * for total_bytes + 64 bytes; stream i occupies
  * [d_stream_off[i], d_stream_off[i] + d_stream_len[i]) and starts 16-byte aligned; the streams' ranges are
- * ascending and do not overlap (a major sync belongs to the one stream whose range holds it: of two streams
- * given the same bytes only one is decoded). */
+ * ascending and do not overlap (a major sync belongs to the one stream whose range holds it).  The ranges are
+ * checked on the device: a stream that starts before the end of a stream in front of it (of two streams given
+ * the same bytes, the second), is misaligned or leaves the buffer is not decoded and carries
+ * DVDA_ST_IRREGULAR (| DVDA_ST_ENVELOPE) -- never a walk outside the buffer. */
 /* (A caller that indexes the same buffers again and again -- a pipeline that reuses its staging buffers -- gets
  * the index's launch sequence replayed as one hipGraph from the third such call on; `stream` must then be a
  * real stream, not NULL.  DVDA_INDEX_GRAPH=0 in the environment switches that off.) */

@@ -726,8 +726,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     if (active) {
         sr = a.seg[segi];
         stream_first = a.streams[sr.stream].first_seg;
-        stream_sync = a.streams[sr.stream].sync;
-        fbase = a.seg_fbase[segi] - a.seg_fbase[stream_first];
+        if (stream_first == 0xFFFFFFFFu) {
+            // a candidate in bytes that belong to no stream (or to a stream whose range the index refused):
+            // it has no frames and no place in the output
+            active = false;
+            stream_first = segi;
+        } else {
+            stream_sync = a.streams[sr.stream].sync;
+            fbase = a.seg_fbase[segi] - a.seg_fbase[stream_first];
+        }
     }
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
     // substream handled by this lane; workspace lane = segment * 2 + substream in every layout and pass

@@ -75,6 +75,7 @@ struct dvda_mlp_hip_ctx {
     uint32_t *d_yield;         // [max_segments]: yield requests of the fast pass (mlp_decode.h, ST_YIELD)
     uint32_t *d_cls;           // [2]: streams with one / two substreams in the batch; [2] = the batch mixes shapes
     uint32_t *d_shape_key;     // [max_streams]
+    uint64_t *d_soff, *d_slen; // [max_streams]: the caller's stream ranges as the index uses them (k_check_ranges)
     uint32_t *d_rank;          // [max_streams]
     uint32_t *d_sorted_cnt;    // [max_streams + 1]
     uint32_t *d_sorted_base;   // [max_streams + 1]
@@ -141,6 +142,8 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_yield);
     (void)hipFree(c->d_cls);
     (void)hipFree(c->d_shape_key);
+    (void)hipFree(c->d_soff);
+    (void)hipFree(c->d_slen);
     (void)hipFree(c->d_rank);
     (void)hipFree(c->d_sorted_cnt);
     (void)hipFree(c->d_sorted_base);
@@ -216,6 +219,8 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_yield, ns * sizeof(uint32_t));
     alloc((void **)&c->d_cls, 4 * sizeof(uint32_t));
     alloc((void **)&c->d_shape_key, (size_t)max_streams * sizeof(uint32_t));
+    alloc((void **)&c->d_soff, (size_t)max_streams * sizeof(uint64_t));
+    alloc((void **)&c->d_slen, (size_t)max_streams * sizeof(uint64_t));
     alloc((void **)&c->d_rank, (size_t)max_streams * sizeof(uint32_t));
     alloc((void **)&c->d_sorted_cnt, ((size_t)max_streams + 1) * sizeof(uint32_t));
     alloc((void **)&c->d_sorted_base, ((size_t)max_streams + 1) * sizeof(uint32_t));
@@ -341,6 +346,51 @@ __global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, u
     }
 }
 
+// The index looks streams up by offset (find_stream: the last stream that starts at or before a byte) and takes a
+// stream's segments to be neighbours in the list of major syncs: the caller's ranges have to be ascending, disjoint,
+// 16-byte aligned and inside the buffer.  Checked here, on the device, instead of trusted: a stream whose range
+// starts before the end of any stream in front of it, is misaligned or leaves the buffer gets length 0 (nothing of
+// it is decoded) and DVDA_ST_IRREGULAR | DVDA_ST_ENVELOPE, and the offsets the index works with are made ascending (max with the
+// furthest end so far) whatever the caller passed.  One workgroup: a running maximum over the streams in order.
+__global__ __launch_bounds__(1024) void k_check_ranges(const uint64_t *__restrict__ off, const uint64_t *__restrict__ len,
+                                                       uint32_t n, uint64_t total_bytes, uint64_t *__restrict__ soff,
+                                                       uint64_t *__restrict__ slen, StreamRec *__restrict__ streams)
+{
+    __shared__ unsigned long long s_max[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    auto end_of = [&](uint32_t i) {
+        const uint64_t o = off[i], l = len[i];
+        return (o <= total_bytes && l <= total_bytes - o) ? o + l : total_bytes;     // (a range that leaves the buffer
+    };                                                                               //  is bad itself; it blocks all of it)
+    unsigned long long m = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const unsigned long long e = end_of(i);
+        m = e > m ? e : m;
+    }
+    s_max[threadIdx.x] = m;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {          // inclusive running maximum over the 1024 parts
+        const unsigned long long v = threadIdx.x >= d ? s_max[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        if (v > s_max[threadIdx.x])
+            s_max[threadIdx.x] = v;
+        __syncthreads();
+    }
+    unsigned long long run = threadIdx.x ? s_max[threadIdx.x - 1] : 0ull;           // furthest end in front of part lo
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint64_t o = off[i], l = len[i];
+        const bool ok = (o & 15u) == 0 && o <= total_bytes && l <= total_bytes - o && o >= run;
+        const uint64_t so = o > run ? o : run;
+        soff[i] = so < total_bytes ? so : total_bytes;
+        slen[i] = ok ? l : 0;
+        if (!ok)
+            streams[i].status = ST_ENVELOPE | (1u << 16);       // (+ DVDA_ST_IRREGULAR: an index finding, kept by k_finalize)
+        const unsigned long long e = end_of(i);
+        run = e > run ? e : run;
+    }
+}
+
 // the index's kernels, in order, on `st`
 static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_bytes, uint64_t total_bytes,
                           const uint64_t *d_stream_off, const uint64_t *d_stream_len, uint32_t n_streams)
@@ -352,6 +402,10 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
         const uint32_t n_init = n_streams > ms ? n_streams : ms;
         hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
                            n_streams, c->d_seg_status, c->d_seg_rows, c->d_yield, ms);
+        hipLaunchKernelGGL(k_check_ranges, dim3(1), dim3(1024), 0, st, d_stream_off, d_stream_len, n_streams, total_bytes,
+                           c->d_soff, c->d_slen, c->d_streams);
+        d_stream_off = c->d_soff;
+        d_stream_len = c->d_slen;
     }
     hipLaunchKernelGGL(k_sync_mask, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, d_bytes,
                        total_bytes, c->d_masks, c->d_tile_count);

@@ -291,6 +291,9 @@ __device__ __forceinline__ uint32_t find_stream(const uint64_t *__restrict__ str
     return lo;
 }
 
+constexpr uint32_t SEG_DEAD = 1u << 24;   // DVDA_ST_FALSE_SYNC: candidate inside another segment's frame chain,
+                                          // or in bytes that belong to no stream
+
 // Pass 3: one lane per candidate walks the size chain to the next major sync.
 __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes,
                                                const uint64_t *__restrict__ stream_off,
@@ -321,9 +324,13 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     r.ndrop = 0;
     r.prev = 0xFFFFFFFFu;
     uint64_t p = off;
-    if (off >= s_end || ((off - s_begin) & 1) || !sync_frame_at(bytes, off, s_end)) {
-        // candidate in inter-stream padding, at an odd stream offset, or cut by
-        // the stream end: not a segment of this stream
+    const bool outside = off >= s_end;          // bytes between two streams' ranges (or a stream of length 0: a
+                                                // range the index refused): nobody's candidate, nobody's finding
+    if (outside) {
+        r.flags = SEG_DEAD;
+        r.end = off;
+    } else if (((off - s_begin) & 1) || !sync_frame_at(bytes, off, s_end)) {
+        // candidate at an odd stream offset, or cut by the stream end: not a segment of this stream
         r.flags = 1u << 16; // DVDA_ST_IRREGULAR
         r.end = off;
     } else {
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
         const uint64_t prev = cand_off[i - 1];
         first = prev < s_begin;
     }
-    if (first) {
+    if (first && !outside) {
         streams[s].first_seg = i;
         streams[s].sync = r.sync;
         // which decode kernels this batch needs: one lane per segment (one substream) / a lane pair
@@ -381,7 +388,6 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     }
 }
 
-constexpr uint32_t SEG_DEAD = 1u << 24;   // DVDA_ST_FALSE_SYNC: candidate inside another segment's frame chain
 
 // Pass 3b (before the scan): a sync pattern can occur inside payload or padding bytes.  Such a
 // false candidate is not a frame start of the real chain: the previous candidate's size-chain walk

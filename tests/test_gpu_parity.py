@@ -645,6 +645,54 @@ def test_two_substreams_of_any_split(pkg, oracle, ss0):
         assert np.array_equal(got, want)
 
 
+def test_stream_ranges_are_checked_not_trusted(pkg, oracle):
+    """The index looks streams up by offset.  Ranges that are not ascending and disjoint (the same bytes given
+    twice, a list in descending order, a range that leaves the buffer, a misaligned start) used to send its
+    walks anywhere -- a descending list ended in a GPU memory fault.  They are checked on the device: the
+    offending streams are reported and not decoded, the others come out exact."""
+    import torch
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=24)
+    b, f = syn.stream(cfg, 5)
+    want, r, st = oracle.decode(b, 6, f)
+    flat, offs, lens = hip.pack_streams([b, b, b])
+    dev = torch.device("cuda", 0)
+    d_bytes = torch.from_numpy(flat).to(dev)
+    total = len(flat) - 64
+    bad = hip.ST["IRREGULAR"]
+
+    def run(o, l):
+        d_off = torch.from_numpy(np.asarray(o, np.int64)).to(dev)
+        d_len = torch.from_numpy(np.asarray(l, np.int64)).to(dev)
+        oo = torch.from_numpy(np.arange(3, dtype=np.int64) * f * 6).to(dev)
+        stride = torch.from_numpy(np.full(3, f, np.int64)).to(dev)
+        pcm = torch.zeros(3 * f * 6, dtype=torch.int32, device=dev)
+        ctx = hip.Context(0, 3, 64)
+        ctx.index(d_bytes.data_ptr(), total, d_off.data_ptr(), d_len.data_ptr(), 3, 0)
+        ctx.decode(pcm.data_ptr(), oo.data_ptr(), stride.data_ptr(), 0)
+        infos = ctx.stream_info(3)
+        host = pcm.cpu().numpy().reshape(3, 6, f)
+        ctx.close()
+        return infos, host
+
+    infos, host = run(offs, lens)
+    assert all(i.status == 0 and i.pcm_frames == f for i in infos) and all(np.array_equal(host[i], want) for i in range(3))
+    # the same bytes twice: the first copy decodes, the second is reported, the third stream is untouched
+    infos, host = run([offs[0], offs[0], offs[2]], lens)
+    assert infos[0].status == 0 and np.array_equal(host[0], want)
+    assert infos[1].status & bad and infos[1].pcm_frames == 0
+    assert infos[2].status == 0 and np.array_equal(host[2], want)
+    # descending order: nothing behind the first entry is in front of it
+    infos, host = run(offs[::-1].copy(), lens)
+    assert infos[1].status & bad and infos[2].status & bad and infos[1].pcm_frames == 0 and infos[2].pcm_frames == 0
+    assert infos[0].status & ~hip.ST_BENIGN or np.array_equal(host[0], want)
+    # a range that leaves the buffer, a start that is not 16-byte aligned
+    infos, host = run(offs, [lens[0], lens[1], lens[2] + (1 << 20)])
+    assert infos[0].status == 0 and infos[1].status == 0 and infos[2].status & bad
+    infos, host = run([offs[0], offs[1] + 2, offs[2]], [lens[0], lens[1] - 2, lens[2]])
+    assert infos[0].status == 0 and infos[1].status & bad and infos[2].status == 0 and np.array_equal(host[2], want)
+
+
 def test_too_small_a_context_is_reported_not_truncated(pkg, oracle):
     """more major syncs than max_segments used to come back as short PCM with status 0."""
     import torch
