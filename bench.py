@@ -456,6 +456,14 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     flat, offs, sizes, frames = syn.batch(cfgc, 1, 1024)
     run("chained_titles", flat, offs, sizes, frames, np.full(len(sizes), 6), 1024 * (128 // 8 + 2), 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="1 024 titles x 128 access units, every segment depends on the one before")
+    # ---- what a 6-channel disc carries: chained titles with two substreams (ch 0-1 | ch 2-5), at the bench batch's size
+    cfgd = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=2, n_aus=args.aus, profile=1,
+                        features=syn.SF["CHAINED"])
+    flat, offs, sizes, frames = syn.batch(cfgd, 1, args.streams)
+    run("chained_two_substreams", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg + args.streams * args.replicas * 2,
+        args.replicas, args.layout, 0, benign=hip.ST_BENIGN,
+        note="the bench batch as a disc would hold it: every segment continues the FIR history of the one before it, "
+             "two substreams per title; decoded by the chain passes (parse in lane pairs, filter, rematrix)")
     one = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=512, profile=1, features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(one, 7, 1)
     run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 0,
