@@ -702,6 +702,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     bool active = segi < n_seg;
     if (!GENERAL && !PARSE && active && *a.hetero)
         segi = a.lane_seg[item];                  // lanes packed by stream shape
+    if (!GENERAL && !PARSE && segi >= n_seg) {
+        // (a lane the packing dealt nothing: candidates in bytes of no stream take no lane -- lane_seg is filled
+        //  with 0xFFFFFFFF before every packing)
+        active = false;
+        segi = n_seg;
+    }
     if (GENERAL || PARSE) {
         active = item < a.list_n && (!PARSE || item < a.plan[n_seg].y);
         segi = 0;

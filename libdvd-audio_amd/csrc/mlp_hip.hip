@@ -424,6 +424,7 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
     hipLaunchKernelGGL(k_stream_rank, dim3((n_streams + 255) / 256), dim3(256), 0, st, c->d_shape_key, c->d_streams,
                        n_streams, c->d_rank, c->d_sorted_cnt, c->d_cls + 2);
     exscan(c, st, c->d_sorted_cnt, c->d_sorted_base, n_streams, nullptr, n_streams);
+    (void)hipMemsetAsync(c->d_lane_seg, 0xFF, (size_t)ms * sizeof(uint32_t), st);     // lanes that are dealt nothing
     hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, st, c->d_seg, c->d_streams, c->d_n_cand, ms,
                        c->d_rank, c->d_sorted_base, c->d_cls + 2, c->d_lane_seg);
 }

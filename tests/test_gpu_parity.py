@@ -691,6 +691,31 @@ def test_stream_ranges_are_checked_not_trusted(pkg, oracle):
     assert infos[0].status == 0 and infos[1].status == 0 and infos[2].status & bad
     infos, host = run([offs[0], offs[1] + 2, offs[2]], [lens[0], lens[1] - 2, lens[2]])
     assert infos[0].status == 0 and infos[1].status & bad and infos[2].status == 0 and np.array_equal(host[2], want)
+    # the same with streams of different shapes in the batch (the lanes are then dealt by stream shape, and the
+    # refused stream's major syncs must take no lane): 6-ch title, 2-ch title, the 2-ch title's bytes once more
+    cfg2 = syn.make_cfg(assignment=1, rate_code=0, n_aus=40)
+    b2, f2 = syn.stream(cfg2, 6)
+    want2, r2, st2 = oracle.decode(b2, 2, f2)
+    flat2, offs2, lens2 = hip.pack_streams([b, b2, b2])
+    d_bytes2 = torch.from_numpy(flat2).to(dev)
+    d_off = torch.from_numpy(np.asarray([offs2[0], offs2[1], offs2[1]], np.int64)).to(dev)
+    d_len = torch.from_numpy(np.asarray(lens2, np.int64)).to(dev)
+    cap = max(f, f2)
+    oo = torch.from_numpy(np.arange(3, dtype=np.int64) * cap * 6).to(dev)
+    stride = torch.from_numpy(np.full(3, cap, np.int64)).to(dev)
+    pcm = torch.zeros(3 * cap * 6, dtype=torch.int32, device=dev)
+    ctx = hip.Context(0, 3, 64)
+    for _ in range(2):                      # (twice on one context: the second index replays the first one's launches)
+        ctx.index(d_bytes2.data_ptr(), len(flat2) - 64, d_off.data_ptr(), d_len.data_ptr(), 3, 0)
+        ctx.decode(pcm.data_ptr(), oo.data_ptr(), stride.data_ptr(), 0)
+        infos = ctx.stream_info(3)
+        host = pcm.cpu().numpy()
+        assert infos[0].status == 0 and infos[0].pcm_frames == f
+        assert np.array_equal(host[:cap * 6].reshape(6, cap)[:, :f], want)
+        assert infos[1].status == 0 and infos[1].pcm_frames == f2
+        assert np.array_equal(host[cap * 6:cap * 6 + 2 * cap].reshape(2, cap)[:, :f2], want2)
+        assert infos[2].status & bad and infos[2].pcm_frames == 0
+    ctx.close()
 
 
 def test_too_small_a_context_is_reported_not_truncated(pkg, oracle):
