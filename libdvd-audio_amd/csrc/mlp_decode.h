@@ -1637,6 +1637,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                           "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
 #endif
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
+        const uint32_t frames_before = frames_done;      // (sequential pass: did this turn close an access unit?)
         uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
         uint64_t flush_row = 0;
         if (pf) {
@@ -2063,6 +2064,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     ch[c] = c < NS ? val[c < NS ? c : 0] : 0;
             }
             row_tail(ch);
+        }
+        if constexpr (GENERAL) {
+            // ---- the two substreams of an access unit must end it at the same PCM frame.  (The passes in front
+            //      of this one hold every substream to the standard length; here lengths are free, and the
+            //      reference, given substreams that disagree, rematrixes over one's length past the other's
+            //      arrays and appends channels of different lengths, src/mlp.c:1308-1320, 598-603: outside what
+            //      it defines -- reported, as the oracle does)
+            const int ended = frames_done != frames_before ? 1 : 0;
+            const int other = __shfl_xor(ended, 1, 64);
+            if (S == 2u && active && ended != other) {
+                status |= ST_ENVELOPE;
+                active = false;
+            }
         }
         DVDA_STAMP(3);
 

@@ -329,9 +329,15 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     if (outside) {
         r.flags = SEG_DEAD;
         r.end = off;
-    } else if (((off - s_begin) & 1) || !sync_frame_at(bytes, off, s_end)) {
-        // candidate at an odd stream offset, or cut by the stream end: not a segment of this stream
+    } else if ((off - s_begin) & 1) {
+        // candidate at an odd stream offset: not a segment of this stream
         r.flags = 1u << 16; // DVDA_ST_IRREGULAR
+        r.end = off;
+    } else if (!sync_frame_at(bytes, off, s_end)) {
+        // the stream ends inside this access unit's major sync (k_sync_mask saw it whole: it tests against the
+        // buffer's end): a cut tail like any other -- the walk in front of it stops here and says
+        // DVDA_ST_TRUNCATED, the bytes stay unconsumed -- not a segment, and no finding of its own
+        r.flags = SEG_DEAD;
         r.end = off;
     } else {
         r.sync = packed_sync_at(bytes, off);

@@ -172,7 +172,7 @@ def pack_streams(streams):
     return flat, np.asarray(offs, np.uint64), np.asarray(lens, np.uint64)
 
 
-def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, layout=PCM_PLANAR):
+def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, layout=PCM_PLANAR, ctx=None):
     """Decodes a list of complete MLP byte streams on the GPU.
 
     Returns (pcm, infos): pcm[i] is an int32 array [channels, pcm_frames] in RIFF-WAVE
@@ -181,6 +181,8 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, la
     library writes frame-major (the dvda_read order) and pcm[i] is that buffer viewed
     as [pcm_frames, channels] and transposed, so callers compare the same way.  Raises
     HipError if the HIP path is unavailable; never falls back to a CPU decoder.
+    `ctx`: a caller's Context to run on (it stays open and keeps its size: a batch it cannot hold raises); its lane
+    and layout settings are set to this call's.
     """
     import torch
     if not torch.cuda.is_available():
@@ -190,7 +192,12 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, la
     total = int(len(flat) - 64)
     if max_segments is None:
         max_segments = max(64, total // 64)
-    ctx = Context(device, len(streams), max_segments, lanes_per_segment, layout)
+    own = ctx is None
+    if own:
+        ctx = Context(device, len(streams), max_segments, lanes_per_segment, layout)
+    else:
+        _check(lib().dvda_mlp_hip_set_lanes_per_segment(ctx._h, lanes_per_segment), "set_lanes")
+        _check(lib().dvda_mlp_hip_set_pcm_layout(ctx._h, layout), "set_pcm_layout")
     try:
         d_bytes = torch.from_numpy(flat).to(dev)
         d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
@@ -200,6 +207,8 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, la
         try:
             ctx.segment_count(st)
         except HipError:
+            if not own:
+                raise
             # more major syncs (sync patterns in payload count too) than the context holds: a larger one
             v = ctypes.c_uint32()
             lib().dvda_mlp_hip_segment_count(ctx._h, ctypes.byref(v), st)
@@ -248,7 +257,8 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, la
             pcm.append(np.ascontiguousarray(a[:, :int(inf.pcm_frames)]))
         return pcm, list(infos)
     finally:
-        ctx.close()
+        if own:
+            ctx.close()
 
 
 def decode_streams_wav(streams, bits, device=0, lanes_per_segment=0):

@@ -796,6 +796,15 @@ static unsigned decode_frame(mlp_oracle *d, const uint8_t *p, size_t len)
             return 0;
         if (s == 0)
             pcm0 = frames;
+        else if (frames != pcm0) {
+            /* The two substreams of an access unit disagree on its length.  The reference rematrixes over
+               channels[0]'s length and reads the other substream's channels past theirs (mlp.c:1308-1320,
+               1342-1344), then extends every output channel by its own length (mlp.c:598-603): channels of
+               different lengths, which dvda_read() interleaves against each other from there on
+               (dvd-audio.c:781-792).  Outside what it defines: reported, not decoded. */
+            d->status |= MLP_ORA_ERR_ENVELOPE;
+            return 0;
+        }
         ss_start += sslen;
         prev_end = ss->end;
     }

@@ -645,6 +645,28 @@ def test_two_substreams_of_any_split(pkg, oracle, ss0):
         assert np.array_equal(got, want)
 
 
+def test_substreams_that_disagree_on_an_access_units_length_are_reported(pkg, oracle):
+    """A two-substream stream in which one access unit is 38 PCM frames long in substream 0 and 19 in substream 1
+    (captured by tools/soak_reuse.py, seed 99: the test generator splits access units per substream when it varies
+    their lengths).  The reference rematrixes over the first channel's length past the other channels' arrays and
+    appends channels of different lengths (src/mlp.c:1308-1320, 598-603) -- outside what it defines.  The oracle
+    reports it; the HIP path used to decode on with a clean status and other PCM.  Both must report it, and agree on
+    everything in front of that access unit."""
+    import os
+    hip = pkg.hipdec
+    z = np.load(os.path.join(os.path.dirname(__file__), "data", "ragged_substreams_2ch_2ss.npz"))
+    b = z["mlp"]
+    want, r, st = oracle.decode(b, 2, 7000)
+    assert st & hip.ST["ENVELOPE"]
+    pcm, infos = _both(hip, [b])
+    assert infos[0].status & hip.ST["ENVELOPE"]
+    from tests import stream_tools
+    offs = stream_tools.frame_offsets(b)
+    head, rh, sth = oracle.decode(b[:offs[39]], 2, 7000)           # the 39 access units in front of it
+    assert sth == 0 and rh == 2026
+    assert pcm[0].shape[1] >= rh and np.array_equal(pcm[0][:, :rh], head)
+
+
 def test_stream_ranges_are_checked_not_trusted(pkg, oracle):
     """The index looks streams up by offset.  Ranges that are not ascending and disjoint (the same bytes given
     twice, a list in descending order, a range that leaves the buffer, a misaligned start) used to send its

@@ -157,3 +157,19 @@ def test_oracle_vs_reference_on_changed_major_syncs(oracle, pkg, S):
     assert want.shape == (6, want_frames)
     got, r2, st = oracle.decode(changed, 6, frames)
     assert st == 2 and r2 == want_frames and np.array_equal(got, want)
+
+
+def test_oracle_reports_substreams_of_different_access_unit_length():
+    """src/mlp.c:1308-1320, 598-603: with substreams that disagree on an access unit's length the reference reads one
+    substream's channels past their arrays and appends channels of different lengths.  The restatement reports the
+    access unit (MLP_ORA_ERR_ENVELOPE) instead of following it there."""
+    import os
+    from tests import oracle_lib, stream_tools
+    z = np.load(os.path.join(os.path.dirname(__file__), "data", "ragged_substreams_2ch_2ss.npz"))
+    b = z["mlp"]
+    o = oracle_lib.Oracle()
+    want, r, st = o.decode(b, 2, 7000)
+    assert st & 0x200
+    offs = stream_tools.frame_offsets(b)
+    head, rh, sth = o.decode(b[:offs[39]], 2, 7000)
+    assert sth == 0 and rh == 2026 and np.array_equal(want[:, :rh], head)

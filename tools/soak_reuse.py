@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""tools/soak_reuse.py [N [SEED]] -- N batches of very different make-up through ONE decode context (what a long-running
+caller does): batch sizes 1..48, one and two substreams, all channel assignments and rates, regular and fuzz-profile
+streams, chained titles, and -- every few batches -- streams of random bytes, streams with a flipped byte, a stream cut
+short.  Every stream the oracle decodes cleanly must come out identical; a stream the oracle rejects must carry a status
+that is not benign or stop at the same PCM-frame count.  Looks for state that outlives a call (lane packing, chain
+plans, lists, counters).  Diagnostic."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import libdvd_audio_amd as pkg  # noqa: E402
+from tests import oracle_lib  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4242
+oracle = oracle_lib.Oracle()
+syn, hip = pkg.synth, pkg.hipdec
+rng = np.random.RandomState(seed0)
+two = [12, 1, 0x14, 6, 9, 3, 17, 20]
+ctx = hip.Context(0, 64, 1 << 15)
+bad = 0
+cases = 0
+for it in range(n):
+    nb = int(rng.randint(1, 49))
+    batch, meta = [], []
+    for j in range(nb):
+        kind = int(rng.randint(0, 20))
+        S = 1 + int(rng.randint(0, 2))
+        asg = int(rng.choice(two)) if S == 2 else int(rng.randint(0, 21))
+        prof = int(rng.randint(0, 2))
+        feats = 0
+        if prof:
+            feats = [syn.SF_FAST, syn.SF_ALL, syn.SF["CHAINED"], int(rng.randint(0, 1 << 18))][int(rng.randint(0, 4))]
+        cfg = syn.make_cfg(assignment=asg, rate_code=int(rng.randint(0, 3)), n_substreams=S, n_aus=int(rng.randint(2, 70)),
+                           profile=prof, features=feats, restart_interval=int(rng.randint(1, 12)))
+        try:
+            b, f = syn.stream(cfg, seed0 * 1000 + it * 64 + j)
+        except Exception:
+            continue
+        if kind == 0:
+            b = rng.randint(0, 256, int(rng.randint(16, 6000))).astype(np.uint8)      # random bytes
+        elif kind == 1:
+            b = b.copy()
+            b[int(rng.randint(0, len(b)))] ^= 1 << int(rng.randint(0, 8))               # one flipped bit
+        elif kind == 2:
+            b = b[:int(rng.randint(8, len(b)))]                                         # cut short
+        batch.append(b)
+        meta.append((asg, S, f))
+    if not batch:
+        continue
+    lanes = [0, 0, 0, 2][int(rng.randint(0, 4))]
+    layout = [hip.PCM_PLANAR, hip.PCM_INTERLEAVED][it & 1]
+    pcm, infos = hip.decode_streams(batch, lanes_per_segment=lanes, layout=layout, ctx=ctx)
+    for b, (asg, S, f), got, inf in zip(batch, meta, pcm, infos):
+        cases += 1
+        nch = syn.channels(asg)
+        if int(inf.channels) and int(inf.channels) != nch:
+            nch = int(inf.channels)         # (a flipped bit in the first major sync's channel assignment: the stream says so)
+        want, r, st = oracle.decode(b, nch, max(f, 1) + 4000)
+        if st == 0 and r == 0:
+            ok = got.shape[1] == 0          # nothing decodable (no major sync, or not one whole access unit): DVDA_ST_NO_SYNC is fine
+        elif st == 0:
+            ok = (inf.status & ~hip.ST_BENIGN) == 0 and got.shape[1] == r and np.array_equal(got, want[:, :r])
+        else:
+            ok = (inf.status & ~hip.ST_BENIGN) != 0 or (got.shape[1] == r and np.array_equal(got, want[:, :r]))
+        if not ok:
+            bad += 1
+            if os.environ.get("SOAK_DUMP"):
+                os.makedirs(os.environ["SOAK_DUMP"], exist_ok=True)
+                np.savez_compressed(os.path.join(os.environ["SOAK_DUMP"], "reuse_%d_%d_%d.npz" % (seed0, it, bad)), mlp=b,
+                                    got=got, want=want[:, :r], meta=np.array([asg, S, f, st, r, inf.status], np.int64))
+            print("MISMATCH batch %d asg %d S %d oracle st %#x r %d | hip st %#x frames %d" % (it, asg, S, st, r, inf.status,
+                                                                                              got.shape[1]), flush=True)
+ctx.close()
+print("soak_reuse: %d batches, %d streams, %d mismatches" % (n, cases, bad))
