@@ -55,7 +55,18 @@ for it in range(n):
     lanes = [0, 0, 0, 2][int(rng.randint(0, 4))]
     layout = [hip.PCM_PLANAR, hip.PCM_INTERLEAVED][it & 1]
     pcm, infos = hip.decode_streams(batch, lanes_per_segment=lanes, layout=layout, ctx=ctx)
-    for b, (asg, S, f), got, inf in zip(batch, meta, pcm, infos):
+    wav = None
+    if it % 4 == 0:
+        # the same batch once more with the WAV payload as the output layout (a context of its own)
+        bits = [24, 16][(it // 4) & 1]
+        wav = (bits,) + hip.decode_streams_wav(batch, bits, lanes_per_segment=lanes)
+    for k, (b, (asg, S, f), got, inf) in enumerate(zip(batch, meta, pcm, infos)):
+        if wav is not None and (inf.status & ~hip.ST_BENIGN) == 0 and got.shape[1]:
+            payload = wav[1][k]
+            winf = wav[2][k]
+            if (winf.status & ~hip.ST_BENIGN) != 0 or payload.tobytes() != oracle.wav_pack(got, wav[0]):
+                bad += 1
+                print("WAV MISMATCH batch %d stream %d asg %d S %d bits %d st %#x" % (it, k, asg, S, wav[0], winf.status), flush=True)
         cases += 1
         nch = syn.channels(asg)
         if int(inf.channels) and int(inf.channels) != nch:
