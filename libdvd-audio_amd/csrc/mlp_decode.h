@@ -837,8 +837,18 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // frame-major, and every segment of this wave is 6 channels in identity RIFF order (all 6-channel
     // assignments but 0x14) into an aligned buffer: the tile is staged frame-major too -- [frame][channel]
     // instead of [channel][frame] -- and a flush reads it front to back.  Decided once per wave.
-    const bool ilv_direct = ILV && !GENERAL && !PARSE &&
-                            __all(segi >= n_seg || (nch_out == 6u && (wavepk & 0xFFFFFFu) == 0x543210u && vec_ok));
+    // (Judged by the SEGMENT a lane names, not by whether the lane has work: in the two-wave layout the staging
+    //  tile is also the exchange between the two waves of a group, so both have to decide alike -- and the idle
+    //  lane of a single-substream segment, whose output offset was never loaded, used to see an aligned buffer
+    //  where its working twin in the other wave saw an unaligned one: two layouts in one tile, channels of the
+    //  group's two-substream segments transposed.  Found by tools/soak_reuse.py.)
+    bool dir_ok = true;
+    if (ILV && !GENERAL && !PARSE && segi < n_seg) {
+        const uint64_t ob = a.out_off[sr.stream], os = a.out_stride[sr.stream];
+        dir_ok = nch_out == 6u && (wavepk & 0xFFFFFFu) == 0x543210u && ((ob | os) & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(a.pcm) & 15) == 0;
+    }
+    const bool ilv_direct = ILV && !GENERAL && !PARSE && __all(dir_ok);
 
     BitReader rd;
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);

@@ -667,6 +667,43 @@ def test_substreams_that_disagree_on_an_access_units_length_are_reported(pkg, or
     assert pcm[0].shape[1] >= rh and np.array_equal(pcm[0][:, :rh], head)
 
 
+def test_two_wave_kernel_with_an_unaligned_output_offset_in_the_group(pkg, oracle):
+    """Forced lane pairs, frame-major output, one group of 64 segments holding single-substream titles next to a
+    two-substream one, and one of the single-substream titles at an output offset that is not a multiple of four
+    values.  The two waves of the group used to choose different staging layouts (the idle twin of the
+    single-substream segment never loaded the offset) and the two-substream title's channels came out transposed,
+    status clean.  Found by tools/soak_reuse.py."""
+    import torch
+    syn, hip = pkg.synth, pkg.hipdec
+    c1 = syn.make_cfg(assignment=12, rate_code=0, n_substreams=1, n_aus=16, restart_interval=2)
+    c2 = syn.make_cfg(assignment=12, rate_code=0, n_substreams=2, n_aus=24, restart_interval=1)
+    (b1, f1), (b2, f2) = syn.stream(c1, 81), syn.stream(c2, 82)
+    w1 = oracle.decode(b1, 6, f1)[0]
+    w2 = oracle.decode(b2, 6, f2)[0]
+    flat, offs, lens = hip.pack_streams([b1, b1, b2])
+    dev = torch.device("cuda", 0)
+    d_bytes = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    out_off = np.array([0, f1 * 6 + 2, f1 * 12 + 8], np.int64)          # the second title starts 2 values off
+    stride = np.array([f1, f1, f2], np.int64)
+    pcm = torch.zeros(int(out_off[2] + f2 * 6 + 16), dtype=torch.int32, device=dev)
+    d_oo = torch.from_numpy(out_off).to(dev)
+    d_stride = torch.from_numpy(stride).to(dev)
+    for lanes in (2, 0):
+        ctx = hip.Context(0, 3, 256, lanes_per_segment=lanes, layout=hip.PCM_INTERLEAVED)
+        ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), 3, 0)
+        pcm.zero_()
+        ctx.decode(pcm.data_ptr(), d_oo.data_ptr(), d_stride.data_ptr(), 0)
+        infos = ctx.stream_info(3)
+        host = pcm.cpu().numpy()
+        ctx.close()
+        for i, (want, f) in enumerate(((w1, f1), (w1, f1), (w2, f2))):
+            assert infos[i].status & ~hip.ST_BENIGN == 0 and infos[i].pcm_frames == f
+            got = host[out_off[i]:out_off[i] + f * 6].reshape(f, 6).T
+            assert np.array_equal(got, want), (lanes, i)
+
+
 def test_stream_ranges_are_checked_not_trusted(pkg, oracle):
     """The index looks streams up by offset.  Ranges that are not ascending and disjoint (the same bytes given
     twice, a list in descending order, a range that leaves the buffer, a misaligned start) used to send its

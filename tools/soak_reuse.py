@@ -54,6 +54,11 @@ for it in range(n):
         continue
     lanes = [0, 0, 0, 2][int(rng.randint(0, 4))]
     layout = [hip.PCM_PLANAR, hip.PCM_INTERLEAVED][it & 1]
+    if os.environ.get("SOAK_ONLY") and it != int(os.environ["SOAK_ONLY"]):
+        continue                    # (replay of one batch of the sequence, on a context that has seen nothing else)
+    if os.environ.get("SOAK_ONLY") and os.environ.get("SOAK_SAVE"):
+        np.savez_compressed(os.environ["SOAK_SAVE"], n=len(batch), lanes=lanes, layout=layout,
+                            **{"s%d" % i: x for i, x in enumerate(batch)})
     pcm, infos = hip.decode_streams(batch, lanes_per_segment=lanes, layout=layout, ctx=ctx)
     wav = None
     if it % 4 == 0:
