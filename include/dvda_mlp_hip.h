@@ -141,7 +141,10 @@ int dvda_mlp_hip_index(dvda_mlp_hip_ctx *ctx, const uint8_t *d_bytes, uint64_t t
  * RIFF-WAVE order (reference src/mlp.c:416-438, 527-533).
  * The call waits once on `stream` for the fast pass: a 32-byte summary tells the host whether the
  * chain passes / the sequential pass have anything to do (they are not launched otherwise); what it
- * enqueues after that is asynchronous again. */
+ * enqueues after that is asynchronous again.
+ * An index may be decoded more than once (a caller that comes back with a larger buffer after
+ * DVDA_ST_OVERFLOW, or wants the titles in a second buffer): every call starts from what the index left,
+ * nothing of the call before it is carried over. */
 int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d_out_off,
                         const uint64_t *d_out_stride, void *stream);
 

@@ -204,7 +204,10 @@ struct DecodeSummary {
     uint32_t chain_segs;           // how many such segments
     uint32_t chain_max_rows;       // the longest of them
     uint32_t seq_streams;          // streams flagged ST_TIMING / ST_SEQ (counted by k_finalize)
-    uint32_t pad[3];
+    uint32_t waiting;              // streams with a segment that waits for a pass behind the fast one (counted by
+                                   // k_finalize from the segments' status, independently of chain_segs: the two
+                                   // have to agree, and the host makes sure nothing waits unreported if they do not)
+    uint32_t pad[2];
 };
 constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
 constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs ...
@@ -2323,13 +2326,19 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
         // decode-time bits are rebuilt from the segments every time (a later pass clears what it
         // repairs); only what the index found stays
         uint32_t st = r.status & ~(0x3FCu | ST_DEFERRED | ST_OVERFLOW | ST_GENERAL);
+        bool waits = false;
         for (uint32_t i = r.first_seg; i < r.first_seg + r.n_seg; i++) {
             const uint32_t ss = seg_status[i];
             rows += seg_rows[i];
             st |= ss | (seg[i].flags & ~SEG_DEAD);      // (what the index found on the segment stays)
-            if (last && (ss & ST_DEFERRED) && !(ss & ST_GENERAL) && !(ss & ~ST_INFO))
-                st |= ST_CAPACITY;      // deferred and never decoded (cannot happen; never silently)
+            if ((ss & ST_DEFERRED) && !(ss & ST_GENERAL) && !(ss & ~ST_INFO)) {
+                waits = true;
+                if (last)
+                    st |= ST_CAPACITY;  // deferred and never decoded (cannot happen; never silently)
+            }
         }
+        if (collect && waits)
+            atomicAdd(&summary->waiting, 1u);
         r.frames = seg_fbase[r.first_seg + r.n_seg] - seg_fbase[r.first_seg];
         r.rows = rows;
         r.status = st;

@@ -48,6 +48,17 @@ using namespace mlp;
 constexpr uint32_t EV_RING = 256;       // decode calls whose kernel time is kept (the newest)
 constexpr uint32_t SEQ_ROUND = 1024;    // streams one round of the sequential pass decodes
 
+// Debug aid: DVDA_POISON=<byte> fills every workspace this library allocates with that byte, so a kernel that
+// reads what no kernel wrote shows itself the same way on every run (tools/soak_reuse.py uses it).
+static hipError_t ws_malloc(void **p, size_t bytes)
+{
+    static const int poison = getenv("DVDA_POISON") ? (int)strtol(getenv("DVDA_POISON"), nullptr, 0) : -1;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison >= 0)
+        e = hipMemset(*p, poison & 0xFF, bytes);
+    return e;
+}
+
 struct dvda_mlp_hip_ctx {
     int device;
     uint32_t max_streams, max_segments;
@@ -106,6 +117,7 @@ struct dvda_mlp_hip_ctx {
     uint32_t n_streams;
     uint64_t tiles;
     bool indexed;
+    bool decoded;              // a decode call has run on the current index (the next one resets the segments first)
     uint32_t lanes_per_seg;
     uint32_t pcm_layout;           // DVDA_PCM_PLANAR / DVDA_PCM_INTERLEAVED
     // the index's launch sequence as a hipGraph, replayed while a caller indexes the same buffers again and
@@ -189,6 +201,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->tiles_cap = 0;
     c->scan_tmp_cap = 0;
     c->indexed = false;
+    c->decoded = false;
     c->idx_graph = nullptr;
     c->idx_graph_state = getenv("DVDA_INDEX_GRAPH") && atoi(getenv("DVDA_INDEX_GRAPH")) == 0 ? -1 : 0;
     c->ev_made = 0;
@@ -200,7 +213,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
         if (e == hipSuccess)
-            e = hipMalloc(p, bytes ? bytes : 16);
+            e = ws_malloc(p, bytes ? bytes : 16);
     };
     alloc((void **)&c->d_cand_off, ns * sizeof(uint64_t));
     alloc((void **)&c->d_seg, ns * sizeof(SegRec));
@@ -272,7 +285,7 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
         (void)hipFree(c->d_masks);
         c->d_masks = nullptr;
         c->masks_cap = 0;
-        if (hipMalloc((void **)&c->d_masks, chunks) != hipSuccess)
+        if (ws_malloc((void **)&c->d_masks, chunks) != hipSuccess)
             return DVDA_HIP_ENOMEM;
         c->masks_cap = chunks;
     }
@@ -285,7 +298,7 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
             (void)hipFree(c->d_scan_tmp);
             c->d_scan_tmp = nullptr;
             c->scan_tmp_cap = 0;
-            if (hipMalloc((void **)&c->d_scan_tmp, need * sizeof(uint32_t)) != hipSuccess)
+            if (ws_malloc((void **)&c->d_scan_tmp, need * sizeof(uint32_t)) != hipSuccess)
                 return DVDA_HIP_ENOMEM;
             c->scan_tmp_cap = need;
         }
@@ -295,8 +308,8 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
         (void)hipFree(c->d_tile_base);
         c->d_tile_count = c->d_tile_base = nullptr;
         c->tiles_cap = 0;
-        if (hipMalloc((void **)&c->d_tile_count, (tiles + 1) * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc((void **)&c->d_tile_base, (tiles + 1) * sizeof(uint32_t)) != hipSuccess)
+        if (ws_malloc((void **)&c->d_tile_count, (tiles + 1) * sizeof(uint32_t)) != hipSuccess ||
+            ws_malloc((void **)&c->d_tile_base, (tiles + 1) * sizeof(uint32_t)) != hipSuccess)
             return DVDA_HIP_ENOMEM;
         c->tiles_cap = tiles;
     }
@@ -322,16 +335,17 @@ static void exscan(dvda_mlp_hip_ctx *c, hipStream_t st, const uint32_t *in, uint
                        n_cap);
 }
 
-// one dispatch for the three things an index call starts from: empty stream records, and the
-// per-segment status / row counters at zero
+// one dispatch for the things an index call starts from: empty stream records, and the per-segment status /
+// row counters / end-of-segment notes at zero (a note of the batch before must not vouch for a segment of this one)
 __global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, uint32_t *seg_rows, uint32_t *yield_req,
-                               uint32_t n_seg)
+                               uint32_t *seg_meta, uint32_t n_seg)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_seg) {
         seg_status[i] = 0;
         seg_rows[i] = 0;
         yield_req[i] = 0;
+        seg_meta[2 * (size_t)i] = seg_meta[2 * (size_t)i + 1] = 0;
     }
     if (i < n) {
         StreamRec r;
@@ -343,6 +357,21 @@ __global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, u
         r.consumed = 0;
         r.rows = 0;
         s[i] = r;
+    }
+}
+
+// A decode call on an index that has been decoded before (the caller came back with a larger PCM buffer, say):
+// what the decode passes left on the segments -- status bits, row counts, yield requests, end-of-segment notes --
+// goes back to what the index left, or the second decode would take the first one's findings for its own.
+__global__ void k_reset_segments(uint32_t *seg_status, uint32_t *seg_rows, uint32_t *yield_req, uint32_t *seg_meta,
+                                 uint32_t n_seg)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_seg) {
+        seg_status[i] = 0;
+        seg_rows[i] = 0;
+        yield_req[i] = 0;
+        seg_meta[2 * (size_t)i] = seg_meta[2 * (size_t)i + 1] = 0;
     }
 }
 
@@ -401,7 +430,7 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
     {
         const uint32_t n_init = n_streams > ms ? n_streams : ms;
         hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
-                           n_streams, c->d_seg_status, c->d_seg_rows, c->d_yield, ms);
+                           n_streams, c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, ms);
         hipLaunchKernelGGL(k_check_ranges, dim3(1), dim3(1024), 0, st, d_stream_off, d_stream_len, n_streams, total_bytes,
                            c->d_soff, c->d_slen, c->d_streams);
         d_stream_off = c->d_soff;
@@ -463,6 +492,7 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     if (c->idx_graph_state == 2 && same) {
         if (hipGraphLaunch(c->idx_graph, st) == hipSuccess) {
             c->indexed = true;
+            c->decoded = false;
             return DVDA_HIP_OK;
         }
         (void)hipGetLastError();
@@ -486,6 +516,7 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
         if (ok && hipGraphLaunch(c->idx_graph, st) == hipSuccess) {
             c->idx_graph_state = 2;
             c->indexed = true;
+            c->decoded = false;
             return DVDA_HIP_OK;
         }
         (void)hipGetLastError();
@@ -502,6 +533,7 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     enqueue_index(c, st, d_bytes, total_bytes, d_stream_off, d_stream_len, n_streams);
     HIP_TRY(hipGetLastError());
     c->indexed = true;
+    c->decoded = false;
     return DVDA_HIP_OK;
 }
 
@@ -515,7 +547,7 @@ static int grow(T **p, uint64_t *cap, uint64_t need)
     *p = nullptr;
     *cap = 0;
     need += need / 8 + 1024;
-    if (hipMalloc((void **)p, need * sizeof(T)) != hipSuccess)
+    if (ws_malloc((void **)p, need * sizeof(T)) != hipSuccess)
         return DVDA_HIP_ENOMEM;
     *cap = need;
     return DVDA_HIP_OK;
@@ -566,6 +598,10 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.seg_meta = c->d_seg_meta;
     a.yield_req = c->d_yield;
     HIP_TRY(hipMemsetAsync(c->d_summary, 0, sizeof(DecodeSummary), st));
+    if (c->decoded)
+        hipLaunchKernelGGL(k_reset_segments, dim3((unsigned)((c->max_segments + 255) / 256)), dim3(256), 0, st,
+                           c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, c->max_segments);
+    c->decoded = true;
     // which kernels: one lane per segment for the streams with one substream, the two-wave layout for those
     // with two -- both unless the caller forced one; a kernel whose class is absent from the batch (the
     // index knows) exits at once
@@ -689,7 +725,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
             (void)hipFree(c->d_fb);
             c->d_fb = nullptr;
             c->fb_slots = 0;
-            if (hipMalloc((void **)&c->d_fb, (size_t)round * FB_WORDS * sizeof(int32_t)) != hipSuccess)
+            if (ws_malloc((void **)&c->d_fb, (size_t)round * FB_WORDS * sizeof(int32_t)) != hipSuccess)
                 return DVDA_HIP_ENOMEM;
             c->fb_slots = round;
         }
@@ -703,7 +739,9 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
                                dim3(DEC_THREADS), 0, st, a);
         }
     }
-    if (c->h_summary->chain_segs || n_seq)
+    // (`waiting` without either: the lanes' count of deferred segments and the segments' status disagree -- the
+    //  last finalize then reports what was left undecoded instead of passing it as clean)
+    if (c->h_summary->chain_segs || n_seq || c->h_summary->waiting)
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 0u, 1u);
     (void)blocks2;

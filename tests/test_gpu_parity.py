@@ -777,6 +777,65 @@ def test_stream_ranges_are_checked_not_trusted(pkg, oracle):
     ctx.close()
 
 
+def test_decoding_one_index_more_than_once(pkg, oracle):
+    """A caller may decode an index again -- it came back with a larger PCM buffer after DVDA_ST_OVERFLOW, or
+    wants the same titles in another buffer.  What the first decode left on the segments (status bits, row
+    counts, which segments the chain passes took) must not be taken by the second for its own findings: the
+    overflow would stick, and the chain passes -- started from a count of NEWLY flagged segments -- would not run,
+    leaving chained titles undecoded under a clean status."""
+    import torch
+    syn, hip = pkg.synth, pkg.hipdec
+    SF = syn.SF
+    cfgs = [syn.make_cfg(assignment=12, rate_code=1, n_aus=24),
+            syn.make_cfg(assignment=12, rate_code=1, n_aus=24, profile=1, features=SF["CHAINED"] | SF["FIRRAND"],
+                         restart_interval=4),
+            syn.make_cfg(assignment=3, rate_code=0, n_substreams=2, n_aus=24, profile=1,
+                         features=SF["CHAINED"] | SF["FIRRAND"], restart_interval=3),
+            syn.make_cfg(assignment=6, rate_code=0, n_aus=20, profile=1, features=SF["VARROWS"] | SF["VARBLOCK"],
+                         restart_interval=5),
+            syn.make_cfg(assignment=1, rate_code=0, n_aus=40)]
+    made = [syn.stream(c, 9100 + i) for i, c in enumerate(cfgs)]
+    streams = [b for b, _ in made]
+    nch = [syn.channels(c.assignment) for c in cfgs]
+    want = [oracle.decode(b, n, f + 64) for (b, f), n in zip(made, nch)]
+    assert all(st == 0 for _, _, st in want)
+    flat, offs, lens = hip.pack_streams(streams)
+    dev = torch.device("cuda", 0)
+    d_bytes = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    n = len(streams)
+    ctx = hip.Context(0, n, 256)
+    try:
+        ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), n, 0)
+        rows = [r for _, r, _ in want]
+
+        def run(cap):
+            oo, pos = [], 0
+            for c, k in zip(cap, nch):
+                oo.append(pos)
+                pos += c * k
+            d_oo = torch.tensor(oo, dtype=torch.int64, device=dev)
+            d_st = torch.tensor(cap, dtype=torch.int64, device=dev)
+            pcm = torch.full((max(pos, 1),), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+            ctx.decode(pcm.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), 0)
+            infos = ctx.stream_info(n)
+            host = pcm.cpu().numpy()
+            return [host[o:o + c * k].reshape(k, c) for o, c, k in zip(oo, cap, nch)], infos
+
+        # first with half the room: every title overflows, says how much it needs
+        got, infos = run([r // 2 for r in rows])
+        assert all(inf.status & hip.ST["OVERFLOW"] for inf in infos)
+        # then, same index, with room -- three times over, every time into a buffer that holds nothing yet
+        for _ in range(3):
+            got, infos = run(rows)
+            for g, inf, (w, r, _) in zip(got, infos, want):
+                assert (inf.status & ~hip.ST_BENIGN) == 0 and int(inf.pcm_frames) == r, hex(inf.status)
+                assert np.array_equal(g[:, :r], w[:, :r])
+    finally:
+        ctx.close()
+
+
 def test_too_small_a_context_is_reported_not_truncated(pkg, oracle):
     """more major syncs than max_segments used to come back as short PCM with status 0."""
     import torch

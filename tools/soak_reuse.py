@@ -72,6 +72,22 @@ for it in range(n):
             if (winf.status & ~hip.ST_BENIGN) != 0 or payload.tobytes() != oracle.wav_pack(got, wav[0]):
                 bad += 1
                 print("WAV MISMATCH batch %d stream %d asg %d S %d bits %d st %#x" % (it, k, asg, S, wav[0], winf.status), flush=True)
+                # what differs, and does the same call say the same thing again (a race or stale memory does not)
+                exp = np.frombuffer(oracle.wav_pack(got, wav[0]), np.uint8)
+                pay = np.frombuffer(payload.tobytes(), np.uint8)
+                m = min(exp.size, pay.size)
+                d = np.nonzero(exp[:m] != pay[:m])[0]
+                spf = syn.channels(asg) * wav[0] // 8
+                print("   bytes %d vs %d; %d differ, frames %s .. %s of %d" % (pay.size, exp.size, d.size,
+                      d[0] // spf if d.size else -1, d[-1] // spf if d.size else -1, got.shape[1]), flush=True)
+                for t in range(3):
+                    again = hip.decode_streams_wav(batch, wav[0], lanes_per_segment=lanes)
+                    print("   again %d: %s" % (t, "same as expected" if again[0][k].tobytes() == exp.tobytes() else
+                                                 "same wrong bytes" if again[0][k].tobytes() == pay.tobytes() else "other bytes"), flush=True)
+                if os.environ.get("SOAK_DUMP"):
+                    os.makedirs(os.environ["SOAK_DUMP"], exist_ok=True)
+                    np.savez_compressed(os.path.join(os.environ["SOAK_DUMP"], "wav_%d_%d_%d.npz" % (seed0, it, k)), mlp=b,
+                                        got=got, pay=pay, exp=exp, lanes=lanes, bits=wav[0])
         cases += 1
         nch = syn.channels(asg)
         if int(inf.channels) and int(inf.channels) != nch:
