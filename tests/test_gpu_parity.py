@@ -1,6 +1,11 @@
 """GPU parity: HIP decode path (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -899,3 +904,17 @@ def test_wav_payload_straight_out_of_the_decode(pkg, oracle, bits):
     # and it is what the separate pack kernel makes of the int32 PCM
     pcm, _ = hip.decode_streams([streams[0][0]])
     assert np.array_equal(hip.pack_wav(pcm[0], bits), got[0])
+
+
+@pytest.mark.parametrize("fill", ["0xA5", "0xFF"])
+def test_workspaces_full_of_garbage_change_nothing(fill):
+    """DVDA_POISON fills every workspace the library allocates: a kernel that reads what no kernel wrote before it
+    (a plan entry, a record terminator, an end-of-segment note of no segment) then fails the same way every time
+    instead of once in a long while.  The deferred-feature, chain, mixed-batch and repeated-decode tests once more,
+    in a process of their own (the switch is read once per process)."""
+    import subprocess
+    env = dict(os.environ, DVDA_POISON=fill)
+    pick = "deferred or chains_and_midframe or mixed_batch or more_than_once or wav_payload or any_split or recipe"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p",
+                        "no:cacheprovider", "-k", pick], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -61,7 +61,7 @@ for it in range(n):
                             **{"s%d" % i: x for i, x in enumerate(batch)})
     pcm, infos = hip.decode_streams(batch, lanes_per_segment=lanes, layout=layout, ctx=ctx)
     wav = None
-    if it % 4 == 0:
+    if it % int(os.environ.get("SOAK_WAV_EVERY", "4")) == 0:
         # the same batch once more with the WAV payload as the output layout (a context of its own)
         bits = [24, 16][(it // 4) & 1]
         wav = (bits,) + hip.decode_streams_wav(batch, bits, lanes_per_segment=lanes)
