@@ -86,8 +86,9 @@ extern "C" {
                                             order by the sequential pass                                  */
 #define DVDA_ST_COLD         (1u << 26)  /* IIR taps, or more than two matrices: the fused row loop keeps
                                             neither in registers -- segment decoded by the chain passes   */
-#define DVDA_ST_YIELD        (1u << 27)  /* the segment in front of a chained one, decoded with it by the chain
-                                            passes instead of alone by the fast pass (informational)     */
+#define DVDA_ST_YIELD        (1u << 27)  /* the segment in front of a chained one (or one of the few segments
+                                            without a chain among many with one), decoded by the chain passes
+                                            with them instead of alone by the fast pass (informational)  */
 /* DVDA_ST_CHAINED, _MIDFRAME, _COLD, _YIELD, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
  * the passes behind it (chain passes: parse in parallel, the filter recursion alone per channel, rematrix
  * in parallel; or the sequential pass); they stay set as information.  Bits that do not invalidate the PCM: */

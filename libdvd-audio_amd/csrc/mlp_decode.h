@@ -87,6 +87,13 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 #ifndef DVDA_YIELD_ASK
 #define DVDA_YIELD_ASK 1
 #endif
+// A lane whose wave has emptied around it -- this many of the wave's 64 lanes stopped at their first block because
+// their segment continues a history (ST_CHAINED) -- hands its segment to the chain passes as well, while it is
+// still within its first two access units: the chain passes run anyway, and a wave kept alive by a few lanes holds
+// the whole fast pass (and everything that waits for it) for the time one segment takes, 2.6 ms.  0: off.
+#ifndef DVDA_YIELD_LONELY
+#define DVDA_YIELD_LONELY 56
+#endif
 // Row-loop experiments of round 2 (tools/ab_build.py + tools/ab_bench.sh):
 //   DVDA_SKIP_SCALAR  the "no lane carries slot k" skip tests a wave-uniform slot count kept in an SGPR
 //                     (refreshed after header parses) instead of a per-row v_cmp + ballot + branch on VCC
@@ -209,6 +216,7 @@ struct DecodeSummary {
                                    // have to agree, and the host makes sure nothing waits unreported if they do not)
     uint32_t pad[2];
 };
+constexpr uint32_t SUMMARY_PARTS = 64;      // the fast pass adds into summary[1 + block % 64]; k_finalize folds them into summary[0]
 constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
 constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs ...
 constexpr int BREC_IIR_WORDS = 12; // ... + when the block (re)sets the slot's IIR: 4 coefficient pairs + 8 history values
@@ -664,6 +672,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     constexpr bool XCH = SIDE && !PARSE;
     __shared__ int32_t s_xch[XCH ? WAVES : 1][MAXCH][XCH ? 64 : 1];
     __shared__ uint32_t s_alive[2][WAVES];
+    __shared__ uint32_t s_nchained[WAVES];          // fast pass: lanes of the wave that stopped on ST_CHAINED (or, two-wave
+                                                    // layout, whose other substream's lane did)
     // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
     // (last substream, odd wave) for the lane that applies them (first substream, even wave)
     constexpr bool WS_BAL = WSPEC && DVDA_WS_BALANCE;
@@ -675,6 +685,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 
     for (int i = threadIdx.x; i < 4 * 256; i += THREADS)
         s_crc[i] = d_crc.t[i];
+    if (threadIdx.x < WAVES)
+        s_nchained[threadIdx.x] = 0;
     if (WSPEC) {
         for (int i = threadIdx.x; i < GROUPS * 2 * OUT_ROWS * 64; i += THREADS)     // "no row there"
             (&s_tag[0][0][0][0])[WSPEC ? i : 0] = 0;
@@ -1114,8 +1126,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             // (looked at on the segment's first few block headers only: the request comes within the first loop
             //  turn of the lane behind this one, or -- that lane's wave starting late -- not in time at all)
             if (DVDA_YIELD_CHECK && !GENERAL && !PARSE && active && frames_done < 2 && (frames_done | blocks_in_frame) != 0 &&
-                __hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                status |= ST_YIELD;            // the next segment chains to this one: both go to the chain passes
+                (__hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                 (DVDA_YIELD_LONELY && s_nchained[wv] >= (uint32_t)DVDA_YIELD_LONELY))) {
+                // the next segment chains to this one: both go to the chain passes -- or nearly every other lane
+                // of the wave has gone there, and this one would hold the pass for a whole segment's time
+                status |= ST_YIELD;
                 active = false;
             }
             if (active) {
@@ -1586,6 +1601,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (!GENERAL && !PARSE && (status & ST_CHAINED)) {
                     active = false;            // left to the chain passes (needs the previous history)
+                    if (DVDA_YIELD_LONELY)
+                        atomicAdd(&s_nchained[wv], 1u);
                     // ... which start one segment earlier if that segment's lane hears of it in time: it is
                     // decoding a whole segment on its own (one lane of many per title) only to hand over its
                     // last eight values, and the parse pass would then wait for it
@@ -1600,6 +1617,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
         }
         if ((USLOT || DVDA_SKIP_SCALAR) && __builtin_expect(__any(hdr_parsed), 0)) {
+            // (a turn in which some lane parsed a block header: once per block, the wave as a whole)
+            if (!GENERAL && !PARSE && DVDA_YIELD_LONELY && active && frames_done < 2 &&
+                s_nchained[wv] >= (uint32_t)DVDA_YIELD_LONELY) {
+                // nearly every other lane of the wave has left for the chain passes (every lane's first header
+                // is parsed in the first turn, so this is known at the end of it): this one goes with them
+                // instead of holding the pass for a whole segment's time
+                status |= ST_YIELD;
+                active = false;
+            }
             uint32_t sw = 2;
 #pragma unroll
             for (int k = 2; k < NS; k++)
@@ -2008,6 +2034,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     const uint32_t ver = (tagw >> 8) & 0xFFFFu;
                     if (!(tagw >> 31)) {
                         active = false;                  // it stopped (its status says why): no more output
+                        if (DVDA_YIELD_LONELY)
+                            atomicAdd(&s_nchained[wv], 1u);      // (gone with it: one lane less that keeps the wave)
                     } else if (__builtin_expect(ver != (par_seen & 0xFFFFu), 0)) {
                         const uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][ver & 1u][0][WS_BAL ? lane & (SPL - 1) : 0];
                         constexpr int PS = WS_BAL ? SPL : 1;
@@ -2287,9 +2315,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 mx = mx > m2 ? mx : m2;
             }
             if (lane == 0) {
-                atomicAdd(&a.summary->chain_segs, (uint32_t)__popcll(counted));
-                atomicAdd(&a.summary->chain_rows, ((unsigned long long)hi << 32) | lo);
-                atomicMax(&a.summary->chain_max_rows, mx);
+                // (into one of SUMMARY_PARTS partial sums, folded by k_finalize: ten thousand waves of a chained
+                //  batch adding to ONE address take each other's time -- 0.5 ms for 4 224 waves, 2 ms for 8 448)
+                DecodeSummary *const part = a.summary + 1 + (blockIdx.x % SUMMARY_PARTS);
+                atomicAdd(&part->chain_segs, (uint32_t)__popcll(counted));
+                atomicAdd(&part->chain_rows, ((unsigned long long)hi << 32) | lo);
+                atomicMax(&part->chain_max_rows, mx);
             }
         }
     }
@@ -2312,6 +2343,22 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
                                                   uint32_t *__restrict__ seq_list, uint32_t collect, uint32_t last)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0 && collect) {
+        // the fast pass's partial sums into the summary proper (and out of the way of the next fold)
+        unsigned long long rows = 0;
+        uint32_t segs = 0, mx = 0;
+        for (uint32_t p = 1; p <= SUMMARY_PARTS; p++) {
+            rows += summary[p].chain_rows;
+            segs += summary[p].chain_segs;
+            mx = summary[p].chain_max_rows > mx ? summary[p].chain_max_rows : mx;
+            summary[p].chain_rows = 0;
+            summary[p].chain_segs = 0;
+            summary[p].chain_max_rows = 0;
+        }
+        summary->chain_rows += rows;
+        summary->chain_segs += segs;
+        summary->chain_max_rows = summary->chain_max_rows > mx ? summary->chain_max_rows : mx;
+    }
     if (s >= n_streams)
         return;
     StreamRec r = streams[s];

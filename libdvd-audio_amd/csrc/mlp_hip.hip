@@ -238,7 +238,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_sorted_cnt, ((size_t)max_streams + 1) * sizeof(uint32_t));
     alloc((void **)&c->d_sorted_base, ((size_t)max_streams + 1) * sizeof(uint32_t));
     alloc((void **)&c->d_lane_seg, ns * sizeof(uint32_t));
-    alloc((void **)&c->d_summary, sizeof(DecodeSummary));
+    alloc((void **)&c->d_summary, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary));        // the total + the fast pass's partial sums
     alloc((void **)&c->d_seq_list, (size_t)max_streams * sizeof(uint32_t));
     alloc((void **)&c->d_plan, (ns + 1) * sizeof(uint4));
     alloc((void **)&c->d_scan4_tmp, (ns / 1024 + 4) * sizeof(uint4));
@@ -597,7 +597,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.lane_seg = c->d_lane_seg;
     a.seg_meta = c->d_seg_meta;
     a.yield_req = c->d_yield;
-    HIP_TRY(hipMemsetAsync(c->d_summary, 0, sizeof(DecodeSummary), st));
+    HIP_TRY(hipMemsetAsync(c->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary), st));
     if (c->decoded)
         hipLaunchKernelGGL(k_reset_segments, dim3((unsigned)((c->max_segments + 255) / 256)), dim3(256), 0, st,
                            c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, c->max_segments);
