@@ -672,6 +672,22 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     }
     if (row >= R || orow >= out_stride)
         continue;
+    if (a.interleaved && nch_out == 6u && ((reinterpret_cast<uintptr_t>(out) | (orow * 24u)) & 7u) == 0) {
+        // six channels, frame-major, the frame 8-byte aligned: three 8-byte stores instead of six scattered dwords
+        int32_t o[6];
+#pragma unroll
+        for (int w = 0; w < 6; w++) {
+            o[w] = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                o[w] = nib(wavepk, c) == (uint32_t)w ? ch[c] : o[w];
+        }
+        int2 *dst = reinterpret_cast<int2 *>(out + orow * 6u);
+        dst[0] = make_int2(o[0], o[1]);
+        dst[1] = make_int2(o[2], o[3]);
+        dst[2] = make_int2(o[4], o[5]);
+        continue;
+    }
 #pragma unroll
     for (int c = 0; c < 6; c++)
         if ((uint32_t)c < nch_out)

@@ -16,6 +16,7 @@ import libdvd_audio_amd as pkg  # noqa: E402
 syn, hip = pkg.synth, pkg.hipdec
 n_titles, n_aus = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 128
 n_ss = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # substreams per title (2: ch 0-1 | ch 2-5, what 6-channel discs carry)
+layout = int(sys.argv[4]) if len(sys.argv) > 4 else 0     # 0 planar, 1 frame-major (hipdec.PCM_*)
 dev = torch.device("cuda", 0)
 for name, feats in (("independent", 0), ("chained", syn.SF["CHAINED"])):
     cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=n_ss, n_aus=n_aus, profile=1 if feats else 0, features=feats)
@@ -28,7 +29,7 @@ for name, feats in (("independent", 0), ("chained", syn.SF["CHAINED"])):
     d_oo = torch.from_numpy(out_off).to(dev)
     d_st = torch.from_numpy(frames.astype(np.int64)).to(dev)
     d_pcm = torch.empty(int(frames.sum()) * 6, dtype=torch.int32, device=dev)
-    ctx = hip.Context(0, n_titles, n_titles * (n_aus // 8 + 2), lanes_per_segment=0)
+    ctx = hip.Context(0, n_titles, n_titles * (n_aus // 8 + 2), lanes_per_segment=0, layout=layout)
     best = 1e9
     for it in range(3):
         torch.cuda.synchronize()
