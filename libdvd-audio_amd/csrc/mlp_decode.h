@@ -92,7 +92,7 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 // still within its first two access units: the chain passes run anyway, and a wave kept alive by a few lanes holds
 // the whole fast pass (and everything that waits for it) for the time one segment takes, 2.6 ms.  0: off.
 #ifndef DVDA_YIELD_LONELY
-#define DVDA_YIELD_LONELY 56
+#define DVDA_YIELD_LONELY 48
 #endif
 // Row-loop experiments of round 2 (tools/ab_build.py + tools/ab_bench.sh):
 //   DVDA_SKIP_SCALAR  the "no lane carries slot k" skip tests a wave-uniform slot count kept in an SGPR
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             //  turn of the lane behind this one, or -- that lane's wave starting late -- not in time at all)
             if (DVDA_YIELD_CHECK && !GENERAL && !PARSE && active && frames_done < 2 && (frames_done | blocks_in_frame) != 0 &&
                 (__hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                 (DVDA_YIELD_LONELY && s_nchained[wv] >= (uint32_t)DVDA_YIELD_LONELY))) {
+                 (DVDA_YIELD_LONELY && __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)DVDA_YIELD_LONELY))) {
                 // the next segment chains to this one: both go to the chain passes -- or nearly every other lane
                 // of the wave has gone there, and this one would hold the pass for a whole segment's time
                 status |= ST_YIELD;
@@ -1613,19 +1613,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 } else {
                     rows_left = block_size;
                     blocks_in_frame++;
+                    // (the lanes that stop above have counted themselves by now -- the branches of this chain run
+                    //  one after the other, this one last; were it otherwise, the check at the next block header
+                    //  does the same a block later: it is a matter of time only)
+                    if (!GENERAL && !PARSE && DVDA_YIELD_LONELY && frames_done < 2 &&
+                        __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >=
+                            (uint32_t)DVDA_YIELD_LONELY) {
+                        status |= ST_YIELD;
+                        active = false;
+                    }
                 }
             }
         }
         if ((USLOT || DVDA_SKIP_SCALAR) && __builtin_expect(__any(hdr_parsed), 0)) {
-            // (a turn in which some lane parsed a block header: once per block, the wave as a whole)
-            if (!GENERAL && !PARSE && DVDA_YIELD_LONELY && active && frames_done < 2 &&
-                s_nchained[wv] >= (uint32_t)DVDA_YIELD_LONELY) {
-                // nearly every other lane of the wave has left for the chain passes (every lane's first header
-                // is parsed in the first turn, so this is known at the end of it): this one goes with them
-                // instead of holding the pass for a whole segment's time
-                status |= ST_YIELD;
-                active = false;
-            }
             uint32_t sw = 2;
 #pragma unroll
             for (int k = 2; k < NS; k++)
