@@ -216,6 +216,8 @@ struct DecodeSummary {
                                    // have to agree, and the host makes sure nothing waits unreported if they do not)
     uint32_t pad[2];
 };
+constexpr uint32_t HDR_RESIDENT = 16;       // dwords the header parser tops the ring up to before a group of reads (one
+                                            // chunk: the most ensure() may ask of a two-chunk ring)
 constexpr uint32_t SUMMARY_PARTS = 64;      // the fast pass adds into summary[1 + block % 64]; k_finalize folds them into summary[0]
 constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
 constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs ...
@@ -1168,6 +1170,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     hdr_restart = restart;
                     if (restart) {
                         // ---- restart header (src/mlp.c:822-851)
+                        // (the whole wave tops its rings up HERE, together: a lane needs a refill once or twice per header, but over 64 lanes
+                        //  at 64 different positions nearly every read of the parse below had some lane waiting for memory, and the wave
+                        //  with it -- 70 memory round trips per header instead of a few)
+                        rd.ensure(HDR_RESIDENT);
                         const uint32_t h0 = rd.read(14);           // 13u sync, 1u noise_type
                         rd.read(16);                               // output_timestamp
                         min_ch = rd.read(4);
@@ -1250,6 +1256,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             bypass_mask = 0;
                             outch_pack = 0;
                             for (uint32_t m = 0; m < matrix_len && ok; m++) {
+                                rd.ensure(HDR_RESIDENT);           // (a matrix is at most 145 bits)
                                 const uint32_t oc = rd.read(4);
                                 const uint32_t frac = rd.read(4);
                                 if (oc > max_mat_ch || frac > 14) {
@@ -1322,6 +1329,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         }
                         // ---- per-channel parameters (runtime loop: cold code)
                         for (uint32_t k = 0; k < nslots && ok; k++) {
+                            rd.ensure(HDR_RESIDENT);               // (a channel's parameters are at most 16 dwords)
                             const uint32_t c = min_ch + k;
                             uint32_t pk_old = 0;
                             int32_t sho_old = 0;
