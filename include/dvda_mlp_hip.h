@@ -181,6 +181,12 @@ int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *ctx, uint32_t *n_segments, void
  * create time); *launches receives the count.  Blocks until those launches have finished. */
 int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *launches);
 
+/* Range-checked diagnostic build (-DDVDA_BOUNDS, tests/test_gpu_soak.py): every index a kernel forms into a
+ * workspace of the library is compared with the workspace's size; out4 = {violations so far, and of the first
+ * one: array tag, index, capacity}.  Returns 1 from a checked build, 0 from the shipped library (which does not
+ * check and reports zeros), < 0 on error. */
+int dvda_mlp_hip_bounds_violations(unsigned long long *out4);
+
 /* Which fast-pass kernels run.  0 (default): chosen per batch from the substream counts the index
  * found -- streams with one substream take the one-lane-per-segment kernel, streams with two the
  * two-wave kernel, a mixed batch both (a kernel whose class is absent exits at once).  1 / 2 force one

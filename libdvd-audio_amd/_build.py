@@ -19,8 +19,10 @@ DISC_SRCS = [os.path.join(HERE, "csrc", "dvda_disc.c"),
              os.path.join(os.path.dirname(HERE), "include", "dvd-audio-hip.h"),
              os.path.join(os.path.dirname(HERE), "include", "dvda_mlp_hip.h")]
 
-HIP_SRCS = [os.path.join(HERE, "csrc", f) for f in
-            ("mlp_hip.hip", "mlp_stream.c", "mlp_decode.h", "mlp_index.h", "mlp_tables.h")]
+# [0] the HIP translation unit, [1] the streaming tier; behind them EVERY header under csrc/ (the staleness
+# test looks at all of them: an edit to any header mlp_hip.hip includes rebuilds the library)
+HIP_SRCS = [os.path.join(HERE, "csrc", "mlp_hip.hip"), os.path.join(HERE, "csrc", "mlp_stream.c")]
+HIP_SRCS += sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))
 HIP_SRCS.append(os.path.join(os.path.dirname(HERE), "include", "dvda_mlp_hip.h"))
 SYNTH_SRCS = [os.path.join(HERE, "synth", f) for f in ("mlp_synth.c", "mlp_synth.h")]
 
@@ -61,6 +63,17 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     return target
 
 
+BOUNDS_SO = os.path.join(HERE, "libdvda_mlp_hip_bounds.so")
+
+
+def build_bounds(force=False):
+    """The range-checked diagnostic build (csrc/mlp_bounds.h; tests/test_gpu_soak.py loads it through
+    DVDA_MLP_HIP_LIB).  Never the shipped library."""
+    if not force and not _stale(BOUNDS_SO, HIP_SRCS):
+        return BOUNDS_SO
+    return build_hip(force=True, defines=["DVDA_BOUNDS=1"], out=BOUNDS_SO)
+
+
 def build_disc(force=False):
     """tier C (dvd-audio.h mirror): links against libdvda_mlp_hip.so next to it."""
     if not force and not _stale(DISC_SO, DISC_SRCS + [HIP_SO]):
@@ -95,4 +108,4 @@ def build_synth(force=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_disc(force), build_tool(force), build_synth(force)
+    return build_hip(force, verbose), build_disc(force), build_tool(force), build_synth(force), build_bounds(force)

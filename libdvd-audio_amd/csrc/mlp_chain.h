@@ -50,6 +50,7 @@ struct ChainArgs {
     uint32_t interleaved;
     uint32_t wav_bits;             // 0, or 16 / 24: packed WAV payload instead of int32 values
     uint32_t remat_blocks;         // k_chain_rematrix: workgroups per segment (1 unless segments are very long)
+    WsCaps caps;                   // what the workspaces hold (block-record walks stop there; the range-checked build)
 };
 
 __device__ __forceinline__ uint32_t chain_n_seg(const ChainArgs &a)
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(256) void k_chain_lists(ChainArgs a)
         return;
     const uint4 p = a.plan[i], q = a.plan[i + 1];
     if (q.y != p.y)
-        a.def_list[p.y] = i;
+        DVDA_AT(a.def_list, p.y, a.caps.max_seg, BT_C_DEF) = i;
     if (q.z != p.z)
-        a.head_list[p.z] = i;
+        DVDA_AT(a.head_list, p.z, a.caps.max_seg, BT_C_HEAD) = i;
 }
 
 // ------------------------------------------------------------------------------------------------ filter
@@ -274,9 +275,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const uint32_t n = chain_n_seg(a);
     if (ci >= a.plan[n].z || k >= 6u)
         return;
-    uint32_t seg = a.head_list[ci];
-    const SegRec r0 = a.seg[seg];
-    const StreamRec sr = a.streams[r0.stream];
+    uint32_t seg = DVDA_AT(a.head_list, ci, a.caps.max_seg, BT_C_HEAD);
+    const SegRec r0 = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
+    const StreamRec sr = DVDA_AT(a.streams, r0.stream, a.caps.max_streams, BT_STREAMS);
     const uint32_t S = (sr.sync >> 24) & 0xFu;
     if (sub >= S)
         return;
@@ -316,9 +317,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
 
     for (;;) {
-        const SegRec r = a.seg[seg];
+        const SegRec r = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
         const uint32_t ss = a.seg_status[seg];
-        const uint32_t meta = a.seg_meta[(size_t)seg * 2 + sub];
+        const uint32_t meta = DVDA_AT(a.seg_meta, (size_t)seg * 2 + sub, a.caps.lanes, BT_C_META);
+        bool overrun = false;           // the walk over this segment's block records left the records: stop, say so
         if (!fail) {
             if (ss & ~ST_INFO)
                 fail = ss & ~ST_INFO;               // the parse pass stopped on an error here
@@ -336,14 +338,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         } else {
             const uint32_t min_ch = meta & 0xFu, max_ch = (meta >> 4) & 0xFu;
             const uint32_t R = (r.nframes - r.ndrop) * rpa;
-            const uint4 pl = a.plan[seg];
-            if (k <= max_ch - min_ch) {
+            const uint4 pl = DVDA_AT(a.plan, seg, a.caps.max_seg + 1u, BT_C_PLAN);
+            if (k <= max_ch - min_ch && DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES)) {
                 // the segment's planes: element (row, plane) at res_index() -- four rows of all eight planes share
                 // a 128-byte line, so the lanes of a chain (one per channel) read and write the same lines together
                 int32_t *const P = a.res + (size_t)pl.x * 8u;
                 const uint32_t plane = min_ch + k;
                 int4 *const Q = reinterpret_cast<int4 *>(P) + plane;         // group g (4 rows) of this plane: Q[g * 8]
                 const uint32_t *rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
+                // (the parse pass ends a substream's records with a terminator inside its brec_capacity(R) words; a
+                //  walk that gets there without meeting it -- records this pass did not write -- stops, and the
+                //  segment is reported, instead of following whatever the memory behind holds)
+                const uint32_t *const rp_end = (a.brec + a.caps.brec) - (rp + brec_capacity(R)) >= 0 ? rp + brec_capacity(R) - 1
+                                                                                                    : a.brec + (a.caps.brec ? a.caps.brec - 1 : 0);
                 const uint32_t nu = R >> 3;         // units of eight PCM frames: two 16-byte pieces of this lane's plane
                                                     // (a segment is a whole number of 40-frame access units)
                 if (meta & 0x200u) {
@@ -353,6 +360,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     // a block that sets filter parameters starts at `row` (src/mlp.c:1033-1068, 1260-1270)
                     auto apply_records = [&]() {
                         while (next_row == row) {
+                            if (rp >= rp_end) {
+                                overrun = true;
+                                next_row = 0xFFFFFFFFu;
+                                break;
+                            }
                             const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
                             if ((mask >> k) & 1u) {
                                 const uint32_t below = (1u << k) - 1u;
@@ -380,7 +392,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                                 }
                             }
                             rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
-                            next_row = rp[0];
+                            next_row = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
+                            overrun = overrun || rp >= rp_end;
                         }
                     };
                     auto slow_step = [&](int32_t residual) {
@@ -421,7 +434,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     bool n_has = false;
                     uint32_t tgt = 0;                // the frame it counts down to (records carry absolute frames)
                     auto preload = [&](uint32_t row_now) {
-                        const uint32_t nr = rp[0];
+                        overrun = overrun || rp >= rp_end;
+                        const uint32_t nr = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
                         n_has = false;
                         tgt = nr;
                         left = nr - row_now;                                  // (terminator: 0xFFFFFFFF, never reached)
@@ -544,7 +558,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 a.fir_ws[(size_t)(k * 8 + j) * TL + (size_t)seg * 2 + sub] = h[j];
-            if (writer)
+            // (a records walk that left its records, on any channel of the segment: reported, and the chain ends)
+            if (overrun) {
+                atomicOr(&a.seg_status[seg], ST_CAPACITY);
+                fail = ST_CAPACITY;
+            }
+            if (writer && !overrun)
                 atomicOr(&a.seg_status[seg], ST_GENERAL);       // filtered: the rematrix pass may take it
             prev_meta = meta;
         }
@@ -572,8 +591,8 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     const uint32_t j = blockIdx.x / a.remat_blocks, by0 = blockIdx.x % a.remat_blocks;
     if (j >= a.plan[n].y)
         return;
-    const uint32_t seg = a.def_list[j];
-    const uint32_t ss = a.seg_status[seg];
+    const uint32_t seg = DVDA_AT(a.def_list, j, a.caps.max_seg, BT_C_DEF);
+    const uint32_t ss = DVDA_AT(a.seg_status, seg, a.caps.max_seg, BT_C_STATUS);
     if (!(ss & ST_GENERAL) || (ss & ~ST_INFO))
         return;                                     // not filtered (its chain stopped before it)
     const SegRec r = a.seg[seg];
@@ -595,6 +614,9 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
     // (256 rows, and a segment's first row is a multiple of 40)
     __shared__ uint8_t s_b[256 * 6 * 3];
     const uint4 pl = a.plan[seg];
+    if (!DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES) ||
+        !DVDA_RANGE_OK((size_t)(pl.x / 40u) * FREC_WORDS, (size_t)(r.nframes - r.ndrop) * FREC_WORDS, a.caps.frec, BT_C_FREC))
+        return;
     int32_t *out = a.pcm + a.out_off[r.stream];
     for (uint32_t by = by0; by * 256u < R; by += a.remat_blocks) {
     const uint32_t row = by * 256u + threadIdx.x;

@@ -1,0 +1,798 @@
+// mlp_coop.h -- the wave-cooperative decode kernel: one WAVE per (restart segment, substream), for batches too
+// small to fill the chip with one LANE per (segment, substream).
+//
+// k_decode (mlp_decode.h) gives every lane a whole segment: 64 independent bit-serial parses per wave, which is the
+// right shape for >= 10^5 segments and the wrong one below ~10^4 -- a batch of 1 024 access units (BASELINE
+// configs[3]) is 16 waves on a chip with 1 024 SIMDs, and the step is one lane's latency through ~1 000
+// instructions per PCM frame.  Here the segment gets a workgroup and every step of reference src/mlp.c runs at the
+// width it really has:
+//
+//   framing, headers   src/mlp.c:392-394, 614-668, 741-1120    wave-uniform (one instruction stream, scalar
+//                                                             registers), from the access unit staged in LDS
+//   symbol SCAN        src/mlp.c:1194-1238 (the lengths only)  wave-uniform: the one truly serial chain of the
+//                                                             format -- where does the next symbol start -- is a
+//                                                             9-bit peek, a count-leading-zeros and an add per
+//                                                             symbol, on a 64-bit window kept in scalar registers;
+//                                                             it emits bit positions, nothing else
+//   residuals          src/mlp.c:1226-1238                     64 lanes, one symbol each: code-book value + LSBs cut
+//                                                             from the LDS-staged bytes at the position the scan
+//                                                             found (8 PCM frames x 8 channel slots per step)
+//   filter_channel     src/mlp.c:1243-1306                     one lane per channel of the substream (the recursion is
+//                                                             serial in time, independent across channels)
+//   rematrix + output  src/mlp.c:1308-1358, 504-533            64 PCM frames per step, once per access unit with
+//                                                             the parameters its last block left -- which is the
+//                                                             reference's own order, so what the lane kernel has to
+//                                                             defer (matrix parameters changing inside a unit, a
+//                                                             restart header inside a unit, IIR taps, six matrices)
+//                                                             is simply decoded here
+//
+// A workgroup is two waves: wave s takes substream s (a single-substream stream leaves wave 1 idle); the two meet
+// at the end of every access unit, where the last substream's wave rematrixes all channels with its own matrices
+// (src/mlp.c:575-582).  Deferred as in the lane kernel: a segment whose first block runs FIR taps (ST_CHAINED: the
+// chain passes, mlp_chain.h) and access units of non-standard length (ST_TIMING: the sequential pass).
+//
+// The host launches this kernel and the lane kernels back to back; the device decides which one acts (coop_takes():
+// segment and access-unit counts of the index), so nothing waits for a count to reach the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mlp_decode.h"
+#include "mlp_chain.h"
+
+namespace mlp {
+
+constexpr int COOP_THREADS = 128;
+constexpr int COOP_ROWS = 160;                  // PCM frames per access unit at standard timing, at most (192 kHz)
+constexpr int COOP_VSTRIDE = COOP_ROWS + 1;     // s_val[channel][frame]: odd stride, conflict-free both ways
+constexpr int COOP_STAGE_DW = 2048 + 8;         // an access unit is at most 8 190 bytes (12-bit size field)
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// wave-uniform MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206) over the access unit
+// staged in LDS as big-endian dwords; bit 0 = the top bit of staged dword 0
+struct UReader {
+    const uint32_t *w;
+    uint32_t pos;
+    __device__ __forceinline__ uint32_t peek32() const
+    {
+        const uint32_t i = (pos >> 5) < (uint32_t)COOP_STAGE_DW - 2u ? pos >> 5 : (uint32_t)COOP_STAGE_DW - 2u, o = pos & 31u;
+        const uint32_t hi = rfl(w[i]), lo = rfl(w[i + 1]);
+        return (uint32_t)((((uint64_t)hi << 32) | lo) << o >> 32);
+    }
+    __device__ __forceinline__ uint32_t read(uint32_t n)           // n in [0, 32]
+    {
+        const uint32_t v = n ? peek32() >> (32u - n) : 0u;
+        pos += n;
+        return v;
+    }
+    __device__ __forceinline__ int32_t read_signed(uint32_t n)     // sign bit first, two's complement
+    {
+        if (n == 0)
+            return 0;
+        const int32_t v = (int32_t)peek32() >> (32u - n);
+        pos += n;
+        return v;
+    }
+};
+
+// per-substream decoder state that lives in LDS (one copy per wave of the workgroup)
+struct CoopSub {
+    uint32_t pk[8];             // per channel slot, packed as in k_decode: codebook | lsb_bits<<2 | qss<<7 | shift<<11 |
+                                // iir_order<<15 | fir_order<<19 | fir_shift<<23 | iir_shift<<27 | (codebook != 0)<<31
+    int32_t sho[8];             // signed huffman offset (src/mlp.c:1152-1176)
+    uint32_t cf[8][4];          // FIR taps, int16 pairs
+    uint32_t icf[8][4];         // IIR taps, int16 pairs
+    int32_t ihist[8][8];        // IIR history a block header sets ([0] = most recent)
+    uint32_t mat[MAXMAT][5];    // matrices: 4 words of channel coefficients (int16 pairs, zero past max_matrix_channel)
+                                // + the two noise coefficients
+};
+
+__global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
+{
+    if (!coop_takes(a))
+        return;
+    __shared__ uint32_t s_stage[COOP_STAGE_DW];
+    __shared__ int32_t s_val[MAXCH][COOP_VSTRIDE];      // residuals -> filtered values, MLP channel order
+    __shared__ uint32_t s_byp[COOP_ROWS];               // bypassed LSBs of the row (last substream's)
+    __shared__ CoopSub s_sub[2];
+    __shared__ uint32_t s_err[2];
+    __shared__ uint8_t s_wav[64 * 6 * 3 + 16];          // packed WAV payload of one output step
+
+    uint32_t n_seg = *a.n_seg_ptr;
+    if (n_seg > a.max_seg)
+        n_seg = a.max_seg;
+    const uint32_t segi = blockIdx.x;
+    if (segi >= n_seg)
+        return;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const SegRec sr = a.seg[segi];
+    if ((sr.flags & (ST_FATAL_INDEX | SEG_DEAD)) || sr.nframes == 0)
+        return;
+    const uint32_t stream_first = a.streams[sr.stream].first_seg;
+    if (stream_first == 0xFFFFFFFFu)
+        return;
+    const uint32_t stream_sync = a.streams[sr.stream].sync;
+    const uint32_t S = (stream_sync >> 24) & 0xFu;
+    const uint32_t sub = wv;
+    const uint32_t assignment = (stream_sync >> 16) & 0x1Fu;
+    const uint32_t rpa = rows_per_au((stream_sync >> 8) & 0xFu);
+    const uint32_t nch_out = channel_count(assignment);
+    const uint32_t wavepk = wave_pack(assignment);
+    if (S < 1u || S > 2u || rpa == 0 || nch_out == 0) {
+        if (threadIdx.x == 0)
+            atomicOr(&a.seg_status[segi], ST_ENVELOPE);
+        return;
+    }
+    if (sub >= S)
+        return;                                 // (a single-substream stream: wave 1 has nothing to do; no barriers then)
+    const bool two = S == 2u;
+    const bool is_last = sub + 1u == S;
+    const uint32_t gl = segi * 2u + sub;        // workspace lane, as in every pass
+    const uint64_t out_base = a.out_off[sr.stream], out_stride = a.out_stride[sr.stream];
+    const uint64_t row0 = (uint64_t)(a.seg_fbase[segi] - a.seg_fbase[stream_first]) * rpa;
+    CoopSub &P = s_sub[sub];
+    const uint32_t slot = lane & 7u, rslot = lane >> 3;     // residual step: lane = (frame of the group of 8, channel slot)
+
+    // ---- wave-uniform decoder state (reference struct substream, src/mlp.c:103-115)
+    uint32_t flags = 0xFF, block_size = 8;
+    uint32_t min_ch = 0, max_ch = 0, max_mat_ch = 0, noise_shift = 0, seed = 0;
+    uint32_t matrix_len = 0, bypass_mask = 0, outch_pack = 0, oshift_pack = 0, qss_pack = 0;
+    uint32_t nslots = 0;
+    bool have_restart = false;
+    uint32_t status = 0;
+    // ---- per-lane filter state: lane k < nslots carries channel min_ch + k (src/mlp.c:297-304: never cleared)
+    int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ih[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t fc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t my_pk = 24u << 2;                   // this lane's slot (residual step: lane & 7; filter step: lane)
+    int32_t my_sho = -(1 << 23);
+    uint32_t f_shift = 0, f_qmask = 0xFFFFFFFFu;
+    bool f_iir = false;
+    if (lane < 8u) {
+        P.pk[lane] = 24u << 2;
+        P.sho[lane] = -(1 << 23);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            P.cf[lane][j] = P.icf[lane][j] = 0;
+    }
+    if (threadIdx.x < 2)
+        s_err[threadIdx.x] = 0;
+    if (two)
+        __syncthreads();
+
+    uint64_t cur = sr.off;
+    uint32_t rows_written = 0, frames_out = 0;
+    const uint32_t chk = a.seg_check[(size_t)segi * 2u + sub];
+    bool stop = false;
+    const uint32_t nthreads = two ? (uint32_t)COOP_THREADS : 64u;
+    const uint32_t tid = two ? threadIdx.x : lane;
+
+    for (uint32_t f = 0; f < sr.nframes && !stop; f++) {
+        // ================================================================ the access unit into LDS
+        // (frames start at even offsets; the stage starts at the dword that holds the first byte)
+        const uint64_t base_b = cur & ~(uint64_t)3;
+        const uint32_t hdr_dw = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.bytes + base_b));
+        const uint32_t hdr_dw1 = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(a.bytes + base_b + 4));
+        const uint32_t bit0 = (uint32_t)(cur & 3u) * 8u;
+        const uint32_t hdr = rfl((uint32_t)((((uint64_t)hdr_dw << 32) | hdr_dw1) << bit0 >> 32));
+        const uint32_t fsize = 2u * ((hdr >> 16) & 0xFFFu);
+        const uint32_t ndw = (fsize + (uint32_t)(cur & 3u) + 3u) / 4u + 2u;         // + what a peek may touch behind it
+        for (uint32_t i = tid; i < ndw; i += nthreads)
+            s_stage[i] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(a.bytes + base_b)[i]);
+        if (two)
+            __syncthreads();
+        UReader rd;
+        rd.w = s_stage;
+        rd.pos = bit0 + 32u;
+        const uint64_t frame_end = cur + fsize;
+        uint32_t err = 0;
+        bool dropped = false;
+        // ---- major sync: the segment's first unit has one (validated by the index).  Any other unit that carries a
+        //      valid one was walked through by the index because its stream parameters differ: the reference drops
+        //      it, restart header and all (src/mlp.c:449-460)
+        if (f == 0) {
+            rd.pos += 28u * 8u;
+        } else if (rd.peek32() == 0xF8726FBBu && fsize >= 32u && sr.ndrop != 0) {
+            const uint32_t save = rd.pos;
+            rd.pos = bit0 + 20u * 8u;
+            const uint32_t count = rd.read(4);
+            if (count == 1u || count == 2u)
+                dropped = true;
+            rd.pos = save;
+        }
+        uint32_t frame_rows = 0;
+        if (!dropped) {
+            // ---- substream info "1u 1u 1u 1p 12u" (+16p) (src/mlp.c:463-468, 660-667)
+            uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0;
+            bool bad = false;
+            for (uint32_t s = 0; s < S; s++) {
+                const uint32_t info = rd.read(16);
+                const uint32_t end = (info & 0xFFFu) * 2u;
+                if (info & 0x8000u)
+                    rd.read(16);
+                if (s == 0)
+                    check0 = (info >> 13) & 1u;
+                if (end < end_prev)
+                    bad = true;
+                if (s == sub) {
+                    my_start = end_prev;
+                    my_end = end;
+                }
+                end_prev = end;
+            }
+            const uint32_t data0_bit = rd.pos;                              // first substream byte (stage bits)
+            const uint64_t data0 = cur + (data0_bit - bit0) / 8u;
+            if (bad || data0 + end_prev > frame_end || (check0 && my_end - my_start < 2u)) {
+                err = ST_EOF;
+            } else {
+                const uint32_t ss_end_bit = data0_bit + 8u * (check0 ? my_end - 2u : my_end);
+                rd.pos = data0_bit + 8u * my_start;
+                uint32_t blocks_in_frame = 0;
+                bool last_block = false;
+                // ======================================================== blocks (src/mlp.c:714-807)
+                while (!err && !last_block) {
+                    bool ok = true;
+                    uint32_t e1 = ST_PARAMS;
+                    uint32_t new_iir_mask = 0;
+                    if (rd.read(1)) {
+                        const bool restart = rd.read(1) != 0;
+                        if (restart) {
+                            // ---- restart header (src/mlp.c:822-851)
+                            const uint32_t h0 = rd.read(14);           // 13u sync, 1u noise_type
+                            rd.read(16);                               // output_timestamp
+                            min_ch = rd.read(4);
+                            max_ch = rd.read(4);
+                            max_mat_ch = rd.read(4);
+                            noise_shift = rd.read(4);
+                            seed = rd.read(23);
+                            rd.read(19);
+                            rd.read(9);                                // check_data_present, lossless_check
+                            rd.read(16);
+                            if (h0 != (0x18F5u << 1) || max_ch < min_ch || max_mat_ch < max_ch) {
+                                ok = false;
+                                e1 = ST_RESTART;
+                            } else if (max_mat_ch >= 6u || max_ch - min_ch >= 6u || (!two && min_ch != 0)) {
+                                ok = false;                            // outside DVD-Audio's layouts: as k_decode
+                                e1 = ST_ENVELOPE;
+                            } else {
+                                for (uint32_t c = 0; c <= max_mat_ch; c++)
+                                    if (rd.read(6) > max_mat_ch) {
+                                        ok = false;
+                                        e1 = ST_RESTART;
+                                    }
+                                rd.read(8);                            // checksum: ignored
+                                nslots = max_ch - min_ch + 1u;
+                                have_restart = true;
+                            }
+                        }
+                        if (!have_restart && ok) {
+                            ok = false;
+                            e1 = ST_ENVELOPE;                          // parameters before any restart header
+                        }
+                        if (ok) {
+                            // ---- decoding parameters (src/mlp.c:866-990); flags bit (7-i) = flags[i]
+                            if (restart) {
+                                flags = rd.read(1) ? rd.read(8) : 0xFFu;
+                            } else if ((flags & 0x80u) && rd.read(1)) {
+                                flags = rd.read(8);
+                            }
+                            if ((flags & 0x01u) && rd.read(1)) {
+                                block_size = rd.read(9);
+                                if (block_size < 8)
+                                    ok = false;
+                            } else if (restart) {
+                                block_size = 8;
+                            }
+                            if (ok && (flags & 0x02u) && rd.read(1)) {
+                                // ---- matrices (src/mlp.c:1003-1023)
+                                matrix_len = rd.read(4);
+                                if (matrix_len > (uint32_t)MAXMAT) {
+                                    ok = false;
+                                    e1 = ST_ENVELOPE;
+                                    matrix_len = 0;
+                                }
+                                bypass_mask = 0;
+                                outch_pack = 0;
+                                for (uint32_t m = 0; m < matrix_len && ok; m++) {
+                                    const uint32_t oc = rd.read(4);
+                                    const uint32_t frac = rd.read(4);
+                                    if (oc > max_mat_ch || frac > 14) {
+                                        ok = false;
+                                        break;
+                                    }
+                                    outch_pack |= oc << (4 * m);
+                                    bypass_mask |= rd.read(1) << m;
+                                    uint32_t pair = 0, noise = 0;
+                                    for (uint32_t c = 0; c < 10; c++) {
+                                        int32_t v = 0;
+                                        if (c < max_mat_ch + 3 && rd.read(1))
+                                            v = (int32_t)((uint32_t)rd.read_signed(frac + 2) << (14 - frac));
+                                        if (c == max_mat_ch + 1)
+                                            noise |= (uint32_t)v & 0xFFFFu;
+                                        if (c == max_mat_ch + 2)
+                                            noise |= (uint32_t)v << 16;
+                                        const int32_t vc = c <= max_mat_ch ? v : 0;
+                                        if (c & 1) {
+                                            if (c < 8)
+                                                P.mat[m][c >> 1] = pair | ((uint32_t)vc << 16);
+                                        } else {
+                                            pair = (uint32_t)vc & 0xFFFFu;
+                                        }
+                                    }
+                                    P.mat[m][4] = noise;
+                                }
+                            } else if (restart) {
+                                matrix_len = 0;
+                                bypass_mask = 0;
+                            }
+                            if (ok && (flags & 0x04u) && rd.read(1)) {
+                                for (uint32_t c = 0; c <= max_mat_ch; c++) {
+                                    const int32_t v = rd.read_signed(4);
+                                    if (v < 0) {
+                                        ok = false;
+                                        e1 = ST_ENVELOPE;              // huge unsigned shift in the reference
+                                    }
+                                    oshift_pack = (oshift_pack & ~(0xFu << (4 * c))) | (((uint32_t)v & 0xFu) << (4 * c));
+                                }
+                            } else if (restart) {
+                                oshift_pack = 0;
+                            }
+                            bool qss_changed = false;
+                            if (ok && (flags & 0x08u) && rd.read(1)) {
+                                for (uint32_t c = 0; c <= max_ch; c++)
+                                    qss_pack = (qss_pack & ~(0xFu << (4 * c))) | (rd.read(4) << (4 * c));
+                                qss_changed = true;
+                            } else if (restart) {
+                                qss_pack = 0;
+                                qss_changed = true;
+                            }
+                            // ---- per-channel parameters (src/mlp.c:944-990, 1029-1120)
+                            for (uint32_t k = 0; k < nslots && ok; k++) {
+                                const uint32_t c = min_ch + k;
+                                const uint32_t pk_old = rfl(P.pk[k]);
+                                const int32_t sho_old = (int32_t)rfl((uint32_t)P.sho[k]);
+                                uint32_t codebook = pk_old & 3u;
+                                const uint32_t lb_old = (pk_old >> 2) & 31u, q_old = (pk_old >> 7) & 15u;
+                                uint32_t iir_order = (pk_old >> 15) & 0xFu, fir_order = (pk_old >> 19) & 0xFu;
+                                uint32_t fir_shift = (pk_old >> 23) & 0xFu, iir_shift = (pk_old >> 27) & 0xFu;
+                                uint32_t lsbs = lb_old + q_old;
+                                int32_t hoff = sho_old + huff_center(codebook, lb_old);
+                                bool touched = qss_changed;
+                                if (rd.read(1)) {
+                                    touched = true;
+                                    if ((flags & 0x10u) && rd.read(1)) {
+                                        // ---- FIR (src/mlp.c:1033-1068)
+                                        fir_order = rd.read(4);
+                                        uint32_t ncf[4] = {0, 0, 0, 0};
+                                        if (fir_order > 8) {
+                                            ok = false;
+                                        } else if (fir_order == 0) {
+                                            fir_shift = 0;
+                                        } else {
+                                            fir_shift = rd.read(4);
+                                            const uint32_t cbits = rd.read(5);
+                                            const uint32_t cshift = rd.read(3);
+                                            if (cbits < 1 || cbits > 16 || cbits + cshift > 16) {
+                                                ok = false;
+                                            } else {
+                                                for (uint32_t j = 0; j < fir_order; j++) {
+                                                    const uint32_t v = ((uint32_t)rd.read_signed(cbits) << cshift) & 0xFFFFu;
+                                                    ncf[j >> 1] |= v << (16u * (j & 1u));
+                                                }
+                                                if (rd.read(1))
+                                                    ok = false;
+                                            }
+                                        }
+                                        for (uint32_t j = 0; j < 4; j++)
+                                            P.cf[k][j] = ncf[j];
+                                    } else if (restart) {
+                                        fir_order = 0;
+                                        fir_shift = 0;
+                                        for (uint32_t j = 0; j < 4; j++)
+                                            P.cf[k][j] = 0;
+                                    }
+                                    if (ok && (flags & 0x20u) && rd.read(1)) {
+                                        // ---- IIR (src/mlp.c:1075-1119)
+                                        new_iir_mask |= 1u << k;
+                                        iir_order = rd.read(4);
+                                        uint32_t nic[4] = {0, 0, 0, 0};
+                                        for (uint32_t j = 0; j < 8; j++)
+                                            P.ihist[k][j] = 0;
+                                        if (iir_order > 8) {
+                                            ok = false;
+                                        } else if (iir_order == 0) {
+                                            iir_shift = 0;
+                                        } else {
+                                            iir_shift = rd.read(4);
+                                            const uint32_t cbits = rd.read(5);
+                                            const uint32_t cshift = rd.read(3);
+                                            if (cbits < 1 || cbits > 16 || cbits + cshift > 16) {
+                                                ok = false;
+                                            } else {
+                                                for (uint32_t j = 0; j < iir_order; j++) {
+                                                    const uint32_t v = ((uint32_t)rd.read_signed(cbits) << cshift) & 0xFFFFu;
+                                                    nic[j >> 1] |= v << (16u * (j & 1u));
+                                                }
+                                                if (rd.read(1)) {
+                                                    const uint32_t sbits = rd.read(4), sshift = rd.read(4);
+                                                    if (sbits == 0) {
+                                                        ok = false;
+                                                        e1 = ST_ENVELOPE;
+                                                    }
+                                                    for (uint32_t j = 0; j < iir_order; j++)
+                                                        P.ihist[k][j] = (int32_t)((uint32_t)rd.read_signed(sbits) << sshift);
+                                                } else {
+                                                    ok = false;
+                                                    e1 = ST_ENVELOPE;   // the reference indexes an emptied history
+                                                }
+                                            }
+                                        }
+                                        for (uint32_t j = 0; j < 4; j++)
+                                            P.icf[k][j] = nic[j];
+                                    } else if (restart) {
+                                        new_iir_mask |= 1u << k;
+                                        iir_order = 0;
+                                        iir_shift = 0;
+                                        for (uint32_t j = 0; j < 4; j++)
+                                            P.icf[k][j] = 0;
+                                        for (uint32_t j = 0; j < 8; j++)
+                                            P.ihist[k][j] = 0;
+                                    }
+                                    if (ok && (flags & 0x40u) && rd.read(1))
+                                        hoff = rd.read_signed(15);
+                                    else if (restart)
+                                        hoff = 0;
+                                    codebook = rd.read(2);
+                                    lsbs = rd.read(5);
+                                    if (lsbs > 24)
+                                        ok = false;
+                                } else if (restart) {
+                                    touched = true;
+                                    fir_order = fir_shift = iir_order = iir_shift = 0;
+                                    new_iir_mask |= 1u << k;
+                                    for (uint32_t j = 0; j < 4; j++)
+                                        P.cf[k][j] = P.icf[k][j] = 0;
+                                    for (uint32_t j = 0; j < 8; j++)
+                                        P.ihist[k][j] = 0;
+                                    hoff = 0;
+                                    codebook = 0;
+                                    lsbs = 24;
+                                }
+                                if (touched && ok) {
+                                    // derived per-block constants (src/mlp.c:1152-1176, 1260-1270)
+                                    const uint32_t q = nib(qss_pack, c);
+                                    if (lsbs < q) {
+                                        ok = false;
+                                        e1 = ST_ENVELOPE;              // unsigned underflow in the reference
+                                    } else {
+                                        const uint32_t lb = lsbs - q;
+                                        uint32_t shift;
+                                        if (fir_order + iir_order > 8) {
+                                            ok = false;
+                                            e1 = ST_FILTER;
+                                        }
+                                        if (fir_shift > 0 && iir_shift > 0) {
+                                            if (fir_shift != iir_shift) {
+                                                ok = false;
+                                                e1 = ST_FILTER;
+                                            }
+                                            shift = fir_shift;
+                                        } else if (fir_order > 0) {
+                                            shift = fir_shift;
+                                        } else {
+                                            shift = iir_shift;
+                                        }
+                                        if (fir_order && f == 0 && blocks_in_frame == 0)
+                                            status |= ST_CHAINED;      // needs the previous segment's history
+                                        P.sho[k] = hoff - huff_center(codebook, lb);
+                                        P.pk[k] = codebook | (lb << 2) | (q << 7) | (shift << 11) | (iir_order << 15) |
+                                                  (fir_order << 19) | (fir_shift << 23) | (iir_shift << 27) |
+                                                  (codebook ? 1u << 31 : 0u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!have_restart && ok) {
+                        ok = false;
+                        e1 = ST_ENVELOPE;
+                    }
+                    if (!ok) {
+                        err = e1;
+                        break;
+                    }
+                    if (status & ST_CHAINED)
+                        break;                      // left to the chain passes (needs the history before this segment)
+                    if (frame_rows + block_size > rpa) {
+                        err = ST_TIMING;            // more PCM frames than the standard access unit: the sequential pass
+                        break;
+                    }
+                    blocks_in_frame++;
+                    // ---- what the lanes need of the block's parameters
+                    my_pk = P.pk[slot];
+                    my_sho = P.sho[slot];
+                    uint32_t scb[6], slb[6];        // the scan's own copy: code book and LSB count per slot
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const uint32_t pkk = (uint32_t)k < nslots ? rfl(P.pk[k]) : 0u;
+                        scb[k] = pkk & 3u;
+                        slb[k] = (pkk >> 2) & 31u;
+                    }
+                    const uint32_t nbyp = (uint32_t)__popc(bypass_mask);
+                    // ================================================ rows of the block, eight at a time
+                    // ---- SCAN: where does each symbol start?  (src/mlp.c:1194-1238, lengths only)
+                    uint32_t pos = rd.pos;
+                    uint32_t widx = pos >> 5;
+                    uint64_t win;
+                    uint32_t navail;
+                    {
+                        const uint32_t d0 = rfl(s_stage[widx]), d1 = rfl(s_stage[widx + 1]);
+                        win = (((uint64_t)d0 << 32) | d1) << (pos & 31u);
+                        navail = 64u - (pos & 31u);
+                        widx += 2;
+                    }
+                    uint32_t next_dw = rfl(s_stage[widx]);
+                    uint32_t bad_code = 0;
+                    // (the window holds at least 33 bits before every symbol -- 9 of code, 24 of LSBs -- and before a
+                    //  row's bypassed LSBs: one dword more whenever it is down to 32 or less, twice if it was empty)
+                    auto refill = [&]() {
+                        if (navail <= 32u) {
+                            win |= (uint64_t)next_dw << (32u - navail);
+                            navail += 32u;
+                            widx++;
+                            next_dw = rfl(s_stage[widx < (uint32_t)COOP_STAGE_DW ? widx : 0]);
+                        }
+                    };
+                    for (uint32_t r0 = 0; r0 < block_size; r0 += 8) {
+                        const uint32_t nr = block_size - r0 < 8u ? block_size - r0 : 8u;
+                        uint32_t v_sym = 0;             // lane (frame * 8 + slot): bit position of that symbol; slot 7: the row's start
+                        for (uint32_t r = 0; r < nr; r++) {
+                            v_sym = lane == r * 8u + 7u ? pos : v_sym;
+                            // the row's bypassed LSBs (at most one per matrix) sit in front of its symbols
+                            refill();
+                            refill();
+                            pos += nbyp;
+                            win <<= nbyp;
+                            navail -= nbyp;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) {
+                                if ((uint32_t)k < nslots) {
+                                    refill();
+                                    refill();
+                                    const uint32_t t9 = (uint32_t)(win >> 55);
+                                    // the three books share one structure (mlp_tables.h): "1" + (3 - book) bits, or
+                                    // z' zeros and a one in the low 7 bits (length z' + 3)
+                                    const uint32_t z = (uint32_t)__builtin_clz((int)((t9 << 25) | 0x01000000u));
+                                    uint32_t len = (t9 & 0x100u) ? 4u - scb[k] : (z > 6u ? 6u : z) + 3u;
+                                    bad_code |= (!(t9 & 0x100u) && z > 6u && scb[k]) ? 1u : 0u;
+                                    len = scb[k] ? len : 0u;
+                                    v_sym = lane == r * 8u + (uint32_t)k ? pos : v_sym;
+                                    const uint32_t tot = len + slb[k];
+                                    pos += tot;
+                                    win <<= tot;
+                                    navail -= tot;
+                                }
+                            }
+                        }
+                        // ---- RESIDUALS: one lane per symbol (src/mlp.c:1226-1238)
+                        {
+                            const uint32_t o = v_sym;
+                            const uint32_t i = (o >> 5) < (uint32_t)COOP_STAGE_DW - 2u ? (o >> 5) : 0u;
+                            const uint64_t ww = ((((uint64_t)s_stage[i]) << 32) | s_stage[i + 1]) << (o & 31u);
+                            const uint32_t cb = my_pk & 3u, lb = (my_pk >> 2) & 31u, q = (my_pk >> 7) & 15u;
+                            const uint32_t e = huff_decode(cb, (uint32_t)(ww >> 55));
+                            const uint32_t msb = e & 0xFFu, len = e >> 8;
+                            const uint32_t lsbv = lb ? (uint32_t)((ww << len) >> (64u - lb)) : 0u;
+                            const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)my_sho) << q);
+                            const uint32_t row = frame_rows + r0 + rslot;
+                            if (rslot < nr && slot < nslots)
+                                s_val[min_ch + slot][row] = residual;
+                            if (rslot < nr && slot == 7u && is_last) {
+                                // the row's bypassed LSBs, dealt to their matrices in stream order
+                                const uint32_t field = nbyp ? (uint32_t)(ww >> (64u - nbyp)) : 0u;
+                                uint32_t bits = 0, rank = 0;
+#pragma unroll
+                                for (int m = 0; m < MAXMAT; m++) {
+                                    const uint32_t bit = (bypass_mask >> m) & 1u;
+                                    bits |= (bit & (field >> ((nbyp - 1u - rank) & 31u))) << m;
+                                    rank += bit;
+                                }
+                                s_byp[row] = bits;
+                            }
+                        }
+                    }
+                    if (bad_code) {
+                        err = ST_HUFFMAN;
+                        break;
+                    }
+                    rd.pos = pos;
+                    // ---- FILTER: lane k runs channel min_ch + k through the block's rows (src/mlp.c:1243-1306)
+                    {
+                        const uint32_t k = lane < 8u ? lane : 0u;
+                        const uint32_t pkk = P.pk[k];
+                        f_shift = (pkk >> 11) & 15u;
+                        f_qmask = 0xFFFFFFFFu << ((pkk >> 7) & 15u);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            fc[2 * j] = lo16(P.cf[k][j]);
+                            fc[2 * j + 1] = hi16(P.cf[k][j]);
+                            ic[2 * j] = lo16(P.icf[k][j]);
+                            ic[2 * j + 1] = hi16(P.icf[k][j]);
+                        }
+                        f_iir = ((pkk >> 15) & 0xFu) != 0;
+                        if ((new_iir_mask >> k) & 1u) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                ih[j] = P.ihist[k][j];
+                        }
+                        const bool any_iir = __any(lane < nslots && f_iir);
+                        if (lane < nslots) {
+                            int32_t *col = &s_val[min_ch + lane][frame_rows];
+                            if (any_iir) {
+                                for (uint32_t r = 0; r < block_size; r++)
+                                    col[r] = iir_step_one(h, fc, ih, ic, f_shift, f_qmask, col[r]);
+                            } else {
+                                for (uint32_t r = 0; r < block_size; r++)
+                                    col[r] = fir_step_one(h, fc, f_shift, f_qmask, col[r]);
+                            }
+                        }
+                    }
+                    frame_rows += block_size;
+                    // ---- "last block" bit (src/mlp.c:729); the substream tail is padding
+                    last_block = rd.read(1) != 0;
+                    if (rd.pos > ss_end_bit)
+                        err = ST_EOF;
+                }
+                if (!err && !(status & ST_CHAINED)) {
+                    if (frame_rows != rpa)
+                        err = ST_TIMING;            // the sequential pass decodes such a stream in order
+                    else if ((chk >> 2) == f)
+                        err = (chk & 1u) ? ST_PARITY : ST_CRC;      // k_au_check's verdict (src/mlp.c:675-706)
+                }
+            }
+        }
+        // ================================================================ the two substreams meet
+        bool quit = err != 0 || (status & ST_CHAINED) != 0;
+        if (two) {
+            if (lane == 0)
+                s_err[sub] = err | (status & ST_CHAINED);
+            __syncthreads();
+            quit = (s_err[0] | s_err[1]) != 0;
+        }
+        status |= err;
+        if (quit) {
+            stop = true;
+        } else if (!dropped && is_last) {
+            // ============================================================ rematrix + output of the access unit
+            // (src/mlp.c:504-533, 1308-1358: once per unit, with the parameters its last block left, all channels
+            //  with the last substream's matrices)
+            const uint64_t au_row0 = row0 + (uint64_t)frames_out * rpa;
+            for (uint32_t rb = 0; rb < rpa; rb += 64u) {
+                const uint32_t row = rb + lane;
+                // the noise generator steps once per PCM frame (src/mlp.c:1327-1334): this lane's frame is `lane` steps on
+                uint32_t sd = seed;
+                for (uint32_t i = 0; i < lane; i++) {
+                    const uint32_t shifted = (sd >> 7) & 0xFFFFu;
+                    sd = (sd << 16) ^ shifted ^ (shifted << 5);
+                }
+                int32_t ch[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    ch[c] = row < rpa ? s_val[c][row < rpa ? row : 0] : 0;
+                const uint32_t bypass_bits = s_byp[row < rpa ? row : 0];
+                const uint32_t shifted = (sd >> 7) & 0xFFFFu;
+                const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(sd >> 15) << noise_shift);
+                const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
+                for (uint32_t m = 0; m < matrix_len; m++) {
+                    const uint32_t nz = P.mat[m][4];
+                    int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        const uint32_t w = P.mat[m][c >> 1];
+                        acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(w) : lo16(w));
+                    }
+                    const uint32_t oc = nib(outch_pack, m);
+                    const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) + ((bypass_bits >> m) & 1u));
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        ch[c] = (uint32_t)c == oc ? nv : ch[c];
+                }
+                if (oshift_pack) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        if ((uint32_t)c <= max_mat_ch)
+                            ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
+                }
+                // the generator's state after this step's frames (64, or what is left of the unit)
+                {
+                    const uint32_t adv = rpa - rb < 64u ? rpa - rb : 64u;
+                    for (uint32_t i = 0; i < adv; i++) {
+                        const uint32_t sh2 = (seed >> 7) & 0xFFFFu;
+                        seed = (seed << 16) ^ sh2 ^ (sh2 << 5);
+                    }
+                }
+                // ---- RIFF order (src/mlp.c:416-438, 527-533), the caller's layout
+                const uint64_t orow = au_row0 + row;
+                const uint32_t nvalid_u = rpa - rb < 64u ? rpa - rb : 64u;
+                uint32_t nvalid = nvalid_u;                 // rows of this step that fit the caller's buffer
+                if (au_row0 + rb >= out_stride)
+                    nvalid = 0;
+                else if (au_row0 + rb + nvalid > out_stride)
+                    nvalid = (uint32_t)(out_stride - (au_row0 + rb));
+                if (nvalid < nvalid_u)
+                    status |= ST_OVERFLOW;
+                int32_t *out = a.pcm + out_base;
+                if (a.wav_bits) {
+                    // packed little-endian payload (write_signed): bytes assembled in LDS, consecutive dwords out
+                    // (a step starts dword-aligned: 64 rows, and a unit's first row is a multiple of 40)
+                    const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
+                    if (lane < nvalid) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            if ((uint32_t)c < nch_out) {
+                                const uint32_t u = wav_signed(ch[c], a.wav_bits);
+                                uint8_t *e = s_wav + lane * spf + nib(wavepk, c) * nb;
+                                e[0] = (uint8_t)u;
+                                e[1] = (uint8_t)(u >> 8);
+                                if (nb == 3u)
+                                    e[2] = (uint8_t)(u >> 16);
+                            }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t nbytes = nvalid * spf;
+                    uint8_t *ob = reinterpret_cast<uint8_t *>(out) + (au_row0 + rb) * spf;
+                    const uint32_t *sd32 = reinterpret_cast<const uint32_t *>(s_wav);
+                    for (uint32_t d = lane; d < (nbytes >> 2); d += 64u)
+                        reinterpret_cast<uint32_t *>(ob)[d] = sd32[d];
+                    for (uint32_t b = (nbytes & ~3u) + lane; b < nbytes; b += 64u)
+                        ob[b] = s_wav[b];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                } else if (lane < nvalid) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        if ((uint32_t)c < nch_out)
+                            out[a.interleaved ? orow * nch_out + nib(wavepk, c)
+                                                       : (uint64_t)nib(wavepk, c) * out_stride + orow] = ch[c];
+                }
+                rows_written += nvalid;
+            }
+        }
+        if (!dropped && !quit)
+            frames_out++;
+        cur = frame_end;
+        if (two)
+            __syncthreads();            // the stage and the values are free again
+    }
+
+    // ---- what a following segment (or a later call) continues from: the FIR history at the segment's end
+    if (!stop && a.fir_ws) {
+        if (lane < 6u) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                a.fir_ws[(size_t)(lane * 8u + j) * a.total_lanes + gl] = lane < nslots ? h[j] : 0;
+        }
+        if (lane == 0)
+            a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8);
+    }
+    if (lane == 0) {
+        uint32_t my_rows = 0;
+        if (status) {
+            const uint32_t old = atomicOr(&a.seg_status[segi], status);
+            if ((status & ST_CHAIN) && !(old & ST_CHAIN))
+                my_rows = (sr.nframes - sr.ndrop) * rpa;
+        }
+        if (my_rows) {
+            DecodeSummary *const part = a.summary + 1 + (blockIdx.x % SUMMARY_PARTS);
+            atomicAdd(&part->chain_segs, 1u);
+            atomicAdd(&part->chain_rows, (unsigned long long)my_rows);
+            atomicMax(&part->chain_max_rows, my_rows);
+        }
+        if (is_last)
+            a.seg_rows[segi] = rows_written;
+    }
+}
+
+} // namespace mlp

@@ -39,6 +39,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mlp_bounds.h"
 #include "mlp_index.h"
 #include "mlp_tables.h"
 
@@ -47,92 +48,30 @@ namespace mlp {
 constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
 // fast pass over two-substream streams: one wave per (64 segments, substream); see k_decode
-#ifndef DVDA_WS_THREADS
-#define DVDA_WS_THREADS 256
-#endif
-constexpr int WS_THREADS = DVDA_WS_THREADS;
-#ifndef DVDA_WS_SLOTS
-#define DVDA_WS_SLOTS 4
-#endif
-constexpr int WS_SLOTS = DVDA_WS_SLOTS;   // channels per substream the two-wave kernel keeps in registers (more: ST_COLD)
+constexpr int WS_THREADS = 256;
+constexpr int WS_SLOTS = 4;   // channels per substream the two-wave kernel keeps in registers (more: ST_COLD)
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
-#ifndef DVDA_RING_PLANES
-#define DVDA_RING_PLANES 8
-#endif
-constexpr int RING_PLANES = DVDA_RING_PLANES;   // planes x 16 B per lane (8 = 128-byte ring)
+constexpr int RING_PLANES = 8;                  // planes x 16 B per lane (8 = 128-byte ring)
 constexpr int RING_DWORDS = RING_PLANES * 4;
 constexpr int CHUNK_DWORDS = 16;                // 64-byte fill granule
-#ifndef DVDA_WS_BALANCE
-#define DVDA_WS_BALANCE 1        // two-wave layout: the first substream's wave rematrixes and stores
-#endif
-#ifndef DVDA_OUT_ROWS
-#define DVDA_OUT_ROWS 4
-#endif
-constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel and flush
-// Experiment, off: the ring holds the stream's dwords already in big-endian value order (swapped once when a
-// 64-byte chunk lands, 16 swaps per ~5 PCM frames) instead of swapping every dword the parser looks at (6+
-// per frame).  Measured neutral (round 2, tools/ab_bench.sh: 4.44 ms either way).
-#ifndef DVDA_RING_SWAPPED
-#define DVDA_RING_SWAPPED 0
-#endif
-// Experiment, off: channel slots a lane does not carry (k >= nslots) hold all-zero parameters (set at every
-// restart header) -- they read no bits and produce 0, so the row loop needs no per-lane "does this lane carry
-// slot k" test, only a wave-uniform "does any lane" one.  Measured (round 2, tools/pmc_valu_ab.sh): the
-// unconditional history moves cost the register allocator more copies than the selects they replace --
-// SQ_INSTS_VALU 2.118e9 vs 2.001e9 per launch, kernel time the same.
-#ifndef DVDA_YIELD_CHECK
-#define DVDA_YIELD_CHECK 1
-#endif
-#ifndef DVDA_YIELD_ASK
-#define DVDA_YIELD_ASK 1
-#endif
-// A lane whose wave has emptied around it -- this many of the wave's 64 lanes stopped at their first block because
-// their segment continues a history (ST_CHAINED) -- hands its segment to the chain passes as well, while it is
-// still within its first two access units: the chain passes run anyway, and a wave kept alive by a few lanes holds
-// the whole fast pass (and everything that waits for it) for the time one segment takes, 2.6 ms.  0: off.
-#ifndef DVDA_YIELD_LONELY
-#define DVDA_YIELD_LONELY 48
-#endif
-// Row-loop experiments of round 2 (tools/ab_build.py + tools/ab_bench.sh):
-//   DVDA_SKIP_SCALAR  the "no lane carries slot k" skip tests a wave-uniform slot count kept in an SGPR
-//                     (refreshed after header parses) instead of a per-row v_cmp + ballot + branch on VCC
-//   DVDA_ADV2_FREE    the rare second window step without its wave-uniform branch (three more selects)
-//   DVDA_FIR_SPLIT    keep the two FIR accumulators apart (the compiler folds them into one 8-deep chain)
-#ifndef DVDA_SKIP_SCALAR
-#define DVDA_SKIP_SCALAR 0
-#endif
-#ifndef DVDA_ADV2_FREE
-#define DVDA_ADV2_FREE 0
-#endif
-#ifndef DVDA_FIR_SPLIT
-#define DVDA_FIR_SPLIT 0
-#endif
-#ifndef DVDA_UNIFORM_SLOTS
-#define DVDA_UNIFORM_SLOTS 0
-#endif
-#if DVDA_RING_SWAPPED
-#define DVDA_RING_IN(x) __builtin_bswap32(x)     // memory dword -> ring dword
-#define DVDA_RING_OUT(x) (x)                     // ring dword -> stream-order value
-#define DVDA_RING_BYTE(v, i) (((v) >> (24 - 8 * (i))) & 0xFFu)   // i-th byte of the stream in a ring dword
-#else
-#define DVDA_RING_IN(x) (x)
-#define DVDA_RING_OUT(x) __builtin_bswap32(x)
-#define DVDA_RING_BYTE(v, i) (((v) >> (8 * (i))) & 0xFFu)
-#endif
+constexpr int OUT_ROWS = 4;                     // PCM frames staged per channel and flush
 // (8 frames = whole 32-byte sectors and half the write requests, 16 = whole 64-byte writes, which the
 //  memory side takes 4 x faster than partial ones -- tools/fetch_calib.hip.  Neither fits: four
 //  2-wave workgroups share a CU only up to ~31 KB of LDS each (measured: 30 208 B fits, 32 256 B
-//  drops to three), the ring and the CRC tables take 17.9 KB, and an 8-frame tile, even with its
-//  last frame kept in registers, needs 21.5 KB.)
-
-// Diagnostic build switches (tools/ab_bench.sh): never defined in the shipped library.
-//   DVDA_EXP_NOSTORE  keep PCM values alive but do not store them (prices the write path)
-//   DVDA_EXP_NOCRC    skip the parity/CRC-8 check (prices it)
+//  drops to three), and an 8-frame tile, even with its last frame kept in registers, needs 21.5 KB.)
+// A lane whose wave has emptied around it -- this many of the wave's 64 lanes stopped at their first block because
+// their segment continues a history (ST_CHAINED) -- hands its segment to the chain passes as well, while it is
+// still within its first two access units: the chain passes run anyway, and a wave kept alive by a few lanes holds
+// the whole fast pass (and everything that waits for it) for the time one segment takes, 2.6 ms.
+constexpr uint32_t YIELD_LONELY = 48;
+// The row-loop experiments of rounds 1 and 2 that lost (ring holding byte-swapped dwords, slot tests on a scalar
+// count, the second window step without its branch, split FIR accumulators, uniform slots, line-aware prefetch,
+// store cache policies, alternating wave roles) are no longer in this file: DESIGN.md section 4 keeps what each
+// measured.  Two diagnostic builds remain (tools/stamp_run.py, tools/coverage_run.py), never in the shipped library:
 //   DVDA_EXP_STAMP    accumulate s_memtime deltas per loop phase into DecodeArgs.dbg
-//   DVDA_EXP_UNDEFPF  leave the prefetch registers of the main loop undefined, as round 1 had them (the form
-//                     that miscompiled the two-wave frame-major instance under unrelated changes);
-//   DVDA_EXP_INITPF   zero them with instructions instead of the empty asm (costs a wait per row)
+//   DVDA_EXP_COUNT    count how often the rarely taken paths run
+// and the range-checked build of tests/test_gpu_soak.py (DVDA_BOUNDS, mlp_bounds.h).
 #if defined(DVDA_EXP_STAMP)
 #define DVDA_STAMP(i)                                                    \
     do {                                                                 \
@@ -149,31 +88,22 @@ constexpr int OUT_ROWS = DVDA_OUT_ROWS;         // PCM frames staged per channel
 #else
 #define DVDA_COV(i) ((void)0)
 #endif
-#if defined(DVDA_EXP_NOSTORE)
-// diagnostic: the kernel without its 16-byte PCM stores (what do they cost?)
-#define DVDA_STORE_V4(dst, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
-#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_) asm volatile("" ::"v"(a_), "v"(b_), "v"(c_), "v"(d_), "v"(dst))
-#else
 // One 16-byte store instruction, opaque to the optimizer: left to itself the compiler merges this
 // store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
 // which doubles the store instructions and splits every half-sector write in two.
 typedef int dvda_v4i __attribute__((ext_vector_type(4)));
-#ifndef DVDA_STORE_MODS
-#define DVDA_STORE_MODS ""
-#endif
 #define DVDA_STORE_V4(dst, a_, b_, c_, d_)                                                          \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_MODS ::"v"(dst), "v"(v4_) : "memory"); \
+        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v4_) : "memory");           \
     } while (0)
 // the same at a constant byte offset from one base address
 #define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" DVDA_STORE_MODS                   \
+        asm volatile("global_store_dwordx4 %0, %1, off offset:%2"                                   \
                      ::"v"(dst), "v"(v4_), "n"(off_) : "memory");                                   \
     } while (0)
-#endif
 
 // (8-byte store at a constant byte offset: the tail of a 72-byte run of packed 24-bit samples)
 typedef int dvda_v2i __attribute__((ext_vector_type(2)));
@@ -289,6 +219,8 @@ struct DecodeArgs {
     uint32_t only_S;               // fast pass: decode only streams with this many substreams (0 = all)
     uint32_t *seg_meta;            // per workspace lane: min_ch | max_ch << 4 at the segment's end
     uint32_t *yield_req;           // per segment: the next segment of the stream continues this one's FIR history
+    const uint32_t *seg_check;     // per (segment, substream): first access unit that fails parity / CRC-8 << 2 | which
+                                   // (1 parity, 2 CRC); 0xFFFFFFFF none -- written by k_au_check (mlp_check.h)
     // sequential pass: lane pair j decodes stream list[list_base + j] from its first segment on
     // chain parse pass: lane (pair) j parses deferred segment list[list_base + j]
     const uint32_t *list;
@@ -299,9 +231,25 @@ struct DecodeArgs {
     int32_t *res;                  // [deferred rows][8 planes], plane-major per segment
     uint32_t *brec;                // block records, per (segment, substream)
     uint32_t *frec;                // per access unit: the rematrix parameters its last block leaves
+    WsCaps caps;                   // what the workspaces hold (consulted by the range-checked build only, mlp_bounds.h)
+    uint32_t coop;                 // who decodes the batch: 0 the device decides (coop_takes), 64 always the wave-cooperative
+                                   // kernel (mlp_coop.h), anything else always the lane kernels
 };
 
-__device__ const CrcTable d_crc = make_crc();
+constexpr uint32_t COOP_MAX_SEG = 8192;         // batches with more segments than this go to the lane kernels ...
+constexpr uint32_t COOP_MAX_AU = 98304;         // ... and so do batches with more access units (one wave scans ~25 us per unit)
+// does the cooperative kernel decode this batch (else the lane kernels do)?  DecodeArgs.coop: 0 auto, 64 always, else never
+__device__ __forceinline__ bool coop_takes(const DecodeArgs &a)
+{
+    if (a.coop)
+        return a.coop == 64u;
+    uint32_t n_seg = *a.n_seg_ptr;
+    if (n_seg > a.max_seg)
+        n_seg = a.max_seg;
+    return n_seg <= COOP_MAX_SEG && a.seg_fbase[n_seg] <= COOP_MAX_AU;
+}
+
+
 
 __device__ __forceinline__ int32_t mask_q(int32_t x, uint32_t q)
 {
@@ -333,11 +281,11 @@ __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, cons
 {
     // dst = slot of the chunk's first dword; the chunk is 16-dword aligned, so no wrap inside it
     if (first_plane)
-        dst[RING_DWORDS * 64] = DVDA_RING_IN(a.x);
-    dst[0 * 64] = DVDA_RING_IN(a.x);  dst[1 * 64] = DVDA_RING_IN(a.y);  dst[2 * 64] = DVDA_RING_IN(a.z);  dst[3 * 64] = DVDA_RING_IN(a.w);
-    dst[4 * 64] = DVDA_RING_IN(b.x);  dst[5 * 64] = DVDA_RING_IN(b.y);  dst[6 * 64] = DVDA_RING_IN(b.z);  dst[7 * 64] = DVDA_RING_IN(b.w);
-    dst[8 * 64] = DVDA_RING_IN(c.x);  dst[9 * 64] = DVDA_RING_IN(c.y);  dst[10 * 64] = DVDA_RING_IN(c.z); dst[11 * 64] = DVDA_RING_IN(c.w);
-    dst[12 * 64] = DVDA_RING_IN(d.x); dst[13 * 64] = DVDA_RING_IN(d.y); dst[14 * 64] = DVDA_RING_IN(d.z); dst[15 * 64] = DVDA_RING_IN(d.w);
+        dst[RING_DWORDS * 64] = (a.x);
+    dst[0 * 64] = (a.x);  dst[1 * 64] = (a.y);  dst[2 * 64] = (a.z);  dst[3 * 64] = (a.w);
+    dst[4 * 64] = (b.x);  dst[5 * 64] = (b.y);  dst[6 * 64] = (b.z);  dst[7 * 64] = (b.w);
+    dst[8 * 64] = (c.x);  dst[9 * 64] = (c.y);  dst[10 * 64] = (c.z); dst[11 * 64] = (c.w);
+    dst[12 * 64] = (d.x); dst[13 * 64] = (d.y); dst[14 * 64] = (d.z); dst[15 * 64] = (d.w);
 }
 
 // ---------------------------------------------------------------- cold helpers
@@ -348,33 +296,6 @@ __device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint3
 {
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     ring_store16(dst, a, b, c, d, first_plane);
-}
-
-// Byte-wise ends of the parity/CRC check (src/mlp.c:1397-1398 and 690-706).
-// st = crc | fin << 8 | bad_parity << 16 | bad_crc << 17 ; returns (par << 32) | new st.
-__device__ __attribute__((noinline)) uint64_t crc_tail(uint32_t v, uint32_t first_byte, uint32_t rem,
-                                                       uint32_t st, uint32_t par, const uint8_t *tab)
-{
-    uint32_t crc = st & 0xFF, fin = (st >> 8) & 0xFF, flags = st >> 16;
-    for (uint32_t i = first_byte; i < 4 && rem; i++, rem--) {
-        const uint32_t b = DVDA_RING_BYTE(v, i);
-        if (rem > 3) {
-            par ^= b;
-            crc = tab[crc ^ b];
-        } else if (rem == 3) {              // last data byte: "final_crc" = state xor byte
-            par ^= b;
-            fin = crc ^ b;
-        } else if (rem == 2) {              // parity byte
-            uint32_t p = par ^ (par >> 16);
-            p = (p ^ (p >> 8)) & 0xFF;
-            if (((p ^ b) & 0xFF) != 0xA9)
-                flags |= 1;
-        } else {                            // CRC-8 byte
-            if (fin != b)
-                flags |= 2;
-        }
-    }
-    return ((uint64_t)par << 32) | (crc | (fin << 8) | (flags << 16));
 }
 
 // IIR taps (src/mlp.c:1289-1291, 1299) are rare on DVD-Audio discs: kept out of
@@ -407,78 +328,26 @@ __device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride,
 struct BitReader {
     const uint4 *gsrc;      // global bytes as 16-byte units
     uint32_t *ring;         // this lane's column: wave ring + lane
-    const uint8_t *crc_tab; // LDS, 4 x 256
     uint32_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
     uint32_t hi, lo, nx;    // stream dwords next-3, next-2, next-1 (big-endian order)
     uint32_t ofs;           // bit offset of the next unread bit inside (hi:lo)
     uint32_t next;          // absolute index of the dword after nx
     uint32_t fillpos;       // ring holds dwords [lo_valid, fillpos); fillpos is a multiple of 16
     uint32_t lo_valid;
-    // parity / CRC-8 over the substream, hashed from the ring behind the parser
-    uint32_t crc_pos;       // next dword to hash
-    uint32_t crc_rem;       // bytes left in [substream data .. parity, crc]; 0 = off
-    uint32_t crc_st;        // crc | fin << 8 | bad_parity << 16 | bad_crc << 17
-    uint32_t par;
 
     __device__ __forceinline__ uint32_t *slot(uint32_t d) const
     {
         return ring + ((d & (RING_DWORDS - 1)) << 6);
     }
-    __device__ __forceinline__ uint32_t ld(uint32_t d) const { return DVDA_RING_OUT(*slot(d)); }
+    __device__ __forceinline__ uint32_t ld(uint32_t d) const { return __builtin_bswap32(*slot(d)); }
     __device__ __forceinline__ void filled()
     {
         fillpos += CHUNK_DWORDS;
         if (fillpos - lo_valid > (uint32_t)RING_DWORDS)
             lo_valid = fillpos - RING_DWORDS;                   // the oldest chunk was overwritten
     }
-    // hashes ring dwords [crc_pos, limit) into the parity/CRC state (limit <= fillpos)
-    __device__ __forceinline__ void crc_catchup(uint32_t limit)
-    {
-        // whole dwords: a loop with nothing but the hash in it (the out-of-line tail below used to sit
-        // in the same loop and cost every iteration its call frame)
-        {
-            // (one counter: the dwords there are, capped by the dwords that are whole)
-            const int32_t avail = (int32_t)(limit - crc_pos);
-            uint32_t steps = crc_rem >= 7u ? (crc_rem - 3u) >> 2 : 0u;
-            steps = avail > 0 ? (steps < (uint32_t)avail ? steps : (uint32_t)avail) : 0u;
-            crc_rem -= 4u * steps;
-            for (; steps; steps--) {
-                const uint32_t v = *slot(crc_pos);
-                crc_pos++;
-                // slicing-by-4: only the first lookup depends on the running state
-                const uint32_t c = crc_st & 0xFF;
-                const uint32_t n = crc_tab[768 + (c ^ DVDA_RING_BYTE(v, 0))] ^ crc_tab[512 + DVDA_RING_BYTE(v, 1)] ^
-                                   crc_tab[256 + DVDA_RING_BYTE(v, 2)] ^ crc_tab[DVDA_RING_BYTE(v, 3)];
-                crc_st = (crc_st & ~0xFFu) | n;
-                par ^= v;
-            }
-        }
-        if (__builtin_expect(crc_rem == 0 || crc_rem >= 7, 1))
-            return;
-        // the last 1..6 bytes of the substream's data (and the general form)
-        while (crc_rem && (int32_t)(limit - crc_pos) > 0) {
-            const uint32_t v = *slot(crc_pos);
-            crc_pos++;
-            if (__builtin_expect(crc_rem >= 7, 1)) {
-                const uint32_t c = crc_st & 0xFF;
-                const uint32_t n = crc_tab[768 + (c ^ DVDA_RING_BYTE(v, 0))] ^ crc_tab[512 + DVDA_RING_BYTE(v, 1)] ^
-                                   crc_tab[256 + DVDA_RING_BYTE(v, 2)] ^ crc_tab[DVDA_RING_BYTE(v, 3)];
-                crc_st = (crc_st & ~0xFFu) | n;
-                par ^= v;
-                crc_rem -= 4;
-            } else {
-                const uint64_t r = crc_tail(v, 0, crc_rem, crc_st, par, crc_tab);
-                crc_st = (uint32_t)r;
-                par = (uint32_t)(r >> 32);
-                crc_rem = crc_rem > 4 ? crc_rem - 4 : 0;
-            }
-        }
-    }
     __device__ __forceinline__ void fill_sync()
     {
-        // the chunk about to be overwritten must already be hashed
-        if (crc_rem && (int32_t)(fillpos + CHUNK_DWORDS - RING_DWORDS - crc_pos) > 0)
-            crc_catchup(fillpos);
         const uint32_t c = fillpos < max_chunk ? fillpos : max_chunk;
         ring_fill_sync(gsrc + (c >> 2), slot(fillpos), (fillpos & (RING_DWORDS - 1)) == 0);
         filled();
@@ -497,7 +366,7 @@ struct BitReader {
         next++;
         ofs -= 32;
     }
-    // repositions the reader; the parity/CRC check must be finished (crc_rem == 0)
+    // repositions the reader
     __device__ __forceinline__ void seek_byte(uint64_t byte_pos)
     {
         const uint32_t t = (uint32_t)(byte_pos >> 2);
@@ -512,28 +381,6 @@ struct BitReader {
         nx = ld(t + 2);
         next = t + 3;
         ofs = (uint32_t)(byte_pos & 3) * 8;
-    }
-    // starts the parity/CRC check at byte_pos (just sought to): n data bytes + 2 trailer bytes
-    __device__ __forceinline__ void crc_begin(uint64_t byte_pos, uint32_t n_data)
-    {
-        const uint32_t first = (uint32_t)(byte_pos & 3);
-        const uint32_t total = n_data + 2;
-        crc_pos = (uint32_t)(byte_pos >> 2);
-        const uint64_t r = crc_tail(*slot(crc_pos), first, total, 0x3C, 0, crc_tab);
-        crc_pos++;
-        crc_st = (uint32_t)r;
-        par = (uint32_t)(r >> 32);
-        const uint32_t used = 4 - first;
-        crc_rem = total > used ? total - used : 0;
-    }
-    // hashes the rest of the substream (through its two trailer bytes)
-    __device__ __forceinline__ void crc_finish()
-    {
-        while (crc_rem) {
-            if ((int32_t)(fillpos - crc_pos) <= 0)
-                fill_sync();
-            crc_catchup(crc_pos + 1);
-        }
     }
     __device__ __forceinline__ uint64_t tell_bits() const { return (uint64_t)(next - 3) * 32 + ofs; }
     __device__ __forceinline__ uint32_t peek32() const
@@ -600,13 +447,8 @@ __device__ __forceinline__ uint32_t huff_decode_m(uint32_t cb, uint32_t t, uint6
     uint32_t val = (t & 0x80u) ? up : dn;
     val = z > 6u ? 0xFFu : val;
     uint32_t e = val | (((z > 6u ? 6u : z) + 3u) << 8);
-#if defined(DVDA_HUFF_PLAIN_SELECTS)
-    e = (t & 0x100u) ? a : e;
-    return e & bmask;
-#else
     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(e) : "v"(a), "s"(m_esc));
     return e & bmask;
-#endif
 }
 
 __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
@@ -640,7 +482,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // fast pass: the batch holds no stream of this kernel's class (set by the index): whole grid exits
     if (!GENERAL && a.only_S && a.cls[a.only_S - 1u] == 0)
         return;
-    __shared__ uint8_t s_crc[4 * 256];
+    // ... or the batch is small enough for the wave-cooperative kernel, which then decodes it (mlp_coop.h)
+    if (!GENERAL && !PARSE && coop_takes(a))
+        return;
     // fast pass over two-substream streams: a wave carries ONE substream of 64 segments.  The odd
     // wave of a group has each segment's last substream (the only one of a single-substream stream):
     // it gathers the row's channels, rematrixes, stages and stores.  The even wave has the first
@@ -661,9 +505,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     constexpr int TP = 6;                                         // staged planes: the channels (the chain parse pass keeps
                                                                   // a row's bypassed LSBs and noise seed in registers: with two
                                                                   // more planes its workgroup was 34 KB of LDS and only three fit a CU)
-    // (the sequential pass keeps the per-lane test: a lane there walks on through segments whose channel
-    //  ranges may differ, and a channel's history outlives the segments that do not carry it)
-    constexpr bool USLOT = DVDA_UNIFORM_SLOTS && !GENERAL;
     __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
     __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS * 2 : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
     // two-wave layout, per row of a tile: "the odd wave's channels are there" | version of the rematrix
@@ -678,15 +519,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                                     // layout, whose other substream's lane did)
     // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
     // (last substream, odd wave) for the lane that applies them (first substream, even wave)
-    constexpr bool WS_BAL = WSPEC && DVDA_WS_BALANCE;
+    constexpr bool WS_BAL = WSPEC;
     // (two copies, by version parity.  Versions are at least 8 rows apart -- a block has 8 rows or more --
     //  so at most one is written per phase, and the reader, one phase behind, has taken version v - 1 before
     //  the phase in which v + 1 overwrites it.  Word 0: a restart header set the noise seed in word 1.)
     constexpr int SPL = 64;
     __shared__ uint32_t s_par[WS_BAL ? GROUPS : 1][2][16][WS_BAL ? SPL : 1];
 
-    for (int i = threadIdx.x; i < 4 * 256; i += THREADS)
-        s_crc[i] = d_crc.t[i];
     if (threadIdx.x < WAVES)
         s_nchained[threadIdx.x] = 0;
     if (WSPEC) {
@@ -701,12 +540,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // (the only one of a single-substream stream), the even wave the first substream of the
     // two-substream ones -- so the even waves never rematrix, stage or store PCM
     const uint32_t ws_grp = (uint32_t)wv >> 1;
-#if defined(DVDA_WS_FLIP)
-    // diagnostic: which wave of a pair takes which role alternates, so that a SIMD does not collect one kind
-    const uint32_t ws_last = ((uint32_t)wv ^ ((uint32_t)wv >> 1) ^ (blockIdx.x >> DVDA_WS_FLIP)) & 1u;
-#else
     const uint32_t ws_last = (uint32_t)wv & 1u;
-#endif
     const uint32_t gl0 = blockIdx.x * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
@@ -718,7 +552,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t segi = item;
     bool active = segi < n_seg;
     if (!GENERAL && !PARSE && active && *a.hetero)
-        segi = a.lane_seg[item];                  // lanes packed by stream shape
+        segi = DVDA_AT(a.lane_seg, item, a.caps.max_seg, BT_LANE_SEG);      // lanes packed by stream shape
     if (!GENERAL && !PARSE && segi >= n_seg) {
         // (a lane the packing dealt nothing: candidates in bytes of no stream take no lane -- lane_seg is filled
         //  with 0xFFFFFFFF before every packing)
@@ -726,11 +560,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         segi = n_seg;
     }
     if (GENERAL || PARSE) {
-        active = item < a.list_n && (!PARSE || item < a.plan[n_seg].y);
+        active = item < a.list_n && (!PARSE || item < DVDA_AT(a.plan, n_seg, a.caps.max_seg + 1u, BT_PLAN).y);
         segi = 0;
         if (active) {
-            const uint32_t e = a.list[a.list_base + item];
-            segi = GENERAL ? a.streams[e].first_seg : e;
+            const uint32_t e = DVDA_AT(a.list, a.list_base + item, GENERAL ? a.caps.max_streams : a.caps.max_seg, BT_LIST);
+            segi = GENERAL ? DVDA_AT(a.streams, e, a.caps.max_streams, BT_STREAMS).first_seg : e;
             active = segi < n_seg;
         }
         if (!active)
@@ -747,8 +581,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     sr.prev = 0xFFFFFFFFu;
     uint32_t fbase = 0, stream_sync = 0, stream_first = 0;
     if (active) {
-        sr = a.seg[segi];
-        stream_first = a.streams[sr.stream].first_seg;
+        sr = DVDA_AT(a.seg, segi, a.caps.max_seg, BT_SEG);
+        stream_first = DVDA_AT(a.streams, sr.stream, a.caps.max_streams, BT_STREAMS).first_seg;
         if (stream_first == 0xFFFFFFFFu) {
             // a candidate in bytes that belong to no stream (or to a stream whose range the index refused):
             // it has no frames and no place in the output
@@ -756,7 +590,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             stream_first = segi;
         } else {
             stream_sync = a.streams[sr.stream].sync;
-            fbase = a.seg_fbase[segi] - a.seg_fbase[stream_first];
+            fbase = a.seg_fbase[segi] - DVDA_AT(a.seg_fbase, stream_first, a.caps.max_seg + 1u, BT_FBASE);
         }
     }
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
@@ -816,6 +650,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
         }
         fbuf = a.fb + (size_t)item * FB_WORDS;
+        if (active && !DVDA_RANGE_OK((size_t)item * FB_WORDS, FB_WORDS, a.caps.fb, BT_FB)) {
+            status |= ST_CAPACITY;
+            active = false;
+        }
         if (active) {
             atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
             row0 = 0;
@@ -828,7 +666,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t *brec = nullptr, *brec_end = nullptr;
     uint32_t *frec = nullptr;
     if (PARSE && active) {
-        const uint4 pl = a.plan[segi];
+        const uint4 pl = DVDA_AT(a.plan, segi, a.caps.max_seg + 1u, BT_PLAN);
         const uint32_t st_j = a.seg_status[segi];
         seg_R = (sr.nframes - sr.ndrop) * rpa;
         out_base = (uint64_t)pl.x * 8u;
@@ -841,6 +679,17 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
         (void)st_j;
         atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
+        // (range-checked build: the segment's planes, block records and per-unit records lie inside the workspaces)
+        if (!DVDA_RANGE_OK(out_base, 8ull * seg_R, a.caps.res, BT_RES) ||
+            !DVDA_RANGE_OK(8ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap, cap, a.caps.brec, BT_BREC) ||
+            !DVDA_RANGE_OK((uint64_t)(pl.x / 40u) * FREC_WORDS, (uint64_t)(sr.nframes - sr.ndrop) * FREC_WORDS, a.caps.frec, BT_FREC)) {
+            status |= ST_CAPACITY;
+            active = false;
+        }
+    }
+    if (active && !DVDA_RANGE_OK(gl, 1, a.caps.lanes, BT_META)) {      // (the per-lane workspaces: fir / meta / mat / iir)
+        status |= ST_CAPACITY;
+        active = false;
     }
     // fast pass: rows this lane may still write (see the row loop)
     uint32_t room = 0;
@@ -870,17 +719,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     BitReader rd;
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
     rd.ring = &s_ring[wv][0][lane];
-    rd.crc_tab = s_crc;
     rd.max_chunk = (uint32_t)(((a.total_bytes + 63) >> 6) << 4);  // the chunk holding the spare bytes
     rd.hi = rd.lo = rd.nx = 0;
     rd.ofs = 0;
     rd.next = 3;
     rd.fillpos = 0;
     rd.lo_valid = 0;
-    rd.crc_pos = 0;
-    rd.crc_rem = 0;
-    rd.crc_st = 0;
-    rd.par = 0;
+    // parity / CRC-8 of the segment's substreams: checked byte-parallel by k_au_check (mlp_check.h) before this
+    // kernel runs; what is left here is one compare per access unit -- the first unit that fails | which check
+    uint32_t chk = active ? DVDA_AT(a.seg_check, (size_t)segi * 2u + sub, 2ull * a.caps.max_seg, BT_CHECK) : 0xFFFFFFFFu;
 
     // ---- per-lane decoder state (reference struct substream, src/mlp.c:103-115), in VGPRs
     int32_t st[NS][8];                // FIR history: st[k][0] = most recent output
@@ -899,8 +746,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #pragma unroll
         for (int j = 0; j < 4; j++)
             cf[k][j] = 0;
-        pk[k] = USLOT ? 0u : 24u << 2;            // codebook 0, 24 LSBs (USLOT: nothing carried yet -- a restart
-        sho[k] = USLOT ? 0 : -(1 << 23);          // header sets every slot it carries)
+        pk[k] = 24u << 2;                         // codebook 0, 24 LSBs
+        sho[k] = -(1 << 23);
     }
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -925,7 +772,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t it = 0;                      // two-wave layout: loop turn (wave-uniform); phase = it / OUT_ROWS
     const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
     uint32_t nslots = 0;
-    uint32_t slots_w = 2;             // wave-uniform: slots some lane of the wave carries (slots 0, 1 always run)
     bool have_restart = false;
     uint32_t iir_any = 0;             // bit k: slot k has IIR order > 0
     bool seg_iir = false;             // chain parse pass: some block of this segment ran IIR taps (seg_meta bit 9)
@@ -1039,8 +885,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         while (nxt < n_seg && a.seg[nxt].stream == sr.stream && (a.seg[nxt].flags & SEG_DEAD))
                             nxt++;
                         if (!(status & ~ST_INFO) && nxt < n_seg) {
-                            const SegRec nr = a.seg[nxt];
-                            const uint32_t nst = a.seg_status[nxt];
+                            const SegRec nr = DVDA_AT(a.seg, nxt, a.caps.max_seg, BT_SEG);
+                            const uint32_t nst = DVDA_AT(a.seg_status, nxt, a.caps.max_seg, BT_STATUS);
                             if (nr.stream == sr.stream && !(nr.flags & ST_FATAL_INDEX) && nr.nframes &&
                                 !(nst & ~ST_INFO)) {
                                 go_on = true;
@@ -1052,6 +898,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                 frames_done = 0;
                                 drops_seen = 0;
                                 rows_written = 0;
+                                chk = DVDA_AT(a.seg_check, (size_t)segi * 2u + sub, 2ull * a.caps.max_seg, BT_CHECK);
+                                if (!DVDA_RANGE_OK(seg_lane, 1, a.caps.lanes, BT_META))
+                                    go_on = false;
                             }
                         }
                         status = 0;
@@ -1062,7 +911,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 {
                     // ---- frame header "4p 12u 16p" (src/mlp.c:392-394)
-                    rd.crc_rem = 0;
                     rd.seek_byte(cur);
                     const uint32_t hdr = rd.read(32);
                     const uint32_t fsize = 2u * ((hdr >> 16) & 0xFFFu);
@@ -1112,12 +960,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         const uint64_t data_hi = check0 ? ss_hi - 2 : ss_hi;
                         ss_end_bit = data_hi * 8;
                         rd.seek_byte(ss_lo);
-                        // ---- parity + CRC-8 over [ss_lo, ss_hi - 2) (src/mlp.c:675-706) ride on
-                        //      the ring consumption from here on
-#if !defined(DVDA_EXP_NOCRC)
-                        if (check0)
-                            rd.crc_begin(ss_lo, (uint32_t)(data_hi - ss_lo));
-#endif
+                        // (parity + CRC-8 over [ss_lo, ss_hi - 2), src/mlp.c:675-706: k_au_check's verdict is
+                        //  looked at when the access unit ends)
                         in_frame = true;
                         frame_rows = 0;
                         blocks_in_frame = 0;
@@ -1127,9 +971,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
             // (looked at on the segment's first few block headers only: the request comes within the first loop
             //  turn of the lane behind this one, or -- that lane's wave starting late -- not in time at all)
-            if (DVDA_YIELD_CHECK && !GENERAL && !PARSE && active && frames_done < 2 && (frames_done | blocks_in_frame) != 0 &&
+            if (!GENERAL && !PARSE && active && frames_done < 2 && (frames_done | blocks_in_frame) != 0 &&
                 (__hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
-                 (DVDA_YIELD_LONELY && __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)DVDA_YIELD_LONELY))) {
+                 __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= YIELD_LONELY)) {
                 // the next segment chains to this one: both go to the chain passes -- or nearly every other lane
                 // of the wave has gone there, and this one would hold the pass for a whole segment's time
                 status |= ST_YIELD;
@@ -1208,19 +1052,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             if (NS < 6 && nslots > (uint32_t)NS)
                                 too_wide = true;
                             have_restart = true;
-                            if constexpr (USLOT) {
-                                // slots beyond the substream's channels: no bits, no taps, value 0
-#pragma unroll
-                                for (int kk = 0; kk < NS; kk++)
-                                    if ((uint32_t)kk >= nslots) {
-                                        pk[kk] = 0;
-                                        sho[kk] = 0;
-#pragma unroll
-                                        for (int j = 0; j < 4; j++)
-                                            cf[kk][j] = 0;
-                                    }
-                                iir_any &= (1u << nslots) - 1u;
-                            }
                         }
                         if (blocks_in_frame)
                             matrix_class_change = true;            // seed / matrix defaults change mid-frame
@@ -1609,37 +1440,27 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (!GENERAL && !PARSE && (status & ST_CHAINED)) {
                     active = false;            // left to the chain passes (needs the previous history)
-                    if (DVDA_YIELD_LONELY)
-                        atomicAdd(&s_nchained[wv], 1u);
+                    atomicAdd(&s_nchained[wv], 1u);
                     // ... which start one segment earlier if that segment's lane hears of it in time: it is
                     // decoding a whole segment on its own (one lane of many per title) only to hand over its
                     // last eight values, and the parse pass would then wait for it
                     // (device-scope accesses on both sides: a plain load may be hoisted out of the loop or served
                     //  from a stale L1 line)
-                    if (DVDA_YIELD_ASK && sr.prev != 0xFFFFFFFFu)
-                        __hip_atomic_store(&a.yield_req[sr.prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sr.prev != 0xFFFFFFFFu)
+                        __hip_atomic_store(&DVDA_AT(a.yield_req, sr.prev, a.caps.max_seg, BT_YIELD), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     rows_left = block_size;
                     blocks_in_frame++;
                     // (the lanes that stop above have counted themselves by now -- the branches of this chain run
                     //  one after the other, this one last; were it otherwise, the check at the next block header
                     //  does the same a block later: it is a matter of time only)
-                    if (!GENERAL && !PARSE && DVDA_YIELD_LONELY && frames_done < 2 &&
-                        __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >=
-                            (uint32_t)DVDA_YIELD_LONELY) {
+                    if (!GENERAL && !PARSE && frames_done < 2 &&
+                        __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= YIELD_LONELY) {
                         status |= ST_YIELD;
                         active = false;
                     }
                 }
             }
-        }
-        if ((USLOT || DVDA_SKIP_SCALAR) && __builtin_expect(__any(hdr_parsed), 0)) {
-            uint32_t sw = 2;
-#pragma unroll
-            for (int k = 2; k < NS; k++)
-                if (__any(active && nslots > (uint32_t)k))
-                    sw = k + 1;
-            slots_w = sw;
         }
         if (!WSPEC && !__any(active))
             break;                     // (two-wave layout: the block leaves together, at the exchange)
@@ -1653,21 +1474,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             if ((int32_t)(rd.fillpos - rd.next) < 12)
                 DVDA_COV(14);                // synchronous ring top-up inside the row loop
             rd.ensure(12);
-            DVDA_STAMP(0);
-            rd.crc_catchup(rd.next);
         }
-        DVDA_STAMP(7);      // parity/CRC catch-up
+        DVDA_STAMP(7);
         // both 64-byte halves of a 128-byte line are requested in consecutive rows, while the line
         // is still in L2 (one HBM fetch per line); a new line is started when half the ring is free
         const int32_t ahead_now = (int32_t)(rd.fillpos - rd.next);
-#if defined(DVDA_LINE_PREFETCH)
-        const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS) &&
-                        ((rd.fillpos & CHUNK_DWORDS) || ahead_now <= RING_DWORDS / 2);
-#else
         const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS);
-#endif
-        // (the chunk this overwrites has been hashed: crc_catchup() above ran up to `next`, and
-        //  ahead_now <= 16 puts `next` past it)
         // Four registers each, written by the loads below and read under the same `pf`.  They must hold a DEFINED
         // value on the lanes that do not load.  Zero-filling them with instructions made the compiler wait for
         // every outstanding memory operation -- the previous row's PCM stores included -- before it could
@@ -1677,12 +1489,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // these registers were defined.  The empty asm defines them -- some value, no instruction, nothing to
         // wait for -- which is all the code ever needed.
         uint4 p0, p1, p2, p3;
-#if defined(DVDA_EXP_INITPF)
-        p0 = p1 = p2 = p3 = make_uint4(0, 0, 0, 0);
-#elif !defined(DVDA_EXP_UNDEFPF)
         asm volatile("" : "=v"(p0.x), "=v"(p0.y), "=v"(p0.z), "=v"(p0.w), "=v"(p1.x), "=v"(p1.y), "=v"(p1.z), "=v"(p1.w),
                           "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
-#endif
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
         const uint32_t frames_before = frames_done;      // (sequential pass: did this turn close an access unit?)
         uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
@@ -1736,19 +1544,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             for (int k = 0; k < NS; k++) {
                 // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
-                const bool in = (USLOT && !WSPEC) ? true : (uint32_t)k < nslots;   // (two-wave layout: whose channel it is)
-                if (k >= 2 && ((USLOT || DVDA_SKIP_SCALAR) ? (uint32_t)k >= slots_w : !__any(in))) {
+                const bool in = (uint32_t)k < nslots;
+                if (k >= 2 && !__any(in)) {
                     if constexpr (!WSPEC)
                         val[k] = 0;
                     continue;
                 }
-                const uint32_t pkk = USLOT ? pk[k] : (in ? pk[k] : 0u);
+                const uint32_t pkk = in ? pk[k] : 0u;
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
                 const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
                 // the two dwords behind the window: one address, one two-address LDS read (mirror plane)
                 const uint32_t *look = rd.slot(rd.next);
-                const uint32_t cand1 = DVDA_RING_OUT(look[0]), cand2 = DVDA_RING_OUT(look[64]);
+                const uint32_t cand1 = __builtin_bswap32(look[0]), cand2 = __builtin_bswap32(look[64]);
                 const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
                 const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);      // bit 8 of the 9-bit peek
@@ -1775,7 +1583,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nh) : "v"(rd.hi), "v"(rd.lo), "s"(step));
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nl) : "v"(rd.lo), "v"(rd.nx), "s"(step));
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nn) : "v"(rd.nx), "v"(cand1), "s"(step));
-                if (DVDA_ADV2_FREE || __builtin_expect(__any(adv == 2), 0)) {
+                if (__builtin_expect(__any(adv == 2), 0)) {
                     const bool two = adv == 2;
                     if (two && in)
                         DVDA_COV(8);                 // two-dword window step
@@ -1804,9 +1612,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 acc1 += (int64_t)hi16(cf[k][2]) * (int64_t)st[k][5];
                 acc0 += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
                 acc1 += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
-#if DVDA_FIR_SPLIT
-                asm volatile("" : "+v"(acc0), "+v"(acc1));
-#endif
                 int64_t acc = acc0 + acc1;
                 bool iir_on = false;
                 if (__builtin_expect(wave_iir, 0)) {
@@ -1818,19 +1623,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 const int32_t ssum = (int32_t)(acc >> shift);
                 value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
-                if constexpr (USLOT) {
-                    // (a slot the lane does not carry runs on zeros: its history is 0 and stays 0)
+                // history moves only for channels this lane really carries
 #pragma unroll
-                    for (int j = 7; j > 0; j--)
-                        st[k][j] = st[k][j - 1];
-                    st[k][0] = value;
-                } else {
-                    // history moves only for channels this lane really carries
-#pragma unroll
-                    for (int j = 7; j > 0; j--)
-                        st[k][j] = in ? st[k][j - 1] : st[k][j];
-                    st[k][0] = in ? value : st[k][0];
-                }
+                for (int j = 7; j > 0; j--)
+                    st[k][j] = in ? st[k][j - 1] : st[k][j];
+                st[k][0] = in ? value : st[k][0];
                 if (__builtin_expect(wave_iir, 0)) {
                     if (iir_on)
                         iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
@@ -1841,7 +1638,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     if (in)
                         xw_mine[k * xstride] = value;     // straight into the tile
                 } else {
-                    val[k] = USLOT ? value : (in ? value : 0);
+                    val[k] = in ? value : 0;
                 }
             }
             if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {
@@ -1946,19 +1743,17 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         status |= ST_EOF;
                         active = false;
                     }
-                    // ---- the rest of the substream goes through the parity/CRC check
-                    if (active)
-                        rd.crc_finish();
-                    rd.crc_rem = 0;
-                    if (rd.crc_st >> 16) {
-                        status |= (rd.crc_st & (1u << 16)) ? ST_PARITY : ST_CRC;
+                    // ---- the substream's parity / CRC-8 (src/mlp.c:675-706): where the reference assert()s
+                    if (active && (chk >> 2) == frames_done) {
+                        status |= (chk & 1u) ? ST_PARITY : ST_CRC;
                         active = false;
                     }
-                    rd.crc_st = 0;
                     if (PARSE && is_last_sub && active) {
                         // ---- what this access unit is rematrixed with: the parameters its last block leaves
                         //      (src/mlp.c:504-525), for the rematrix pass
                         uint32_t *F = frec + (size_t)au_idx * FREC_WORDS;
+                        if (!DVDA_RANGE_OK((size_t)(F - a.frec), FREC_WORDS, a.caps.frec, BT_FREC))
+                            F = a.frec;
                         F[0] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
                         F[1] = outch_pack;
                         F[2] = qss_pack;
@@ -2042,8 +1837,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     const uint32_t ver = (tagw >> 8) & 0xFFFFu;
                     if (!(tagw >> 31)) {
                         active = false;                  // it stopped (its status says why): no more output
-                        if (DVDA_YIELD_LONELY)
-                            atomicAdd(&s_nchained[wv], 1u);      // (gone with it: one lane less that keeps the wave)
+                        atomicAdd(&s_nchained[wv], 1u);      // (gone with it: one lane less that keeps the wave)
                     } else if (__builtin_expect(ver != (par_seen & 0xFFFFu), 0)) {
                         const uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][ver & 1u][0][WS_BAL ? lane & (SPL - 1) : 0];
                         constexpr int PS = WS_BAL ? SPL : 1;
@@ -2234,6 +2028,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             //      lanes of a chain read it together, the rematrix pass reads it once
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
             int32_t *dst = a.res + out_base + (flush_row >> 2) * 32u;
+            if (!DVDA_RANGE_OK(out_base + (flush_row >> 2) * 32u, 32, a.caps.res, BT_RES))
+                dst = a.res;
 #pragma unroll
             for (int c = 0; c < TP; c++)
                 DVDA_STORE_V4_AT(dst, 16 * c, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane],
@@ -2418,26 +2214,17 @@ __global__ __launch_bounds__(64) void k_selftest_bits(const uint8_t *bytes, uint
                                                       uint32_t n, int64_t *out, uint32_t resident)
 {
     __shared__ uint32_t s_ring[RING_DWORDS + 1][64];
-    __shared__ uint8_t s_crc[4 * 256];
-    for (int i = threadIdx.x; i < 4 * 256; i += 64)
-        s_crc[i] = d_crc.t[i];
-    __syncthreads();
     if (threadIdx.x != 0)
         return;
     BitReader rd;
     rd.gsrc = reinterpret_cast<const uint4 *>(bytes);
     rd.ring = &s_ring[0][0];
-    rd.crc_tab = s_crc;
     rd.max_chunk = (uint32_t)((((uint64_t)n_bytes + 63) >> 6) << 4);
     rd.hi = rd.lo = rd.nx = 0;
     rd.ofs = 0;
     rd.next = 3;
     rd.fillpos = 0;
     rd.lo_valid = 0;
-    rd.crc_pos = 0;
-    rd.crc_rem = 0;
-    rd.crc_st = 0;
-    rd.par = 0;
     rd.seek_byte(0);
     for (uint32_t i = 0; i < n; i++) {
         const int32_t w = widths[i];

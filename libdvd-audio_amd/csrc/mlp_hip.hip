@@ -3,6 +3,7 @@
 //
 //   index : k_sync_mask -> k_exscan_u32 -> k_sync_scatter -> k_chase ->
 //           k_exscan_u32 -> k_link                 (framing, src/mlp.c:384-405)
+//           -> k_au_check                          (parity / CRC-8 of every substream, src/mlp.c:670-712)
 //   decode: k_decode (fast pass) -> k_finalize -> [summary to the host] ->
 //           chain passes (mlp_chain.h) and / or the sequential pass, only when the fast pass
 //           left something to them                 (src/mlp.c:407-1358)
@@ -21,19 +22,13 @@
 #include "../../include/dvda_mlp_hip.h"
 #include "mlp_decode.h"
 #include "mlp_chain.h"
+#include "mlp_check.h"
+#include "mlp_coop.h"
 #include "mlp_index.h"
 #include "pcm_unswizzle.h"
 #include "wav_pack.h"
 
 using namespace mlp;
-
-// diagnostic builds: extra dynamic LDS per fast-pass workgroup (occupancy probe, no code change)
-#if defined(DVDA_EXP_DYN_LDS)
-#include <stdlib.h>
-#define DVDA_DYN_LDS_EXPR (getenv("DVDA_DYN_LDS") ? (unsigned)atoi(getenv("DVDA_DYN_LDS")) : 0u)
-#else
-#define DVDA_DYN_LDS_EXPR 0
-#endif
 
 #define HIP_TRY(x)                                                                         \
     do {                                                                                   \
@@ -64,6 +59,7 @@ struct dvda_mlp_hip_ctx {
     uint32_t max_streams, max_segments;
     // index workspace
     uint8_t *d_masks;
+    uint16_t *d_parts;         // [masks_cap]: per 16-byte chunk, CRC-8 from state 0 | XOR of its bytes << 8 (mlp_check.h)
     uint64_t masks_cap;        // chunks
     uint32_t *d_tile_count;    // [tiles + 1]
     uint32_t *d_tile_base;     // [tiles + 1]; last = number of candidates
@@ -84,6 +80,7 @@ struct dvda_mlp_hip_ctx {
     int32_t *d_fir;
     uint32_t *d_seg_meta;      // [iir_lanes]: channel range per (segment, substream) at the segment's end
     uint32_t *d_yield;         // [max_segments]: yield requests of the fast pass (mlp_decode.h, ST_YIELD)
+    uint32_t *d_seg_check;     // [2 * max_segments]: parity / CRC-8 verdict per (segment, substream) (mlp_check.h)
     uint32_t *d_cls;           // [2]: streams with one / two substreams in the batch; [2] = the batch mixes shapes
     uint32_t *d_shape_key;     // [max_streams]
     uint64_t *d_soff, *d_slen; // [max_streams]: the caller's stream ranges as the index uses them (k_check_ranges)
@@ -133,9 +130,40 @@ struct dvda_mlp_hip_ctx {
     uint64_t ev_count;         // decode calls recorded since the last dvda_mlp_hip_kernel_time
 };
 
+// what the workspaces hold right now (mlp_bounds.h)
+static WsCaps ws_caps(const dvda_mlp_hip_ctx *c)
+{
+    WsCaps w;
+    w.res = c->res_cap;
+    w.brec = c->brec_cap;
+    w.frec = c->frec_cap;
+    w.fb = (uint64_t)c->fb_slots * FB_WORDS;
+    w.max_seg = c->max_segments;
+    w.max_streams = c->max_streams;
+    w.lanes = c->iir_lanes;
+    w.pad = 0;
+    return w;
+}
+
+// range-checked build: violations counted by the kernels so far (0 in the shipped library, which does not check)
+extern "C" int dvda_mlp_hip_bounds_violations(unsigned long long *out4)
+{
+    if (!out4)
+        return DVDA_HIP_EINVAL;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+#if defined(DVDA_BOUNDS)
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out4, HIP_SYMBOL(mlp::g_bounds), 4 * sizeof(unsigned long long)));
+    return 1;       // (a checked build)
+#else
+    return DVDA_HIP_OK;
+#endif
+}
+
 static void free_ws(dvda_mlp_hip_ctx *c)
 {
     (void)hipFree(c->d_masks);
+    (void)hipFree(c->d_parts);
     (void)hipFree(c->d_tile_count);
     (void)hipFree(c->d_tile_base);
     (void)hipFree(c->d_cand_off);
@@ -152,6 +180,7 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_fir);
     (void)hipFree(c->d_seg_meta);
     (void)hipFree(c->d_yield);
+    (void)hipFree(c->d_seg_check);
     (void)hipFree(c->d_cls);
     (void)hipFree(c->d_shape_key);
     (void)hipFree(c->d_soff);
@@ -230,6 +259,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_fir, (size_t)c->iir_lanes * 6 * 8 * sizeof(int32_t));
     alloc((void **)&c->d_seg_meta, (size_t)c->iir_lanes * sizeof(uint32_t));
     alloc((void **)&c->d_yield, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_check, 2 * ns * sizeof(uint32_t));
     alloc((void **)&c->d_cls, 4 * sizeof(uint32_t));
     alloc((void **)&c->d_shape_key, (size_t)max_streams * sizeof(uint32_t));
     alloc((void **)&c->d_soff, (size_t)max_streams * sizeof(uint64_t));
@@ -271,6 +301,16 @@ extern "C" void dvda_mlp_hip_destroy(dvda_mlp_hip_ctx *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
+#if defined(DVDA_BOUNDS)
+    if (getenv("DVDA_BOUNDS_REPORT")) {
+        unsigned long long v[4] = {0, 0, 0, 0};
+        (void)dvda_mlp_hip_bounds_violations(v);
+        fprintf(stderr, "dvda_mlp_hip: bounds violations: %llu", v[0]);
+        if (v[0])
+            fprintf(stderr, " (first: tag %llu index %llu capacity %llu)", v[1], v[2], v[3]);
+        fprintf(stderr, "\n");
+    }
+#endif
     free_ws(c);
     delete c;
 }
@@ -283,9 +323,12 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
     const uint64_t tiles = (chunks + IDX_TILE_CHUNKS - 1) / IDX_TILE_CHUNKS;
     if (chunks > c->masks_cap) {
         (void)hipFree(c->d_masks);
+        (void)hipFree(c->d_parts);
         c->d_masks = nullptr;
+        c->d_parts = nullptr;
         c->masks_cap = 0;
-        if (ws_malloc((void **)&c->d_masks, chunks) != hipSuccess)
+        if (ws_malloc((void **)&c->d_masks, chunks) != hipSuccess ||
+            ws_malloc((void **)&c->d_parts, (chunks + 8) * sizeof(uint16_t)) != hipSuccess)
             return DVDA_HIP_ENOMEM;
         c->masks_cap = chunks;
     }
@@ -437,7 +480,7 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
         d_stream_len = c->d_slen;
     }
     hipLaunchKernelGGL(k_sync_mask, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, d_bytes,
-                       total_bytes, c->d_masks, c->d_tile_count);
+                       total_bytes, c->d_masks, c->d_tile_count, c->d_parts);
     exscan(c, st, c->d_tile_count, c->d_tile_base, (uint32_t)tiles, nullptr, (uint32_t)tiles);
     hipLaunchKernelGGL(k_sync_scatter, dim3((unsigned)tiles), dim3(IDX_THREADS), 0, st, c->d_masks,
                        total_bytes, c->d_tile_base, c->d_cand_off, ms);
@@ -456,6 +499,9 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
     (void)hipMemsetAsync(c->d_lane_seg, 0xFF, (size_t)ms * sizeof(uint32_t), st);     // lanes that are dealt nothing
     hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, st, c->d_seg, c->d_streams, c->d_n_cand, ms,
                        c->d_rank, c->d_sorted_base, c->d_cls + 2, c->d_lane_seg);
+    // parity / CRC-8 of every substream, byte-parallel (16 lanes per segment): the decode lanes only compare
+    hipLaunchKernelGGL(k_au_check, dim3((unsigned)(((uint64_t)ms * CHK_GROUP + CHK_THREADS - 1) / CHK_THREADS)),
+                       dim3(CHK_THREADS), 0, st, d_bytes, c->d_parts, c->d_seg, c->d_n_cand, ms, c->d_streams, c->d_seg_check);
 }
 
 extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, uint64_t total_bytes,
@@ -597,6 +643,8 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     a.lane_seg = c->d_lane_seg;
     a.seg_meta = c->d_seg_meta;
     a.yield_req = c->d_yield;
+    a.seg_check = c->d_seg_check;
+    a.caps = ws_caps(c);
     HIP_TRY(hipMemsetAsync(c->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary), st));
     if (c->decoded)
         hipLaunchKernelGGL(k_reset_segments, dim3((unsigned)((c->max_segments + 255) / 256)), dim3(256), 0, st,
@@ -605,8 +653,12 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     // which kernels: one lane per segment for the streams with one substream, the two-wave layout for those
     // with two -- both unless the caller forced one; a kernel whose class is absent from the batch (the
     // index knows) exits at once
-    const uint32_t force = c->lanes_per_seg;
-    const bool run1 = force != 2, run2 = force != 1;
+    // (64: always the wave-cooperative kernel; 0: the device picks it for small batches -- coop_takes() -- and the
+    //  lane kernels for everything else; 1 / 2 force a lane kernel)
+    const bool coop_only = c->lanes_per_seg == 64;
+    const uint32_t force = coop_only ? 0u : c->lanes_per_seg;
+    const bool run1 = force != 2 && !coop_only, run2 = force != 1 && !coop_only;
+    a.coop = coop_only ? 64u : force;
     const uint64_t ms = c->max_segments;
     const unsigned blocks1 = (unsigned)((ms + DEC_THREADS - 1) / DEC_THREADS);            // one lane per segment
     const unsigned blocks2 = (unsigned)((2 * ms + DEC_THREADS - 1) / DEC_THREADS);        // lane pairs
@@ -615,12 +667,16 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     const uint32_t slot = (uint32_t)(c->ev_count % EV_RING);
     HIP_TRY(hipEventRecord(c->ev[2 * slot], st));
     // ---- fast pass (timed: the dominant kernel)
+    if (coop_only || force == 0) {
+        const unsigned cblocks = (unsigned)(coop_only || ms < COOP_MAX_SEG ? ms : COOP_MAX_SEG);
+        hipLaunchKernelGGL(k_coop, dim3(cblocks), dim3(COOP_THREADS), 0, st, a);
+    }
     if (run1) {
         a.only_S = force ? 0u : 1u;
         if (a.interleaved)
-            hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
+            hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
         else
-            hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), DVDA_DYN_LDS_EXPR, st, a);
+            hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
     }
     if (run2) {
         a.only_S = force ? 0u : 2u;
@@ -651,8 +707,10 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
             (rc = grow(&c->d_brec, &c->brec_cap, 8 * rows + 128ull * segs + 64)) != 0 ||
             (rc = grow(&c->d_frec, &c->frec_cap, (rows / 40 + segs + 1) * FREC_WORDS)) != 0)
             return rc;
+        a.caps = ws_caps(c);
         ChainArgs ca;
         memset(&ca, 0, sizeof(ca));
+        ca.caps = a.caps;
         ca.seg = c->d_seg;
         ca.seg_fbase = c->d_seg_fbase;
         ca.n_seg_ptr = c->d_n_cand;
@@ -691,12 +749,12 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         a.res = c->d_res;
         a.brec = c->d_brec;
         a.frec = c->d_frec;
-        if (run1) {
+        if (force != 2) {
             a.only_S = force ? 0u : 1u;
             hipLaunchKernelGGL((k_decode<6, false, false, false, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
                                dim3(DEC_THREADS), 0, st, a);
         }
-        if (run2) {
+        if (force != 1) {
             a.only_S = force ? 0u : 2u;
             hipLaunchKernelGGL((k_decode<6, true, false, false, true>), dim3((2 * segs + DEC_THREADS - 1) / DEC_THREADS),
                                dim3(DEC_THREADS), 0, st, a);
@@ -730,6 +788,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
             c->fb_slots = round;
         }
         a.fb = c->d_fb;
+        a.caps = ws_caps(c);
         a.list = c->d_seq_list;
         a.only_S = 0;
         for (uint32_t base = 0; base < n_seq; base += round) {
@@ -759,7 +818,7 @@ extern "C" int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *c, uint32_t layout)
 
 extern "C" int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *c, uint32_t lanes)
 {
-    if (!c || lanes > 2)
+    if (!c || (lanes > 2 && lanes != 64))
         return DVDA_HIP_EINVAL;
     c->lanes_per_seg = lanes;
     return DVDA_HIP_OK;

@@ -88,14 +88,24 @@ __device__ __forceinline__ uint32_t packed_sync_at(const uint8_t *b, uint64_t p)
            ((ld_u8(b, p + 9) & 0xFu) << 12) | ((ld_u8(b, p + 11) & 0x1Fu) << 16) | ((ld_u8(b, p + 20) >> 4) << 24);
 }
 
+__device__ const CheckTables d_chk = make_check();
+
 // Pass 1: one mask byte per 16-byte chunk (bit j = candidate at chunk*16 + 2j),
 // plus the number of candidates per 64 KiB tile.
+// While the chunk is in registers anyway: its part of the substream check (mlp_check.h) -- the CRC-8 of the
+// chunk's 16 bytes from state 0 (sixteen table look-ups; the LDS pipe is idle in this kernel, which is bound by
+// HBM) and the XOR of its bytes, two bytes per chunk into parts[].  k_au_check puts them together per substream.
 __global__ __launch_bounds__(IDX_THREADS) void k_sync_mask(const uint8_t *__restrict__ bytes,
                                                            uint64_t total_bytes,
                                                            uint8_t *__restrict__ masks,
-                                                           uint32_t *__restrict__ tile_count)
+                                                           uint32_t *__restrict__ tile_count,
+                                                           uint16_t *__restrict__ parts)
 {
     __shared__ uint32_t s_cnt[IDX_THREADS / 64];
+    __shared__ uint8_t s_slice[16 * 256];
+    for (int i = threadIdx.x; i < 16 * 256 / 16; i += IDX_THREADS)
+        reinterpret_cast<uint4 *>(s_slice)[i] = reinterpret_cast<const uint4 *>(d_chk.slice)[i];
+    __syncthreads();
     const uint64_t n_chunks = (total_bytes + 15) >> 4;
     const uint64_t tile0 = (uint64_t)blockIdx.x * IDX_TILE_CHUNKS;
     uint32_t cnt = 0;
@@ -121,6 +131,18 @@ __global__ __launch_bounds__(IDX_THREADS) void k_sync_mask(const uint8_t *__rest
         }
         masks[chunk] = (uint8_t)m;
         cnt += __popc(m);
+        {
+            // byte i of the chunk carries x^(8 (16 - i)): table 15 - i
+            uint32_t c0 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                c0 ^= s_slice[(15 - 4 * k) * 256 + (w[k] & 0xFFu)] ^ s_slice[(14 - 4 * k) * 256 + ((w[k] >> 8) & 0xFFu)] ^
+                      s_slice[(13 - 4 * k) * 256 + ((w[k] >> 16) & 0xFFu)] ^ s_slice[(12 - 4 * k) * 256 + (w[k] >> 24)];
+            uint32_t px = w[0] ^ w[1] ^ w[2] ^ w[3];
+            px ^= px >> 16;
+            px = (px ^ (px >> 8)) & 0xFFu;
+            parts[chunk] = (uint16_t)(c0 | (px << 8));
+        }
     }
     // block reduce
     for (int o = 32; o > 0; o >>= 1)

@@ -69,6 +69,36 @@ constexpr CrcTable make_crc()
     return c;
 }
 
+// ---- CRC-8 as field arithmetic (mlp_check.h): 0x163 is primitive, so GF(2)[x] / 0x163 = GF(256) and x generates
+//      its multiplicative group
+struct CheckTables {
+    uint8_t slice[16 * 256];        // slice[k * 256 + b] = b * x^(8 (k + 1))
+    uint8_t log[256];               // log_x(v), v != 0
+    uint8_t exp[512];               // x^i, i < 510 (period 255: no reduction of log + exponent needed)
+};
+
+constexpr CheckTables make_check()
+{
+    CheckTables t{};
+    for (unsigned i = 0; i < 256; i++) {
+        unsigned v = i;
+        for (int k = 0; k < 8; k++)
+            v = (v & 0x80) ? (((v << 1) ^ 0x63) & 0xFF) : ((v << 1) & 0xFF);
+        t.slice[i] = (uint8_t)v;                                    // the reference's table, src/mlp.c:1363-1395
+    }
+    for (int k = 1; k < 16; k++)
+        for (unsigned i = 0; i < 256; i++)
+            t.slice[k * 256 + i] = t.slice[t.slice[(k - 1) * 256 + i]];
+    unsigned v = 1;
+    for (unsigned i = 0; i < 512; i++) {
+        t.exp[i] = (uint8_t)v;
+        if (i < 255)
+            t.log[v] = (uint8_t)i;
+        v = (v & 0x80) ? (((v << 1) ^ 0x63) & 0xFF) : ((v << 1) & 0xFF);
+    }
+    return t;
+}
+
 // ------------------------------------------------------------ channel tables
 // wave_pack(assignment): nibble c = RIFF-WAVE index of MLP channel c, 0xF = none
 constexpr uint32_t wave_pack(unsigned a)

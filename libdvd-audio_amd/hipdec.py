@@ -40,6 +40,7 @@ _lib = None
 EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
            "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
            "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_selftest_bits",
+           "dvda_mlp_hip_bounds_violations",
            "dvda_mlp_hip_set_lanes_per_segment",
            "dvda_mlp_hip_set_pcm_layout", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",

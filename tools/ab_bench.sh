@@ -10,7 +10,7 @@ for v in "$@"; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); print('$v', 'rep$rep', 'value', j['value'], 'kernel_ms', j['roofline']['kernel_ms'])
+        j = json.loads(l); print('$v', 'rep$rep', 'value', j['value'], 'ms_per_step', j['ms_per_step'], 'kernel_ms', j['roofline']['kernel_ms'])
 "
   done
 done
