@@ -36,6 +36,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "mlp_decode.h"
 #include "mlp_chain.h"
 
@@ -47,6 +48,14 @@ constexpr int COOP_VSTRIDE = COOP_ROWS + 1;     // s_val[channel][frame]: odd st
 constexpr int COOP_STAGE_DW = 2048 + 8;         // an access unit is at most 8 190 bytes (12-bit size field)
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// v[LANE] = s (one v_writelane_b32 with the lane as an inline constant; this compiler has no builtin for it)
+template <int LANE>
+__device__ __forceinline__ void coop_writelane(uint32_t &v, uint32_t s)
+{
+    static_assert(LANE >= 0 && LANE < 64, "lane");
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+}
 
 // wave-uniform MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206) over the access unit
 // staged in LDS as big-endian dwords; bit 0 = the top bit of staged dword 0
@@ -104,7 +113,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     const uint32_t segi = blockIdx.x;
     if (segi >= n_seg)
         return;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = rfl(threadIdx.x >> 6);          // (wave-uniform, and the compiler has to know it: everything the
+                                                        //  parse derives from `sub` stays in scalar registers)
     const SegRec sr = a.seg[segi];
     if ((sr.flags & (ST_FATAL_INDEX | SEG_DEAD)) || sr.nframes == 0)
         return;
@@ -510,69 +521,97 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     // ---- what the lanes need of the block's parameters
                     my_pk = P.pk[slot];
                     my_sho = P.sho[slot];
-                    uint32_t scb[6], slb[6];        // the scan's own copy: code book and LSB count per slot
+                    // the scan's own copy of what it needs per slot: length of the "1 + bits" codes, whether there is
+                    // a code book at all (as a mask), LSB count
+                    uint32_t s_lena[6], s_cbm[6], s_lb[6];
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
                         const uint32_t pkk = (uint32_t)k < nslots ? rfl(P.pk[k]) : 0u;
-                        scb[k] = pkk & 3u;
-                        slb[k] = (pkk >> 2) & 31u;
+                        const uint32_t cb = pkk & 3u;
+                        s_lena[k] = cb ? 4u - cb : 0u;
+                        s_cbm[k] = cb ? 0xFFFFFFFFu : 0u;
+                        s_lb[k] = (pkk >> 2) & 31u;
                     }
                     const uint32_t nbyp = (uint32_t)__popc(bypass_mask);
                     // ================================================ rows of the block, eight at a time
                     // ---- SCAN: where does each symbol start?  (src/mlp.c:1194-1238, lengths only)
+                    // The window: `win` holds the stream from the next unread bit on, `navail` valid bits of it (may
+                    // go below zero by a bit: a 33-bit symbol out of 32 -- the next dword's shift takes that into
+                    // account); one dword more whenever 32 or less are left, so a code's 9 bits are always there (the
+                    // LSBs behind it are not looked at here).  The dword after that is already on its way from LDS:
+                    // asked for at the last refill, taken (readfirstlane) at this one -- no wait on the chain.
+                    // (`navail` is not kept: the window ends at bit 32 * widx, so 32 or less are left once
+                    //  pos >= thr = 32 * widx - 32 -- one compare on the position the chain carries anyway)
                     uint32_t pos = rd.pos;
-                    uint32_t widx = pos >> 5;
+                    uint32_t widx = (pos >> 5) + 2u;
                     uint64_t win;
-                    uint32_t navail;
                     {
-                        const uint32_t d0 = rfl(s_stage[widx]), d1 = rfl(s_stage[widx + 1]);
+                        const uint32_t d0 = rfl(s_stage[widx - 2u]), d1 = rfl(s_stage[widx - 1u]);
                         win = (((uint64_t)d0 << 32) | d1) << (pos & 31u);
-                        navail = 64u - (pos & 31u);
-                        widx += 2;
                     }
-                    uint32_t next_dw = rfl(s_stage[widx]);
-                    uint32_t bad_code = 0;
-                    // (the window holds at least 33 bits before every symbol -- 9 of code, 24 of LSBs -- and before a
-                    //  row's bypassed LSBs: one dword more whenever it is down to 32 or less, twice if it was empty)
+                    uint32_t thr = 32u * widx - 32u;
+                    const uint32_t *pnext = s_stage + widx;
+                    uint32_t pend = *pnext;                 // (a vector register: the load is not waited for here)
                     auto refill = [&]() {
-                        if (navail <= 32u) {
-                            win |= (uint64_t)next_dw << (32u - navail);
-                            navail += 32u;
-                            widx++;
-                            next_dw = rfl(s_stage[widx < (uint32_t)COOP_STAGE_DW ? widx : 0]);
+                        if (pos >= thr) {
+                            win |= (uint64_t)rfl(pend) << (pos - thr);      // 32 - (bits left) = pos - thr
+                            thr += 32u;
+                            pnext++;
+                            pend = *pnext;
                         }
                     };
+                    uint32_t bad_code = 0;
                     for (uint32_t r0 = 0; r0 < block_size; r0 += 8) {
                         const uint32_t nr = block_size - r0 < 8u ? block_size - r0 : 8u;
                         uint32_t v_sym = 0;             // lane (frame * 8 + slot): bit position of that symbol; slot 7: the row's start
-                        for (uint32_t r = 0; r < nr; r++) {
-                            v_sym = lane == r * 8u + 7u ? pos : v_sym;
+                        auto scan_row = [&](auto R) {
+                            constexpr int r = decltype(R)::value;
+                            coop_writelane<r * 8 + 7>(v_sym, pos);
                             // the row's bypassed LSBs (at most one per matrix) sit in front of its symbols
-                            refill();
                             refill();
                             pos += nbyp;
                             win <<= nbyp;
-                            navail -= nbyp;
-#pragma unroll
-                            for (int k = 0; k < 6; k++) {
-                                if ((uint32_t)k < nslots) {
-                                    refill();
-                                    refill();
-                                    const uint32_t t9 = (uint32_t)(win >> 55);
-                                    // the three books share one structure (mlp_tables.h): "1" + (3 - book) bits, or
-                                    // z' zeros and a one in the low 7 bits (length z' + 3)
-                                    const uint32_t z = (uint32_t)__builtin_clz((int)((t9 << 25) | 0x01000000u));
-                                    uint32_t len = (t9 & 0x100u) ? 4u - scb[k] : (z > 6u ? 6u : z) + 3u;
-                                    bad_code |= (!(t9 & 0x100u) && z > 6u && scb[k]) ? 1u : 0u;
-                                    len = scb[k] ? len : 0u;
-                                    v_sym = lane == r * 8u + (uint32_t)k ? pos : v_sym;
-                                    const uint32_t tot = len + slb[k];
-                                    pos += tot;
-                                    win <<= tot;
-                                    navail -= tot;
+                            auto sym = [&](auto K) {
+                                constexpr int k = decltype(K)::value;
+                                refill();
+                                // the three books share one structure (mlp_tables.h): "1" + (3 - book) bits, or z' zeros
+                                // and a one in the seven bits behind the first two (length z' + 3, capped: an invalid
+                                // code is found by the lane that decodes the symbol)
+                                const uint32_t top = (uint32_t)(win >> 32);
+                                const uint32_t z = (uint32_t)__builtin_clz((int)(((top << 2) & 0xFE000000u) | 0x01000000u));
+                                const uint32_t len_l = ((z > 6u ? 6u : z) + 3u) & s_cbm[k];
+                                uint32_t esc = top >> 31;
+                                asm volatile("" : "+s"(esc));          // (a scalar compare and select, not a 64-bit vector compare)
+                                const uint32_t len = esc ? s_lena[k] : len_l;
+                                coop_writelane<r * 8 + k>(v_sym, pos);
+                                const uint32_t tot = len + s_lb[k];
+                                pos += tot;
+                                win <<= tot;
+                            };
+                            sym(std::integral_constant<int, 0>{});
+                            if (nslots > 1u) {
+                                sym(std::integral_constant<int, 1>{});
+                                if (nslots > 2u) {
+                                    sym(std::integral_constant<int, 2>{});
+                                    if (nslots > 3u) {
+                                        sym(std::integral_constant<int, 3>{});
+                                        if (nslots > 4u) {
+                                            sym(std::integral_constant<int, 4>{});
+                                            if (nslots > 5u)
+                                                sym(std::integral_constant<int, 5>{});
+                                        }
+                                    }
                                 }
                             }
-                        }
+                        };
+                        scan_row(std::integral_constant<int, 0>{});
+                        if (nr > 1u) scan_row(std::integral_constant<int, 1>{});
+                        if (nr > 2u) scan_row(std::integral_constant<int, 2>{});
+                        if (nr > 3u) scan_row(std::integral_constant<int, 3>{});
+                        if (nr > 4u) scan_row(std::integral_constant<int, 4>{});
+                        if (nr > 5u) scan_row(std::integral_constant<int, 5>{});
+                        if (nr > 6u) scan_row(std::integral_constant<int, 6>{});
+                        if (nr > 7u) scan_row(std::integral_constant<int, 7>{});
                         // ---- RESIDUALS: one lane per symbol (src/mlp.c:1226-1238)
                         {
                             const uint32_t o = v_sym;
@@ -586,6 +625,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                             const uint32_t row = frame_rows + r0 + rslot;
                             if (rslot < nr && slot < nslots)
                                 s_val[min_ch + slot][row] = residual;
+                            // (an invalid code decodes to 0xFF: found here, by the lane that has the symbol)
+                            if (__any(rslot < nr && slot < nslots && msb == 0xFFu))
+                                bad_code = 1;
                             if (rslot < nr && slot == 7u && is_last) {
                                 // the row's bypassed LSBs, dealt to their matrices in stream order
                                 const uint32_t field = nbyp ? (uint32_t)(ww >> (64u - nbyp)) : 0u;
@@ -627,12 +669,21 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         const bool any_iir = __any(lane < nslots && f_iir);
                         if (lane < nslots) {
                             int32_t *col = &s_val[min_ch + lane][frame_rows];
+                            // (the next row's residual is asked for before this row's recursion step: the LDS round
+                            //  trip is not on the chain)
+                            int32_t x = col[0];
                             if (any_iir) {
-                                for (uint32_t r = 0; r < block_size; r++)
-                                    col[r] = iir_step_one(h, fc, ih, ic, f_shift, f_qmask, col[r]);
+                                for (uint32_t r = 0; r < block_size; r++) {
+                                    const int32_t nx = col[r + 1u < block_size ? r + 1u : r];
+                                    col[r] = iir_step_one(h, fc, ih, ic, f_shift, f_qmask, x);
+                                    x = nx;
+                                }
                             } else {
-                                for (uint32_t r = 0; r < block_size; r++)
-                                    col[r] = fir_step_one(h, fc, f_shift, f_qmask, col[r]);
+                                for (uint32_t r = 0; r < block_size; r++) {
+                                    const int32_t nx = col[r + 1u < block_size ? r + 1u : r];
+                                    col[r] = fir_step_one(h, fc, f_shift, f_qmask, x);
+                                    x = nx;
+                                }
                             }
                         }
                     }

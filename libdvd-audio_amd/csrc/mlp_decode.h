@@ -225,6 +225,7 @@ struct DecodeArgs {
     // chain parse pass: lane (pair) j parses deferred segment list[list_base + j]
     const uint32_t *list;
     uint32_t list_base, list_n;
+    const uint32_t *list_n_ptr;    // != nullptr: the list's length lives on the device (non-blocking decode); list_n caps it
     // chain parse pass: where segment `seg` puts its planes / records (ChainPlan, mlp_chain.h)
     const uint4 *plan;             // per segment: .x deferred rows before it, .y deferred segments before it,
                                    //              .z chains before it
@@ -236,8 +237,12 @@ struct DecodeArgs {
                                    // kernel (mlp_coop.h), anything else always the lane kernels
 };
 
-constexpr uint32_t COOP_MAX_SEG = 8192;         // batches with more segments than this go to the lane kernels ...
-constexpr uint32_t COOP_MAX_AU = 98304;         // ... and so do batches with more access units (one wave scans ~25 us per unit)
+// Which batches the wave-cooperative kernel takes (measured, tools/coop_bench.py, MI355X): one wave scans an access
+// unit in ~45 us alone on its SIMD and ~35 us of SIMD time when four share one, a lane of k_decode needs ~200 us per
+// unit but 64 of them run per wave -- the two meet at ~4 000 segments of 8 units (1.3 ms either way); below that the
+// cooperative kernel wins (1 024 single units: 0.09 vs 0.19 ms; one title of 64 segments: 0.45 vs 1.2 ms).
+constexpr uint32_t COOP_MAX_SEG = 4096;         // batches with more segments than this go to the lane kernels ...
+constexpr uint32_t COOP_MAX_AU = 32768;         // ... and so do batches with more access units
 // does the cooperative kernel decode this batch (else the lane kernels do)?  DecodeArgs.coop: 0 auto, 64 always, else never
 __device__ __forceinline__ bool coop_takes(const DecodeArgs &a)
 {
@@ -560,7 +565,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         segi = n_seg;
     }
     if (GENERAL || PARSE) {
-        active = item < a.list_n && (!PARSE || item < DVDA_AT(a.plan, n_seg, a.caps.max_seg + 1u, BT_PLAN).y);
+        active = item < a.list_n && (a.list_n_ptr == nullptr || item < *a.list_n_ptr) && (!PARSE || item < DVDA_AT(a.plan, n_seg, a.caps.max_seg + 1u, BT_PLAN).y);
         segi = 0;
         if (active) {
             const uint32_t e = DVDA_AT(a.list, a.list_base + item, GENERAL ? a.caps.max_streams : a.caps.max_seg, BT_LIST);

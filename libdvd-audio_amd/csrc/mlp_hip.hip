@@ -98,6 +98,7 @@ struct dvda_mlp_hip_ctx {
     // grown on first use (a batch that needs them):
     int32_t *d_fb;             // sequential pass: one frame buffer per lane pair of a round
     uint32_t fb_slots;
+    uint32_t rsv_segs;         // dvda_mlp_hip_reserve: deferred segments a non-blocking decode launches its chain passes for
     int32_t *d_res;            // chain passes: planes
     uint64_t res_cap;          // PCM frames
     uint32_t *d_brec;
@@ -606,8 +607,67 @@ static int read_summary(dvda_mlp_hip_ctx *c, hipStream_t st)
     return DVDA_HIP_OK;
 }
 
+// The chain passes' workspaces hold less than the plan asks for (a non-blocking decode runs on what
+// dvda_mlp_hip_reserve left): nothing is deferred to them then -- the plan's totals are zeroed, every chain kernel
+// behind this one finds no work, and the segments that waited are reported DVDA_ST_CAPACITY by the last k_finalize.
+__global__ void k_chain_guard(uint4 *plan, const uint32_t *n_seg_ptr, uint32_t max_seg, WsCaps caps, uint32_t seg_cap)
+{
+    uint32_t n = *n_seg_ptr;
+    if (n > max_seg)
+        n = max_seg;
+    const uint4 t = plan[n];
+    const unsigned long long rows = t.x, segs = t.y;
+    if (segs > seg_cap || rows * 8 + 64 > caps.res || 8 * rows + 128ull * segs + 64 > caps.brec ||
+        (rows / 40 + segs + 1) * FREC_WORDS > caps.frec)
+        plan[n] = make_uint4(t.x, 0, 0, 0);
+}
+
+extern "C" int dvda_mlp_hip_reserve(dvda_mlp_hip_ctx *c, uint64_t chain_pcm_frames, uint32_t chain_segments,
+                                    uint32_t seq_streams)
+{
+    if (!c)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (chain_pcm_frames >> 32)
+        return DVDA_HIP_ECAPACITY;
+    int rc;
+    if (chain_segments || chain_pcm_frames) {
+        if ((rc = grow(&c->d_res, &c->res_cap, chain_pcm_frames * 8 + 64)) != 0 ||
+            (rc = grow(&c->d_brec, &c->brec_cap, 8 * chain_pcm_frames + 128ull * chain_segments + 64)) != 0 ||
+            (rc = grow(&c->d_frec, &c->frec_cap, (chain_pcm_frames / 40 + chain_segments + 1) * FREC_WORDS)) != 0)
+            return rc;
+        if (chain_segments > c->rsv_segs)
+            c->rsv_segs = chain_segments;
+    }
+    const uint32_t round = seq_streams < SEQ_ROUND ? seq_streams : SEQ_ROUND;
+    if (round > c->fb_slots) {
+        (void)hipFree(c->d_fb);
+        c->d_fb = nullptr;
+        c->fb_slots = 0;
+        if (ws_malloc((void **)&c->d_fb, (size_t)round * FB_WORDS * sizeof(int32_t)) != hipSuccess)
+            return DVDA_HIP_ENOMEM;
+        c->fb_slots = round;
+    }
+    return DVDA_HIP_OK;
+}
+
+static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off, const uint64_t *d_out_stride,
+                       void *stream_, bool blocking);
+
 extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off,
                                    const uint64_t *d_out_stride, void *stream_)
+{
+    return decode_impl(c, d_pcm, d_out_off, d_out_stride, stream_, true);
+}
+
+extern "C" int dvda_mlp_hip_decode_async(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off,
+                                         const uint64_t *d_out_stride, void *stream_)
+{
+    return decode_impl(c, d_pcm, d_out_off, d_out_stride, stream_, false);
+}
+
+static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off, const uint64_t *d_out_stride,
+                       void *stream_, bool blocking)
 {
     if (!c || !d_pcm || !d_out_off || !d_out_stride)
         return DVDA_HIP_EINVAL;
@@ -691,21 +751,25 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                        c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
     HIP_TRY(hipGetLastError());
-    int rc = read_summary(c, st);
-    if (rc)
+    // A blocking call waits for the fast pass here: its summary says what else is launched and how large the chain
+    // workspaces have to be.  A non-blocking call (dvda_mlp_hip_decode_async) never waits and never allocates: the
+    // passes behind the fast pass are enqueued on the workspaces dvda_mlp_hip_reserve left, sized for what was
+    // reserved, and find their work -- or none -- on the device.
+    int rc = 0;
+    if (blocking && (rc = read_summary(c, st)) != 0)
         return rc;
 
     // ---- chain passes: segments that continue the FIR history of the one before them, or change
     //      matrix-class parameters inside an access unit
-    if (c->h_summary->chain_segs) {
-        const uint64_t rows = c->h_summary->chain_rows;
-        const uint32_t segs = c->h_summary->chain_segs;
-        const uint32_t max_rows = c->h_summary->chain_max_rows;
+    if (blocking ? c->h_summary->chain_segs != 0 : c->rsv_segs != 0) {
+        const uint64_t rows = blocking ? c->h_summary->chain_rows : 0;
+        const uint32_t segs = blocking ? c->h_summary->chain_segs : c->rsv_segs;
+        const uint32_t max_rows = blocking ? c->h_summary->chain_max_rows : 0;
         if (rows >> 32)
             return DVDA_HIP_ECAPACITY;          // plan entries are 32-bit (137 GB of planes)
-        if ((rc = grow(&c->d_res, &c->res_cap, rows * 8 + 64)) != 0 ||
-            (rc = grow(&c->d_brec, &c->brec_cap, 8 * rows + 128ull * segs + 64)) != 0 ||
-            (rc = grow(&c->d_frec, &c->frec_cap, (rows / 40 + segs + 1) * FREC_WORDS)) != 0)
+        if (blocking && ((rc = grow(&c->d_res, &c->res_cap, rows * 8 + 64)) != 0 ||
+                         (rc = grow(&c->d_brec, &c->brec_cap, 8 * rows + 128ull * segs + 64)) != 0 ||
+                         (rc = grow(&c->d_frec, &c->frec_cap, (rows / 40 + segs + 1) * FREC_WORDS)) != 0))
             return rc;
         a.caps = ws_caps(c);
         ChainArgs ca;
@@ -740,6 +804,8 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         hipLaunchKernelGGL(k_scan4_sums, dim3(1), dim3(1024), 0, st, c->d_scan4_tmp, sblocks);
         hipLaunchKernelGGL(k_scan4_add, dim3(sblocks), dim3(1024), 0, st, c->d_plan, c->d_scan4_tmp, sblocks,
                            c->d_n_cand, c->max_segments);
+        if (!blocking)
+            hipLaunchKernelGGL(k_chain_guard, dim3(1), dim3(1), 0, st, c->d_plan, c->d_n_cand, c->max_segments, a.caps, segs);
         hipLaunchKernelGGL(k_chain_lists, dim3((unsigned)((ms + 255) / 256)), dim3(256), 0, st, ca);
         // parse: lane (pair) j takes deferred segment def_list[j]
         a.list = c->d_def_list;
@@ -770,16 +836,16 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
         HIP_TRY(hipGetLastError());
-        if ((rc = read_summary(c, st)) != 0)
+        if (blocking && (rc = read_summary(c, st)) != 0)
             return rc;
     }
 
     // ---- sequential pass: streams with non-standard timing, IIR taps or restart headers inside an access
     //      unit, whole and in order, one lane pair and one frame buffer per stream, a round at a time
-    const uint32_t n_seq = c->h_summary->seq_streams;
+    const uint32_t n_seq = blocking ? c->h_summary->seq_streams : c->fb_slots;
     if (n_seq) {
         const uint32_t round = n_seq < SEQ_ROUND ? n_seq : SEQ_ROUND;
-        if (round > c->fb_slots) {
+        if (blocking && round > c->fb_slots) {
             (void)hipFree(c->d_fb);
             c->d_fb = nullptr;
             c->fb_slots = 0;
@@ -791,6 +857,9 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
         a.caps = ws_caps(c);
         a.list = c->d_seq_list;
         a.only_S = 0;
+        // (non-blocking: ONE round of as many streams as frame buffers were reserved; how many streams there are
+        //  the kernel reads on the device, and what does not fit is reported by the last k_finalize)
+        a.list_n_ptr = blocking ? nullptr : &c->d_summary->seq_streams;
         for (uint32_t base = 0; base < n_seq; base += round) {
             a.list_base = base;
             a.list_n = n_seq - base < round ? n_seq - base : round;
@@ -800,7 +869,7 @@ extern "C" int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const ui
     }
     // (`waiting` without either: the lanes' count of deferred segments and the segments' status disagree -- the
     //  last finalize then reports what was left undecoded instead of passing it as clean)
-    if (c->h_summary->chain_segs || n_seq || c->h_summary->waiting)
+    if (!blocking || c->h_summary->chain_segs || n_seq || c->h_summary->waiting)
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 0u, 1u);
     (void)blocks2;

@@ -111,7 +111,7 @@ def test_wav_payload(pkg, oracle, coop, bits):
 
 def test_the_library_picks_it_for_small_batches_and_not_for_large_ones(pkg, oracle):
     """lanes 0: a batch of a few segments is decoded by the cooperative kernel, one past the device-side threshold
-    (8 192 segments) by the lane kernels -- the same PCM either way, nothing said by the caller."""
+    (4 096 segments) by the lane kernels -- the same PCM either way, nothing said by the caller."""
     syn, hip = pkg.synth, pkg.hipdec
     cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=16)
     small = [syn.stream(cfg, 9000 + i) for i in range(6)]
@@ -119,11 +119,11 @@ def test_the_library_picks_it_for_small_batches_and_not_for_large_ones(pkg, orac
     for (b, f), got, inf in zip(small, pcm, infos):
         want, r, st = oracle.decode(b, 6, f)
         assert st == 0 and inf.status == 0 and np.array_equal(got, want)
-    # 8 200 single-unit streams = 8 200 segments: past the threshold
+    # 4 200 single-unit streams = 4 200 segments: past the threshold
     cfg1 = syn.make_cfg(assignment=1, rate_code=0, n_substreams=1, n_aus=1)
-    flat, offs, sizes, frames = syn.batch(cfg1, 77, 8200)
+    flat, offs, sizes, frames = syn.batch(cfg1, 77, 4200)
     streams = [flat[int(o):int(o + s)] for o, s in zip(offs, sizes)]
     pcm, infos = hip.decode_streams(streams)
-    for i in range(0, 8200, 97):
+    for i in range(0, 4200, 97):
         want, r, st = oracle.decode(streams[i], 2, int(frames[i]))
         assert st == 0 and infos[i].status == 0 and np.array_equal(pcm[i], want)

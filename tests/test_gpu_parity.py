@@ -638,8 +638,8 @@ def test_two_substreams_of_any_split(pkg, oracle, ss0):
             syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0, profile=1,
                          features=syn.SF["CHAINED"] | syn.SF["FIRRAND"], restart_interval=4)]
     streams = [syn.stream(c, 9300 + 10 * ss0 + i) for i, c in enumerate(cfgs)]
-    pcm, infos = _both(hip, [b for b, _ in streams])
-    wide = ss0 < 2 or ss0 > 4
+    pcm, infos = _both(hip, [b for b, _ in streams], lanes_per_segment=2)      # (the two-wave kernel; a batch this small
+    wide = ss0 < 2 or ss0 > 4                                                    #  would otherwise get the cooperative one)
     for i, ((b, f), got, inf) in enumerate(zip(streams, pcm, infos)):
         want, r, st = oracle.decode(b, 6, f)
         assert st == 0 and r == f
