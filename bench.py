@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     help="1 = the BASELINE metric; 2 = the recipe's 2-substream variant (ch 0-1 | ch 2-5)")
     ap.add_argument("--assignment", type=int, default=12,
                     help="channel assignment of the synthetic titles (12 = 6-ch, the BASELINE metric)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="decode contexts in flight (each its own HIP stream and PCM buffer; a step is one index + one "
+                         "decode of the whole batch on the next of them): 1 = strictly one step after the other")
     ap.add_argument("--layout", default="interleaved", choices=("interleaved", "planar"),
                     help="PCM layout written by the decode: interleaved = frame-major, the order the "
                          "reference's dvda_read() hands out (default); planar = the order its decode_packet "
@@ -177,7 +180,12 @@ class Batch:
     """A set of MLP streams resident in HBM + the decode context and output buffers for it."""
 
     def __init__(self, pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, replicas, layout, lanes,
-                 n_segments):
+                 n_segments, depth=1, chained=False):
+        """depth > 1: a pipeline of `depth` decode contexts, each with its own HIP stream and PCM buffer, over the
+        same resident input -- step i runs on slot i % depth with the non-blocking decode call, so the index of one
+        batch overlaps the decode of the batch before it (what a production feeder does; a step is still one index
+        + one decode of the WHOLE batch).  chained: the titles' restart points carry FIR taps, the chain passes'
+        workspaces are reserved ahead (dvda_mlp_hip_reserve) so that the non-blocking call can decode them."""
         hip = pkg.hipdec
         self.hip, self.torch, self.dev = hip, torch, dev
         self.layout = {"interleaved": hip.PCM_INTERLEAVED, "planar": hip.PCM_PLANAR, "wav24": hip.PCM_WAV24}[layout]
@@ -208,20 +216,47 @@ class Batch:
         self.d_len = torch.from_numpy(self.all_len).to(dev)
         self.d_out_off = torch.from_numpy(self.out_off).to(dev)
         self.d_stride = torch.from_numpy(self.all_frames).to(dev)
-        self.d_pcm = torch.empty(max(self.pcm_words, 1), dtype=torch.int32, device=dev)
         self.n_segments = n_segments
-        self.ctx = hip.Context(local_rank, self.n_streams, n_segments, lanes_per_segment=lanes, layout=self.layout)
-        # a stream of its own (not the legacy default stream): the library replays the index as a hipGraph when the
-        # same buffers are indexed again, and capture needs a real stream
-        self._tstream = torch.cuda.Stream(dev)
+        self.depth = max(1, depth)
+        self.ctxs, self._tstreams, self.streams, self.d_pcms = [], [], [], []
+        for _ in range(self.depth):
+            self.d_pcms.append(torch.empty(max(self.pcm_words, 1), dtype=torch.int32, device=dev))
+            c = hip.Context(local_rank, self.n_streams, n_segments, lanes_per_segment=lanes, layout=self.layout)
+            if self.depth > 1 or chained:
+                c.reserve(self.rows_total if chained else 0, n_segments if chained else 0, 0)
+            self.ctxs.append(c)
+            # a stream of its own (not the legacy default stream): the library replays the index as a hipGraph when
+            # the same buffers are indexed again, and capture needs a real stream
+            ts = torch.cuda.Stream(dev)
+            self._tstreams.append(ts)
+            self.streams.append(ts.cuda_stream)
+        self.ctx, self.d_pcm, self.stream = self.ctxs[0], self.d_pcms[0], self.streams[0]
+        self._turn = 0
         torch.cuda.synchronize(dev)
-        self.stream = self._tstream.cuda_stream
 
     def step(self, n_streams=None):
         n = self.n_streams if n_streams is None else n_streams
         total = self.total_bytes if n == self.n_streams else int(self.all_off[n])
-        self.ctx.index(self.d_bytes.data_ptr(), total, self.d_off.data_ptr(), self.d_len.data_ptr(), n, self.stream)
-        self.ctx.decode(self.d_pcm.data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), self.stream)
+        k = self._turn % self.depth
+        self._turn += 1
+        ctx, st = self.ctxs[k], self.streams[k]
+        ctx.index(self.d_bytes.data_ptr(), total, self.d_off.data_ptr(), self.d_len.data_ptr(), n, st)
+        if self.depth > 1:
+            ctx.decode_async(self.d_pcms[k].data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), st)
+        else:
+            ctx.decode(self.d_pcms[k].data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), st)
+
+    def kernel_time(self):
+        """mean fast-pass kernel ms and launches over all slots since the last call"""
+        tot, n, dtot = 0.0, 0, 0.0
+        for c in self.ctxs:
+            dms, dk = c.decode_time()           # (first: kernel_time resets the ring)
+            ms, k = c.kernel_time()
+            tot += ms * k
+            dtot += dms * dk
+            n += k
+        self.last_decode_ms = dtot / n if n else 0.0    # whole decode call: every pass + the gaps between them
+        return (tot / n if n else 0.0), n
 
     def sync(self):
         self.torch.cuda.synchronize(self.dev)
@@ -231,23 +266,28 @@ class Batch:
         for _ in range(warmup):
             self.step(n_streams)
         self.sync()
-        self.ctx.kernel_time()
+        self.kernel_time()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(n_streams)
         self.sync()
         dt = time.perf_counter() - t0
-        kms, launches = self.ctx.kernel_time()
+        kms, launches = self.kernel_time()
         return dt, kms, launches
 
     def check_status(self, n_streams=None, benign=0):
         n = self.n_streams if n_streams is None else n_streams
-        infos = self.ctx.stream_info(n, stream=self.stream)
-        bad = [(i, hex(inf.status), int(inf.pcm_frames)) for i, inf in enumerate(infos)
-               if (inf.status & ~benign) != 0 or inf.pcm_frames != self.all_frames[i]]
-        if bad:
-            raise SystemExit("decode reported errors: %s" % bad[:8])
+        for k in range(min(self.depth, max(self._turn, 1))):
+            infos = self.ctxs[k].stream_info(n, stream=self.streams[k])
+            bad = [(i, hex(inf.status), int(inf.pcm_frames)) for i, inf in enumerate(infos)
+                   if (inf.status & ~benign) != 0 or inf.pcm_frames != self.all_frames[i]]
+            if bad:
+                raise SystemExit("decode reported errors (pipeline slot %d): %s" % (k, bad[:8]))
         return infos
+
+    def slots_equal(self):
+        """every pipeline slot decoded the batch to the same PCM (compared on the device)"""
+        return all(bool(self.torch.equal(self.d_pcms[0], p)) for p in self.d_pcms[1:min(self.depth, self._turn)])
 
     def title(self, host, i):
         """PCM of stream i out of a host copy of d_pcm, as [channels, frames]"""
@@ -283,8 +323,9 @@ class Batch:
         return all(bool(self.torch.equal(first, self.d_pcm[r * per:(r + 1) * per])) for r in range(1, self.R))
 
     def close(self):
-        self.ctx.close()
-        del self.d_pcm, self.d_bytes
+        for c in self.ctxs:
+            c.close()
+        del self.d_pcm, self.d_pcms, self.d_bytes
 
 
 def roofline_record(b, kms, launches, traffic, valu_per_sample=None):
@@ -350,8 +391,11 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         ok = b.verify_sample(flat, offs, sizes, picks)
         if not ok:
             raise SystemExit("sub-record %s: HIP decode differs from the oracle" % name)
+        # kernel_ms: device time of the whole decode call (fast pass + chain passes + sequential pass + what lies
+        # between them); fast_pass_ms: the fast-pass kernels alone
         rec = {"value": round(b.samples * steps / dt / 1e6, 1), "unit": "Msamples/s",
-               "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(kms, 4), "titles": b.n_streams,
+               "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(b.last_decode_ms, 4),
+               "fast_pass_ms": round(kms, 4), "titles": b.n_streams,
                "samples_per_step": b.samples, "compressed_bytes": b.comp_bytes,
                "algorithmic_bytes_per_launch": b.comp_bytes + b.out_bytes * b.samples,
                "bit_exact_sample": ok}
@@ -475,6 +519,37 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 8 192 access units (68 s of 96 kHz audio): the filter "
                                    "pass's serial recurrence is what bounds it")
     out["mixed_corpus_c5"] = mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup)
+    # ---- BASELINE configs[3] on this GPU: 1 024 independent single-access-unit streams in ONE batch -- the low-
+    #      parallelism regime, decoded by the wave-cooperative kernel (csrc/mlp_coop.h); throughput back to back and
+    #      the latency of one batch (index + decode enqueued and waited for, host clock); all 1 024 vs the oracle
+    t_run = time.perf_counter()
+    cfg4 = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=1)
+    flat4, offs4, sizes4, frames4 = syn.batch(cfg4, 1, 1024)
+    b4 = Batch(pkg, torch, dev, local_rank, flat4, offs4, sizes4, frames4, np.full(1024, 6), 1, "interleaved", 0, 1024)
+    k4 = 200
+    dt, kms, _ = b4.timed(k4, 10)
+    b4.check_status()
+    lat = []
+    for _ in range(100):
+        b4.sync()
+        t1 = time.perf_counter()
+        b4.step()
+        b4.sync()
+        lat.append(time.perf_counter() - t1)
+    lat.sort()
+    ok4 = b4.verify_sample(flat4, offs4, sizes4, np.arange(1024))
+    if not ok4:
+        raise SystemExit("sub-record c4: HIP decode differs from the oracle")
+    out["c4"] = {"value": round(b4.samples * k4 / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / k4 * 1e3, 4),
+                 "kernel_ms": round(b4.last_decode_ms, 4), "fast_pass_ms": round(kms, 4), "streams": 1024,
+                 "samples_per_step": b4.samples, "bit_exact_all_1024": ok4,
+                 "latency": {"median_ms": round(lat[len(lat) // 2] * 1e3, 4), "min_ms": round(lat[0] * 1e3, 4),
+                             "p90_ms": round(lat[int(len(lat) * 0.9)] * 1e3, 4), "batches": len(lat),
+                             "what": "one batch: index + decode enqueued and waited for, host clock"},
+                 "note": "BASELINE configs[3]: 1 024 independent 6-ch/96 kHz streams of ONE access unit (major sync + "
+                         "restart header + raw lead-in), one batch, one GPU; kernel picked by the library (wave-cooperative)"}
+    sys.stderr.write("bench: sub-record c4 %.1f s\n" % (time.perf_counter() - t_run))
+    b4.close()
     return out
 
 
@@ -781,7 +856,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
     n_seg = len(sizes) * replicas * ((aus + cfg.restart_interval - 1) // cfg.restart_interval)
     b = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, np.full(len(sizes), nch), replicas, args.layout,
-              0, max(n_seg, 64))          # 0: the library picks the kernels from the indexed substream counts
+              0, max(n_seg, 64), depth=args.pipeline)   # 0: the library picks the kernels from the indexed counts
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -795,13 +870,29 @@ def main():
     for _ in range(args.warmup):
         b.step()
     barrier()
-    b.ctx.kernel_time()  # drop warmup launches
+    b.kernel_time()  # drop warmup launches
     t0 = time.perf_counter()
     for _ in range(args.steps):
         b.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = b.ctx.kernel_time()
+    kernel_ms, launches = b.kernel_time()
+    # ---- the same step with nothing in flight beside it: one slot, the blocking decode call, waited for every time
+    serial = None
+    if args.pipeline > 1 and world == 1:
+        ks = max(3, min(10, args.steps))
+        b.sync()
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            b.ctxs[0].index(b.d_bytes.data_ptr(), b.total_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(), b.n_streams, b.streams[0])
+            b.ctxs[0].decode(b.d_pcms[0].data_ptr(), b.d_out_off.data_ptr(), b.d_stride.data_ptr(), b.streams[0])
+            b.sync()
+        t_serial = (time.perf_counter() - t1) / ks
+        skms, _ = b.kernel_time()
+        serial = {"ms_per_step": round(t_serial * 1e3, 4), "value": round(b.samples / t_serial / 1e6, 1),
+                  "kernel_ms": round(skms, 4), "steps": ks,
+                  "what": "index + blocking decode on ONE context, device idle in between (no overlap of one "
+                          "batch's index with another's decode)"}
 
     # ---- every title must have decoded cleanly ...
     b.check_status()
@@ -839,7 +930,7 @@ def main():
                 break
         checked = len(sizes)
         del host, ref_pcm
-        bit_exact = bit_exact and b.replicas_equal()
+        bit_exact = bit_exact and b.replicas_equal() and b.slots_equal()
         if not bit_exact:
             raise SystemExit("HIP decode differs from the CPU decoder (%s)" % cpu[0]["kind"])
     elif args.verify or args.workload == "c4":
@@ -900,6 +991,9 @@ def main():
                 "samples_per_step_per_gpu": b.samples,
                 "compressed_bytes_per_gpu": b.comp_bytes,
                 "parallelism": "titles sharded over %d GPU(s), no data-path collective" % world,
+                "pipeline": ("%d decode contexts in flight per GPU (own HIP stream and PCM buffer each, non-blocking "
+                             "decode call): the index of batch n + 1 overlaps the decode of batch n" % args.pipeline)
+                if args.pipeline > 1 else "one step after the other (blocking decode call)",
                 "bit_exact": bit_exact,
                 "bit_exact_titles_checked": checked,
                 "bit_exact_against": (cpu[0]["kind"] + " CPU decode of every unique title; replicas compared on the device")
@@ -907,6 +1001,8 @@ def main():
             },
             "roofline": roofline_record(b, kernel_ms, launches, prof["hbm_bytes_per_launch"] if prof else None, issue),
         }
+        if serial:
+            out["serial_step"] = serial
         if latency:
             out["latency"] = latency
         if cpu:

@@ -149,6 +149,26 @@ int dvda_mlp_hip_index(dvda_mlp_hip_ctx *ctx, const uint8_t *d_bytes, uint64_t t
 int dvda_mlp_hip_decode(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d_out_off,
                         const uint64_t *d_out_stride, void *stream);
 
+/* The same without the host ever waiting and without any allocation: every pass is enqueued on `stream` and the call
+ * returns -- so a caller can have the index of the next batch running (another context, another stream) while this
+ * batch decodes, or capture the call.  What the fast pass defers is decoded on the workspaces dvda_mlp_hip_reserve
+ * left: the chain passes are launched for as many deferred segments / PCM frames as were reserved and find their
+ * work on the device, the sequential pass for as many streams as were reserved; a batch that needs more than was
+ * reserved is NOT decoded short silently -- the streams left over carry DVDA_ST_CAPACITY (dvda_mlp_hip_stream_info),
+ * and the blocking call or a larger reservation decodes them.  With nothing reserved (a batch of regular titles with
+ * raw lead-in blocks at their restart points) only the fast pass and two small bookkeeping kernels are launched.
+ * Host-blocking entry points are dvda_mlp_hip_decode (once per call, twice when chains exist; it also grows the
+ * workspaces on first use) and the *_info / *_count calls. */
+int dvda_mlp_hip_decode_async(dvda_mlp_hip_ctx *ctx, int32_t *d_pcm, const uint64_t *d_out_off,
+                              const uint64_t *d_out_stride, void *stream);
+
+/* Sizes the workspaces of the passes behind the fast pass ahead of time (they only ever grow): chain passes for
+ * `chain_segments` deferred segments holding `chain_pcm_frames` PCM frames in all (for titles whose restart points
+ * carry FIR taps -- what encoders write -- that is every segment and every frame of the batch), the sequential pass
+ * for `seq_streams` streams at a time.  After it neither decode call allocates for a batch within these sizes. */
+int dvda_mlp_hip_reserve(dvda_mlp_hip_ctx *ctx, uint64_t chain_pcm_frames, uint32_t chain_segments,
+                         uint32_t seq_streams);
+
 /* PCM layout of dvda_mlp_hip_decode (default DVDA_PCM_PLANAR, above).  DVDA_PCM_INTERLEAVED writes
  * frame-major instead: d_pcm[d_out_off[i] + pcm_frame * channels + channel] -- the order the
  * reference's dvda_read() hands out (src/dvd-audio.c:781-792); d_out_stride[i] stays the capacity
@@ -181,6 +201,12 @@ int dvda_mlp_hip_segment_count(dvda_mlp_hip_ctx *ctx, uint32_t *n_segments, void
  * create time); *launches receives the count.  Blocks until those launches have finished. */
 int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *launches);
 
+/* The same ring read the other way: average device time of a whole decode call -- from the first kernel of the fast
+ * pass to the last kernel the call enqueued (chain passes, sequential pass, bookkeeping; for the blocking call the
+ * gaps while the host read the summary count too).  Does not reset the ring: call it before
+ * dvda_mlp_hip_kernel_time. */
+int dvda_mlp_hip_decode_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *calls);
+
 /* Range-checked diagnostic build (-DDVDA_BOUNDS, tests/test_gpu_soak.py): every index a kernel forms into a
  * workspace of the library is compared with the workspace's size; out4 = {violations so far, and of the first
  * one: array tag, index, capacity}.  Returns 1 from a checked build, 0 from the shipped library (which does not
@@ -193,7 +219,12 @@ int dvda_mlp_hip_bounds_violations(unsigned long long *out4);
  * kernel for the whole batch (1: a two-substream stream is then reported as DVDA_ST_ENVELOPE; 2: the
  * two-wave kernel keeps four channels per substream in registers -- what discs carry is 2 + 4 -- and a
  * substream with five or six channels is decoded by the passes behind it, DVDA_ST_COLD | DVDA_ST_GENERAL
- * set, PCM identical). */
+ * set, PCM identical).
+ * Under 0 a SMALL batch -- at most 4 096 segments and 32 768 access units, counted on the device by the index --
+ * is decoded by the wave-cooperative kernel instead (csrc/mlp_coop.h: one wave per (segment, substream), the
+ * bit-serial symbol scan in scalar registers, residuals / filter / rematrix at the width they have): BASELINE
+ * configs[3]'s 1 024 single access units, a single title, a streaming-tier packet.  64 forces that kernel for any
+ * batch; 1 / 2 never use it. */
 int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
 
 /* Per-segment results of the last decode (blocks on `stream`). */

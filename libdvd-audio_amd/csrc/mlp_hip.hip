@@ -127,6 +127,8 @@ struct dvda_mlp_hip_ctx {
     int idx_graph_state;       // 0: off / not yet, 1: the key was seen once (capture on the next match), 2: captured, -1: disabled
     // timing of the fast-pass kernel: a fixed ring of (start, stop) pairs made at create time
     hipEvent_t ev[2 * EV_RING];
+    hipEvent_t ev_end[EV_RING];    // behind the last kernel of the decode call (dvda_mlp_hip_decode_time)
+    uint32_t ev_end_made;
     uint32_t ev_made;          // events created
     uint64_t ev_count;         // decode calls recorded since the last dvda_mlp_hip_kernel_time
 };
@@ -204,6 +206,8 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_frec);
     for (uint32_t i = 0; i < c->ev_made; i++)
         (void)hipEventDestroy(c->ev[i]);
+    for (uint32_t i = 0; i < c->ev_end_made; i++)
+        (void)hipEventDestroy(c->ev_end[i]);
     if (c->idx_graph)
         (void)hipGraphExecDestroy(c->idx_graph);
 }
@@ -235,6 +239,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->idx_graph = nullptr;
     c->idx_graph_state = getenv("DVDA_INDEX_GRAPH") && atoi(getenv("DVDA_INDEX_GRAPH")) == 0 ? -1 : 0;
     c->ev_made = 0;
+    c->ev_end_made = 0;
     c->ev_count = 0;
     c->d_init_fir = nullptr;
     c->lanes_per_seg = 0;           // chosen per batch from the indexed substream counts
@@ -286,6 +291,11 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
         e = hipEventCreate(&c->ev[i]);
         if (e == hipSuccess)
             c->ev_made = i + 1;
+    }
+    for (uint32_t i = 0; e == hipSuccess && i < EV_RING; i++) {
+        e = hipEventCreate(&c->ev_end[i]);
+        if (e == hipSuccess)
+            c->ev_end_made = i + 1;
     }
     if (e != hipSuccess) {
         fprintf(stderr, "dvda_mlp_hip: workspace allocation failed: %s\n", hipGetErrorString(e));
@@ -873,6 +883,7 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 0u, 1u);
     (void)blocks2;
+    HIP_TRY(hipEventRecord(c->ev_end[slot], st));
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
 }
@@ -956,6 +967,28 @@ extern "C" int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *c, double *avg_ms, uin
     *avg_ms = n ? total / n : 0.0;
     if (launches)
         *launches = n;
+    return DVDA_HIP_OK;
+}
+
+// the same ring, first kernel of a decode call to its last (fast pass + whatever ran behind it, and the gaps in
+// between): does not reset the ring -- call it BEFORE dvda_mlp_hip_kernel_time
+extern "C" int dvda_mlp_hip_decode_time(dvda_mlp_hip_ctx *c, double *avg_ms, uint32_t *calls)
+{
+    if (!c || !avg_ms)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    double total = 0;
+    const uint32_t n = c->ev_count < EV_RING ? (uint32_t)c->ev_count : EV_RING;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t slot = (uint32_t)((c->ev_count - 1 - i) % EV_RING);
+        HIP_TRY(hipEventSynchronize(c->ev_end[slot]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[2 * slot], c->ev_end[slot]));
+        total += ms;
+    }
+    *avg_ms = n ? total / n : 0.0;
+    if (calls)
+        *calls = n;
     return DVDA_HIP_OK;
 }
 

@@ -40,7 +40,8 @@ _lib = None
 EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", "dvda_mlp_hip_decode",
            "dvda_mlp_hip_stream_info", "dvda_mlp_hip_segment_count", "dvda_mlp_hip_kernel_time",
            "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_selftest_bits",
-           "dvda_mlp_hip_bounds_violations",
+           "dvda_mlp_hip_bounds_violations", "dvda_mlp_hip_decode_async", "dvda_mlp_hip_reserve",
+           "dvda_mlp_hip_decode_time",
            "dvda_mlp_hip_set_lanes_per_segment",
            "dvda_mlp_hip_set_pcm_layout", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
@@ -70,9 +71,12 @@ def lib():
         L.dvda_mlp_hip_destroy.restype = None
         L.dvda_mlp_hip_index.argtypes = [vp, vp, u64, vp, vp, u32, vp]
         L.dvda_mlp_hip_decode.argtypes = [vp, vp, vp, vp, vp]
+        L.dvda_mlp_hip_decode_async.argtypes = [vp, vp, vp, vp, vp]
+        L.dvda_mlp_hip_reserve.argtypes = [vp, u64, u32, u32]
         L.dvda_mlp_hip_stream_info.argtypes = [vp, ctypes.POINTER(StreamInfo), u32, vp]
         L.dvda_mlp_hip_segment_count.argtypes = [vp, ctypes.POINTER(u32), vp]
         L.dvda_mlp_hip_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
+        L.dvda_mlp_hip_decode_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
         L.dvda_mlp_hip_set_lanes_per_segment.argtypes = [vp, u32]
         L.dvda_mlp_hip_set_pcm_layout.argtypes = [vp, u32]
         L.dvda_mlp_hip_version.restype = ctypes.c_char_p
@@ -139,6 +143,14 @@ class Context:
         _check(lib().dvda_mlp_hip_decode(self._h, d_pcm_ptr, d_out_off_ptr, d_out_stride_ptr, stream),
                "dvda_mlp_hip_decode")
 
+    def decode_async(self, d_pcm_ptr, d_out_off_ptr, d_out_stride_ptr, stream=0):
+        """dvda_mlp_hip_decode_async: every pass enqueued, no host wait, no allocation (see reserve)."""
+        _check(lib().dvda_mlp_hip_decode_async(self._h, d_pcm_ptr, d_out_off_ptr, d_out_stride_ptr, stream),
+               "dvda_mlp_hip_decode_async")
+
+    def reserve(self, chain_pcm_frames=0, chain_segments=0, seq_streams=0):
+        _check(lib().dvda_mlp_hip_reserve(self._h, chain_pcm_frames, chain_segments, seq_streams), "dvda_mlp_hip_reserve")
+
     def stream_info(self, n=None, stream=0):
         n = self.n_streams if n is None else n
         arr = (StreamInfo * n)()
@@ -149,6 +161,13 @@ class Context:
         v = ctypes.c_uint32()
         _check(lib().dvda_mlp_hip_segment_count(self._h, ctypes.byref(v), stream), "segment_count")
         return int(v.value)
+
+    def decode_time(self):
+        """mean device ms of a whole decode call (all passes); call before kernel_time(), which resets the ring"""
+        ms = ctypes.c_double()
+        n = ctypes.c_uint32()
+        _check(lib().dvda_mlp_hip_decode_time(self._h, ctypes.byref(ms), ctypes.byref(n)), "decode_time")
+        return float(ms.value), int(n.value)
 
     def kernel_time(self):
         ms = ctypes.c_double()
