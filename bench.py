@@ -62,7 +62,7 @@ def parse_args(argv=None):
                     help="1 = the BASELINE metric; 2 = the recipe's 2-substream variant (ch 0-1 | ch 2-5)")
     ap.add_argument("--assignment", type=int, default=12,
                     help="channel assignment of the synthetic titles (12 = 6-ch, the BASELINE metric)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=1,
                     help="decode contexts in flight (each its own HIP stream and PCM buffer; a step is one index + one "
                          "decode of the whole batch on the next of them): 1 = strictly one step after the other")
     ap.add_argument("--layout", default="interleaved", choices=("interleaved", "planar"),
@@ -232,6 +232,7 @@ class Batch:
             self.streams.append(ts.cuda_stream)
         self.ctx, self.d_pcm, self.stream = self.ctxs[0], self.d_pcms[0], self.streams[0]
         self._turn = 0
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]       # slot k's decode has finished
         torch.cuda.synchronize(dev)
 
     def step(self, n_streams=None):
@@ -242,7 +243,13 @@ class Batch:
         ctx, st = self.ctxs[k], self.streams[k]
         ctx.index(self.d_bytes.data_ptr(), total, self.d_off.data_ptr(), self.d_len.data_ptr(), n, st)
         if self.depth > 1:
+            # the decodes themselves run one after the other (two fast-pass kernels side by side only take each
+            # other's issue slots): this slot's decode waits for the previous slot's; what overlaps is this
+            # slot's INDEX -- bound by HBM -- with that decode -- bound by instruction issue
+            if self._turn > 1:
+                self._tstreams[k].wait_event(self._done[(k - 1) % self.depth])
             ctx.decode_async(self.d_pcms[k].data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), st)
+            self._done[k].record(self._tstreams[k])
         else:
             ctx.decode(self.d_pcms[k].data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), st)
 

@@ -96,21 +96,35 @@ struct CoopSub {
                                 // + the two noise coefficients
 };
 
+// PARSE = false: the fast pass for small batches (everything up to PCM).
+// PARSE = true : the chain passes' parse pass for small batches -- workgroup j takes deferred segment def_list[j] and
+//   leaves what k_decode<.., PARSE> leaves (mlp_decode.h): residuals, bypassed LSBs and noise seeds in the segment's
+//   eight planes, a block record per block that sets filter parameters, a record per access unit with the
+//   rematrix parameters its last block left; k_chain_filter / k_chain_rematrix take it from there.  (One lane of
+//   k_decode needs 1.6 ms for a segment of eight units whatever the batch holds: for ONE chained title that was
+//   half of the whole decode.)
+template <bool PARSE>
 __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
 {
-    if (!coop_takes(a))
+    if (!PARSE && !coop_takes(a))
         return;
     __shared__ uint32_t s_stage[COOP_STAGE_DW];
     __shared__ int32_t s_val[MAXCH][COOP_VSTRIDE];      // residuals -> filtered values, MLP channel order
     __shared__ uint32_t s_byp[COOP_ROWS];               // bypassed LSBs of the row (last substream's)
     __shared__ CoopSub s_sub[2];
     __shared__ uint32_t s_err[2];
+    __shared__ uint32_t s_yield;
     __shared__ uint8_t s_wav[64 * 6 * 3 + 16];          // packed WAV payload of one output step
 
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
-    const uint32_t segi = blockIdx.x;
+    uint32_t segi = blockIdx.x;
+    if (PARSE) {
+        if (blockIdx.x >= a.list_n || blockIdx.x >= a.plan[n_seg].y)
+            return;
+        segi = a.list[a.list_base + blockIdx.x];
+    }
     if (segi >= n_seg)
         return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -174,6 +188,21 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     uint32_t rows_written = 0, frames_out = 0;
     const uint32_t chk = a.seg_check[(size_t)segi * 2u + sub];
     bool stop = false;
+    // ---- parse pass: where this segment's planes and records go (ChainPlan, mlp_chain.h)
+    uint32_t *brec = nullptr, *brec_end = nullptr, *frec = nullptr;
+    int32_t *planes = nullptr;
+    bool seg_iir = false;
+    if (PARSE) {
+        const uint4 pl = a.plan[segi];
+        const uint32_t seg_R = (sr.nframes - sr.ndrop) * rpa;
+        const uint32_t cap = brec_capacity(seg_R);
+        planes = a.res + (uint64_t)pl.x * 8u;
+        brec = a.brec + 8ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap;
+        brec_end = brec + cap - 2u;                 // room for the terminator
+        frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
+        if (lane == 0)
+            atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
+    }
     const uint32_t nthreads = two ? (uint32_t)COOP_THREADS : 64u;
     const uint32_t tid = two ? threadIdx.x : lane;
 
@@ -244,8 +273,11 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     bool ok = true;
                     uint32_t e1 = ST_PARAMS;
                     uint32_t new_iir_mask = 0;
+                    uint32_t chg_mask = 0, iir_mask = 0, rec_words = 0;     // parse pass: this block's record
+                    bool seq_needed = false, hdr_restart = false;
                     if (rd.read(1)) {
                         const bool restart = rd.read(1) != 0;
+                        hdr_restart = restart;
                         if (restart) {
                             // ---- restart header (src/mlp.c:822-851)
                             const uint32_t h0 = rd.read(14);           // 13u sync, 1u noise_type
@@ -492,12 +524,44 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                                         } else {
                                             shift = iir_shift;
                                         }
-                                        if (fir_order && f == 0 && blocks_in_frame == 0)
+                                        if (!PARSE && fir_order && f == 0 && blocks_in_frame == 0)
                                             status |= ST_CHAINED;      // needs the previous segment's history
                                         P.sho[k] = hoff - huff_center(codebook, lb);
                                         P.pk[k] = codebook | (lb << 2) | (q << 7) | (shift << 11) | (iir_order << 15) |
                                                   (fir_order << 19) | (fir_shift << 23) | (iir_shift << 27) |
                                                   (codebook ? 1u << 31 : 0u);
+                                        if (iir_order)
+                                            seg_iir = true;
+                                        if (PARSE) {
+                                            // ---- what the filter pass needs of this slot from this row on (the block
+                                            //      record of k_decode<.., PARSE>): shift | quant step | orders, the FIR
+                                            //      taps, and -- when this block (re)sets the slot's IIR -- its taps and
+                                            //      the history it starts from
+                                            const bool nw_iir = ((new_iir_mask >> k) & 1u) != 0;
+                                            const bool with_iir = nw_iir && iir_order != 0;
+                                            uint32_t *w = brec + 2 + rec_words;
+                                            if (w + BREC_SLOT_WORDS + (with_iir ? BREC_IIR_WORDS : 0) > brec_end) {
+                                                seq_needed = true;      // more parameter changes than the records hold
+                                            } else {
+                                                if (lane == 0) {
+                                                    w[0] = shift | (q << 4) | (fir_order << 8) | (iir_order << 12) | (nw_iir ? 1u << 16 : 0u);
+                                                    for (uint32_t j = 0; j < 4; j++)
+                                                        w[1 + j] = P.cf[k][j];
+                                                    if (with_iir) {
+                                                        for (uint32_t j = 0; j < 4; j++)
+                                                            w[5 + j] = P.icf[k][j];
+                                                        for (uint32_t j = 0; j < 8; j++)
+                                                            w[9 + j] = (uint32_t)P.ihist[k][j];
+                                                    }
+                                                }
+                                                chg_mask |= 1u << k;
+                                                rec_words += BREC_SLOT_WORDS;
+                                                if (with_iir) {
+                                                    iir_mask |= 1u << k;
+                                                    rec_words += BREC_IIR_WORDS;
+                                                }
+                                            }
+                                        }
                                     }
                                 }
                             }
@@ -511,8 +575,26 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         err = e1;
                         break;
                     }
-                    if (status & ST_CHAINED)
-                        break;                      // left to the chain passes (needs the history before this segment)
+                    if (status & ST_CHAINED) {
+                        // left to the chain passes (needs the history before this segment) -- which start one segment
+                        // earlier if that segment's workgroup hears of it in time (ST_YIELD, as in the lane kernel: it
+                        // is decoding a whole segment on its own only to hand over its last eight values, and for one
+                        // chained title that segment is all the fast pass has to do)
+                        if (lane == 0 && sr.prev != 0xFFFFFFFFu)
+                            __hip_atomic_store(&a.yield_req[sr.prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    if (PARSE && chg_mask) {
+                        if (lane == 0) {
+                            brec[0] = frames_out * rpa + frame_rows;    // first PCM frame (of the segment) the record applies to
+                            brec[1] = chg_mask | (iir_mask << 8);
+                        }
+                        brec += 2 + rec_words;
+                    }
+                    if (PARSE && (seq_needed || (hdr_restart && blocks_in_frame))) {
+                        err = ST_SEQ;               // a restart header inside a unit, or records overflowed: the whole
+                        break;                      // stream goes through the sequential pass
+                    }
                     if (frame_rows + block_size > rpa) {
                         err = ST_TIMING;            // more PCM frames than the standard access unit: the sequential pass
                         break;
@@ -648,7 +730,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     }
                     rd.pos = pos;
                     // ---- FILTER: lane k runs channel min_ch + k through the block's rows (src/mlp.c:1243-1306)
-                    {
+                    //      (parse pass: the residuals stay as they are, k_chain_filter runs the recursion)
+                    if (!PARSE) {
                         const uint32_t k = lane < 8u ? lane : 0u;
                         const uint32_t pkk = P.pk[k];
                         f_shift = (pkk >> 11) & 15u;
@@ -712,6 +795,42 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         status |= err;
         if (quit) {
             stop = true;
+        } else if (PARSE && !dropped && is_last) {
+            // ============================================================ parse pass: the unit's rows into the planes
+            // ([row / 4][plane][row % 4], res_index(): residuals of the six channels, bypassed LSBs, the noise seed
+            //  the row is rematrixed with) and its rematrix parameters into the per-unit record
+            const uint32_t seg_row0 = frames_out * rpa;
+            for (uint32_t rb = 0; rb < rpa; rb += 64u) {
+                const uint32_t row = rb + lane;
+                uint32_t sd = seed;
+                for (uint32_t i = 0; i < lane; i++) {
+                    const uint32_t shifted = (sd >> 7) & 0xFFFFu;
+                    sd = (sd << 16) ^ shifted ^ (shifted << 5);
+                }
+                if (row < rpa) {
+                    int32_t *dst = planes + res_index(seg_row0 + row, 0);
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        dst[4 * c] = s_val[c][row];
+                    dst[4 * 6] = (int32_t)s_byp[row];
+                    dst[4 * 7] = (int32_t)sd;
+                }
+                const uint32_t adv = rpa - rb < 64u ? rpa - rb : 64u;
+                for (uint32_t i = 0; i < adv; i++) {
+                    const uint32_t sh2 = (seed >> 7) & 0xFFFFu;
+                    seed = (seed << 16) ^ sh2 ^ (sh2 << 5);
+                }
+            }
+            if (lane == 0) {
+                uint32_t *F = frec + (size_t)frames_out * FREC_WORDS;
+                F[0] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
+                F[1] = outch_pack;
+                F[2] = qss_pack;
+                F[3] = oshift_pack;
+                for (uint32_t m = 0; m < matrix_len; m++)
+                    for (uint32_t j = 0; j < 5; j++)
+                        F[4 + m * 5 + j] = P.mat[m][j];
+            }
         } else if (!dropped && is_last) {
             // ============================================================ rematrix + output of the access unit
             // (src/mlp.c:504-533, 1308-1358: once per unit, with the parameters its last block left, all channels
@@ -813,11 +932,42 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         }
         if (!dropped && !quit)
             frames_out++;
+        // (the segment behind this one continues its history: both go to the chain passes -- looked at after the
+        //  first two units only; later the request is ignored and the segment is decoded here, which is as good)
+        const bool ask = !PARSE && !quit && f < 2u && f + 1u < sr.nframes;
+        uint32_t yield = 0;
+        if (ask) {
+            const uint32_t y = __hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!two)
+                yield = rfl(y);
+            else if (threadIdx.x == 0)
+                s_yield = y;            // (one reading for both waves: they have to leave together)
+        }
         cur = frame_end;
-        if (two)
+        if (two) {
             __syncthreads();            // the stage and the values are free again
+            if (ask)
+                yield = rfl(s_yield);
+        }
+        if (yield) {
+            status |= ST_YIELD;
+            stop = true;
+        }
     }
 
+    if (PARSE) {
+        // ---- end of this (segment, substream)'s records; the segment's channel range and whether any of its blocks
+        //      runs IIR taps, for the filter pass
+        if (lane == 0) {
+            if (!stop) {
+                brec[0] = brec[1] = 0xFFFFFFFFu;
+                a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8) | (seg_iir ? 1u << 9 : 0u);
+            }
+            if (status)
+                atomicOr(&a.seg_status[segi], status);
+        }
+        return;
+    }
     // ---- what a following segment (or a later call) continues from: the FIR history at the segment's end
     if (!stop && a.fir_ws) {
         if (lane < 6u) {

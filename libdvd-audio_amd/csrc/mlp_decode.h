@@ -65,6 +65,11 @@ constexpr int OUT_ROWS = 4;                     // PCM frames staged per channel
 // still within its first two access units: the chain passes run anyway, and a wave kept alive by a few lanes holds
 // the whole fast pass (and everything that waits for it) for the time one segment takes, 2.6 ms.
 constexpr uint32_t YIELD_LONELY = 48;
+// header gate of the one-lane kernels (see the header phase of k_decode)
+#ifndef DVDA_HDR_GATE
+#define DVDA_HDR_GATE 1
+#endif
+constexpr uint32_t HDR_GATE_TURNS = 4, HDR_GATE_LANES = 16;
 // The row-loop experiments of rounds 1 and 2 that lost (ring holding byte-swapped dwords, slot tests on a scalar
 // count, the second window step without its branch, split FIR accumulators, uniform slots, line-aware prefetch,
 // store cache policies, alternating wave roles) are no longer in this file: DESIGN.md section 4 keeps what each
@@ -775,6 +780,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t par_seen = 0, par_pub = 0;   // WS_BAL: version of the published parameters (taken / written)
     uint32_t par_phase = 0;               // ... and the phase + 1 the last one was written in
     uint32_t it = 0;                      // two-wave layout: loop turn (wave-uniform); phase = it / OUT_ROWS
+    uint32_t gate_turn = 0;               // loop turn for the header gate (wave-uniform)
+    constexpr bool HDR_GATE = DVDA_HDR_GATE && !PAIRED && !GENERAL;
     const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
     uint32_t nslots = 0;
     bool have_restart = false;
@@ -864,7 +871,23 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         DVDA_STAMP(5);
         bool hdr_parsed = false;       // this lane parsed a block header in this iteration
         // =================================================== header phase
-        if (__builtin_expect(active && rows_left == 0, 0)) {
+        // The header parser is long, cold code, and the wave runs it whenever ANY lane stands at a block header.
+        // On streams whose blocks carry parameters (what encoders write) the lanes of a wave drift apart, nearly
+        // every loop turn has some lane at a header, and the whole wave pays the parser every turn: the header
+        // parse becomes the row loop (sub.fuzz_fast_features: 9 x below the headline in round 2).  So headers are
+        // parsed in company: the phase runs when every active lane waits for it (lanes in lockstep: at once), when
+        // HDR_GATE_LANES of them do, or on every HDR_GATE_TURNS-th turn -- a lane waits a few turns, rowless, and
+        // the wave pays the parser a quarter as often.  (Not in the two-wave layout -- its waves exchange rows by
+        // turn count -- nor in the sequential pass, whose lane pairs end access units together.)
+        bool hdr_now = active && rows_left == 0;
+        if (HDR_GATE && __builtin_expect(__any(hdr_now), 0)) {
+            const uint64_t m_need = __ballot(hdr_now), m_act = __ballot(active);
+            const bool go = m_need == m_act || (uint32_t)__popcll(m_need) >= HDR_GATE_LANES ||
+                            (gate_turn & (HDR_GATE_TURNS - 1u)) == 0u;
+            hdr_now = hdr_now && go;
+        }
+        gate_turn++;
+        if (__builtin_expect(hdr_now, 0)) {
             // (a loop only because of dropped frames: a frame that carries a major sync with other stream
             //  parameters yields nothing and the next one is looked at, src/mlp.c:449-460)
             while (active && !in_frame) {
@@ -1825,7 +1848,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // ---- the frame's channels 0..7 come together for the rematrix
         int32_t ch[MAXCH];
         // (two-wave layout: the lane that rematrixes starts OUT_ROWS turns late, for good)
-        const bool in_row = active && (!adopt || it >= (uint32_t)OUT_ROWS);
+        const bool in_row = active && (!HDR_GATE || rows_left != 0) && (!adopt || it >= (uint32_t)OUT_ROWS);
         if constexpr (WSPEC) {
             if (in_row)
                 row_head();

@@ -739,7 +739,7 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     // ---- fast pass (timed: the dominant kernel)
     if (coop_only || force == 0) {
         const unsigned cblocks = (unsigned)(coop_only || ms < COOP_MAX_SEG ? ms : COOP_MAX_SEG);
-        hipLaunchKernelGGL(k_coop, dim3(cblocks), dim3(COOP_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_coop<false>, dim3(cblocks), dim3(COOP_THREADS), 0, st, a);
     }
     if (run1) {
         a.only_S = force ? 0u : 1u;
@@ -825,15 +825,23 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         a.res = c->d_res;
         a.brec = c->d_brec;
         a.frec = c->d_frec;
-        if (force != 2) {
-            a.only_S = force ? 0u : 1u;
-            hipLaunchKernelGGL((k_decode<6, false, false, false, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
-                               dim3(DEC_THREADS), 0, st, a);
-        }
-        if (force != 1) {
-            a.only_S = force ? 0u : 2u;
-            hipLaunchKernelGGL((k_decode<6, true, false, false, true>), dim3((2 * segs + DEC_THREADS - 1) / DEC_THREADS),
-                               dim3(DEC_THREADS), 0, st, a);
+        // (few deferred segments -- one chained title, a small batch: a workgroup per segment, mlp_coop.h; a lane of
+        //  k_decode needs 1.6 ms for a segment of eight units however few there are.  Known on the host in the
+        //  blocking call; the non-blocking one sizes by its reservation.)
+        const bool coop_parse = coop_only || (c->lanes_per_seg == 0 && segs <= COOP_MAX_SEG);
+        if (coop_parse) {
+            hipLaunchKernelGGL(k_coop<true>, dim3(segs), dim3(COOP_THREADS), 0, st, a);
+        } else {
+            if (force != 2) {
+                a.only_S = force ? 0u : 1u;
+                hipLaunchKernelGGL((k_decode<6, false, false, false, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
+                                   dim3(DEC_THREADS), 0, st, a);
+            }
+            if (force != 1) {
+                a.only_S = force ? 0u : 2u;
+                hipLaunchKernelGGL((k_decode<6, true, false, false, true>), dim3((2 * segs + DEC_THREADS - 1) / DEC_THREADS),
+                                   dim3(DEC_THREADS), 0, st, a);
+            }
         }
         // filter: 16 lanes per chain (at most one chain per deferred segment)
         hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""tools/shape_bench.py [SHAPE ...] -- one bench sub-record shape at a time, for A/B builds (DVDA_MLP_HIP_LIB):
+fuzz_fast, fuzz_all, hetero_short, chained (1 024 x 128), chained2 (4 096 x 512, two substreams), two (two substreams).
+Prints Msamples/s, ms per step, whole-call and fast-pass kernel ms.  Diagnostic."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import libdvd_audio_amd as pkg  # noqa: E402
+from bench import Batch, gen_mixed  # noqa: E402
+
+syn, hip = pkg.synth, pkg.hipdec
+dev = torch.device("cuda", 0)
+SF = syn.SF
+
+
+def run(name, flat, offs, sizes, frames, nchs, nseg, replicas, layout="planar", lanes=0, steps=10):
+    b = Batch(pkg, torch, dev, 0, flat, offs, sizes, frames, nchs, replicas, layout, lanes, nseg)
+    dt, kms, _ = b.timed(steps, 2)
+    b.check_status(benign=hip.ST_BENIGN)
+    ok = b.verify_sample(flat, offs, sizes, np.linspace(0, b.n_streams - 1, num=8, dtype=np.int64))
+    print("%-14s %9.1f Msamples/s  %8.3f ms/step  call %8.3f ms  fast pass %8.3f ms  bit-exact %s" % (
+        name, b.samples * steps / dt / 1e6, dt / steps * 1e3, b.last_decode_ms, kms, ok), flush=True)
+    b.close()
+    del b
+    torch.cuda.empty_cache()
+
+
+shapes = [(12, 1, 8), (1, 1, 5), (12, 2, 16), (0x12, 0, 3), (12, 0, 8), (6, 1, 4), (0, 2, 8), (12, 1, 2)]
+which = sys.argv[1:] or ["fuzz_fast", "fuzz_all", "chained", "two"]
+for w in which:
+    if w in ("fuzz_fast", "fuzz_all"):
+        feats = syn.SF_FAST & ~(SF["IIR"] | SF["MATRIXRAND"]) if w == "fuzz_fast" else syn.SF_FAST
+        specs = [(syn.make_cfg(assignment=a, rate_code=rc, n_substreams=1, n_aus=64, profile=1, features=feats,
+                               restart_interval=ri), 512) for a, rc, ri in shapes]
+        flat, offs, sizes, frames, nchs, nseg = gen_mixed(syn, specs, 90000)
+        run(w, flat, offs, sizes, frames, nchs, nseg * 4, 4)
+    elif w == "chained":
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=128, profile=1, features=SF["CHAINED"])
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
+        run(w, flat, offs, sizes, frames, np.full(1024, 6), 1024 * 17, 1, "interleaved")
+    elif w in ("chained1", "chained2"):
+        S = 1 if w == "chained1" else 2
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=512, profile=1, features=SF["CHAINED"])
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
+        run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 65, 4, "interleaved")
+    elif w == "two":
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=512)
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
+        run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 64, 4, "interleaved")
+    elif w in ("one_chained", "one_chained_long"):
+        n_aus = 512 if w == "one_chained" else 8192
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=n_aus, profile=1, features=SF["CHAINED"])
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 1)
+        run(w, flat, offs, sizes, frames, np.full(1, 6), n_aus // 8 + 8, 1, "interleaved", steps=20)
+    elif w == "headline":
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=512)
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
+        run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 64, 4, "interleaved")

@@ -8,17 +8,31 @@ os.environ["DVDA_MLP_HIP_LIB"] = os.path.join(ROOT, "libdvd-audio_amd", "exp_sta
 import numpy as np, torch
 import libdvd_audio_amd as pkg
 syn, hip = pkg.synth, pkg.hipdec
-SS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512, n_substreams=SS)
-flat, offs, sizes, frames = syn.batch(cfg, 1, 2048)
+SS = 1
+if len(sys.argv) > 1 and sys.argv[1] in ("fuzz_fast", "fuzz_all"):
+    # the bench's fuzz sub-record shape (8 configurations x 512 titles of 64 access units)
+    from bench import gen_mixed
+    SF = syn.SF
+    feats = syn.SF_FAST & ~(SF["IIR"] | SF["MATRIXRAND"]) if sys.argv[1] == "fuzz_fast" else syn.SF_FAST
+    shapes = [(12, 1, 8), (1, 1, 5), (12, 2, 16), (0x12, 0, 3), (12, 0, 8), (6, 1, 4), (0, 2, 8), (12, 1, 2)]
+    specs = [(syn.make_cfg(assignment=a, rate_code=rc, n_substreams=1, n_aus=64, profile=1, features=feats,
+                           restart_interval=ri), 512) for a, rc, ri in shapes]
+    flat, offs, sizes, frames, nchs, nseg = gen_mixed(syn, specs, 90000)
+    n = len(sizes)
+else:
+    SS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512, n_substreams=SS)
+    flat, offs, sizes, frames = syn.batch(cfg, 1, 2048)
+    n = 2048
+    nchs = np.full(n, 6, np.int64)
+    nseg = n * 64
 dev = torch.device("cuda", 0)
 d_bytes = torch.from_numpy(flat).to(dev)
-n = 2048
 d_off = torch.from_numpy(offs.astype(np.int64)).to(dev); d_len = torch.from_numpy(sizes.astype(np.int64)).to(dev)
-out_off = np.zeros(n, np.int64); out_off[1:] = np.cumsum(frames[:-1].astype(np.int64) * 6)
+out_off = np.zeros(n, np.int64); out_off[1:] = np.cumsum(frames[:-1].astype(np.int64) * nchs[:-1])
 d_oo = torch.from_numpy(out_off).to(dev); d_st = torch.from_numpy(frames.astype(np.int64)).to(dev)
-d_pcm = torch.empty(int(frames.sum()) * 6, dtype=torch.int32, device=dev)
-ctx = hip.Context(0, n, n * 64, lanes_per_segment=0)
+d_pcm = torch.empty(int((frames.astype(np.int64) * nchs).sum()), dtype=torch.int32, device=dev)
+ctx = hip.Context(0, n, nseg, lanes_per_segment=0)
 for it in range(2):
     ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), n, 0)
     ctx.decode(d_pcm.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), 0)
@@ -27,7 +41,7 @@ for it in range(2):
     hip.lib().dvda_mlp_hip_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     hip.lib().dvda_mlp_hip_debug_counters(ctx._h, out)
 names = ["header phase", "prefetch issue / sync fill", "parse+filter (row)", "exchange+rematrix+stage", "ring commit+flush",
-         "loop top", "phase barrier (two-wave) / wait for the chunk (one-lane)", "parity/CRC catch-up"]
+         "loop top", "phase barrier (two-wave) / wait for the chunk (one-lane)", "ring top-up test"]
 for role in range(2 if SS == 2 else 1):
     v = np.array(list(out)[8 * role:8 * role + 8], dtype=np.float64)
     print("role", role, "(two-wave layout: 0 = first substream's wave, rematrixes; 1 = last substream's wave)" if SS == 2 else "")
