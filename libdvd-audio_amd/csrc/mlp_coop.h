@@ -58,27 +58,55 @@ __device__ __forceinline__ void coop_writelane(uint32_t &v, uint32_t s)
 }
 
 // wave-uniform MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206) over the access unit
-// staged in LDS as big-endian dwords; bit 0 = the top bit of staged dword 0
+// staged in LDS as big-endian dwords; bit 0 = the top bit of staged dword 0.
+// The stream sits in a 64-bit window in scalar registers: `win` from the next unread bit on, valid up to stream bit
+// thr + 32; one dword more whenever 32 bits or less are left (pos >= thr), so a read of up to 32 bits -- or the 9-bit
+// peek of the symbol scan, which works on this same state -- never waits: the dword behind the window was asked for
+// at the last refill (`pend`, a vector register the LDS read lands in) and is only taken (readfirstlane) at this one.
+// (First version: two LDS reads + two readfirstlanes per field, a round trip on every one of a header's ~150 fields.)
 struct UReader {
     const uint32_t *w;
-    uint32_t pos;
-    __device__ __forceinline__ uint32_t peek32() const
+    uint64_t win;
+    uint32_t pos, thr;
+    const uint32_t *pnext;
+    uint32_t pend;
+    __device__ __forceinline__ void seek(uint32_t p)
     {
-        const uint32_t i = (pos >> 5) < (uint32_t)COOP_STAGE_DW - 2u ? pos >> 5 : (uint32_t)COOP_STAGE_DW - 2u, o = pos & 31u;
-        const uint32_t hi = rfl(w[i]), lo = rfl(w[i + 1]);
-        return (uint32_t)((((uint64_t)hi << 32) | lo) << o >> 32);
+        const uint32_t i = (p >> 5) < (uint32_t)COOP_STAGE_DW - 3u ? p >> 5 : (uint32_t)COOP_STAGE_DW - 3u;
+        const uint32_t d0 = rfl(w[i]), d1 = rfl(w[i + 1]);
+        win = (((uint64_t)d0 << 32) | d1) << (p & 31u);
+        pos = p;
+        thr = 32u * i + 32u;
+        pnext = w + i + 2;
+        pend = *pnext;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (pos >= thr) {
+            win |= (uint64_t)rfl(pend) << (pos - thr);      // 32 - (bits left) = pos - thr
+            thr += 32u;
+            pnext++;
+            pend = *pnext;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek32()
+    {
+        refill();
+        return (uint32_t)(win >> 32);
     }
     __device__ __forceinline__ uint32_t read(uint32_t n)           // n in [0, 32]
     {
-        const uint32_t v = n ? peek32() >> (32u - n) : 0u;
+        refill();
+        const uint32_t v = n ? (uint32_t)(win >> (64u - n)) : 0u;
+        win <<= n;
         pos += n;
         return v;
     }
     __device__ __forceinline__ int32_t read_signed(uint32_t n)     // sign bit first, two's complement
     {
-        if (n == 0)
-            return 0;
-        const int32_t v = (int32_t)peek32() >> (32u - n);
+        refill();
+        const int32_t v = n ? (int32_t)((int64_t)win >> (64u - n)) : 0;
+        win <<= n;
         pos += n;
         return v;
     }
@@ -222,7 +250,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             __syncthreads();
         UReader rd;
         rd.w = s_stage;
-        rd.pos = bit0 + 32u;
+        rd.seek(bit0 + 32u);
         const uint64_t frame_end = cur + fsize;
         uint32_t err = 0;
         bool dropped = false;
@@ -230,14 +258,14 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         //      valid one was walked through by the index because its stream parameters differ: the reference drops
         //      it, restart header and all (src/mlp.c:449-460)
         if (f == 0) {
-            rd.pos += 28u * 8u;
+            rd.seek(rd.pos + 28u * 8u);
         } else if (rd.peek32() == 0xF8726FBBu && fsize >= 32u && sr.ndrop != 0) {
             const uint32_t save = rd.pos;
-            rd.pos = bit0 + 20u * 8u;
+            rd.seek(bit0 + 20u * 8u);
             const uint32_t count = rd.read(4);
             if (count == 1u || count == 2u)
                 dropped = true;
-            rd.pos = save;
+            rd.seek(save);
         }
         uint32_t frame_rows = 0;
         if (!dropped) {
@@ -265,7 +293,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                 err = ST_EOF;
             } else {
                 const uint32_t ss_end_bit = data0_bit + 8u * (check0 ? my_end - 2u : my_end);
-                rd.pos = data0_bit + 8u * my_start;
+                rd.seek(data0_bit + 8u * my_start);
                 uint32_t blocks_in_frame = 0;
                 bool last_block = false;
                 // ======================================================== blocks (src/mlp.c:714-807)
@@ -622,53 +650,34 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     // account); one dword more whenever 32 or less are left, so a code's 9 bits are always there (the
                     // LSBs behind it are not looked at here).  The dword after that is already on its way from LDS:
                     // asked for at the last refill, taken (readfirstlane) at this one -- no wait on the chain.
-                    // (`navail` is not kept: the window ends at bit 32 * widx, so 32 or less are left once
-                    //  pos >= thr = 32 * widx - 32 -- one compare on the position the chain carries anyway)
-                    uint32_t pos = rd.pos;
-                    uint32_t widx = (pos >> 5) + 2u;
-                    uint64_t win;
-                    {
-                        const uint32_t d0 = rfl(s_stage[widx - 2u]), d1 = rfl(s_stage[widx - 1u]);
-                        win = (((uint64_t)d0 << 32) | d1) << (pos & 31u);
-                    }
-                    uint32_t thr = 32u * widx - 32u;
-                    const uint32_t *pnext = s_stage + widx;
-                    uint32_t pend = *pnext;                 // (a vector register: the load is not waited for here)
-                    auto refill = [&]() {
-                        if (pos >= thr) {
-                            win |= (uint64_t)rfl(pend) << (pos - thr);      // 32 - (bits left) = pos - thr
-                            thr += 32u;
-                            pnext++;
-                            pend = *pnext;
-                        }
-                    };
+                    // (the reader's own window: rd.win / rd.pos / rd.thr, see UReader)
                     uint32_t bad_code = 0;
                     for (uint32_t r0 = 0; r0 < block_size; r0 += 8) {
                         const uint32_t nr = block_size - r0 < 8u ? block_size - r0 : 8u;
                         uint32_t v_sym = 0;             // lane (frame * 8 + slot): bit position of that symbol; slot 7: the row's start
                         auto scan_row = [&](auto R) {
                             constexpr int r = decltype(R)::value;
-                            coop_writelane<r * 8 + 7>(v_sym, pos);
+                            coop_writelane<r * 8 + 7>(v_sym, rd.pos);
                             // the row's bypassed LSBs (at most one per matrix) sit in front of its symbols
-                            refill();
-                            pos += nbyp;
-                            win <<= nbyp;
+                            rd.refill();
+                            rd.pos += nbyp;
+                            rd.win <<= nbyp;
                             auto sym = [&](auto K) {
                                 constexpr int k = decltype(K)::value;
-                                refill();
+                                rd.refill();
                                 // the three books share one structure (mlp_tables.h): "1" + (3 - book) bits, or z' zeros
                                 // and a one in the seven bits behind the first two (length z' + 3, capped: an invalid
                                 // code is found by the lane that decodes the symbol)
-                                const uint32_t top = (uint32_t)(win >> 32);
+                                const uint32_t top = (uint32_t)(rd.win >> 32);
                                 const uint32_t z = (uint32_t)__builtin_clz((int)(((top << 2) & 0xFE000000u) | 0x01000000u));
                                 const uint32_t len_l = ((z > 6u ? 6u : z) + 3u) & s_cbm[k];
                                 uint32_t esc = top >> 31;
                                 asm volatile("" : "+s"(esc));          // (a scalar compare and select, not a 64-bit vector compare)
                                 const uint32_t len = esc ? s_lena[k] : len_l;
-                                coop_writelane<r * 8 + k>(v_sym, pos);
+                                coop_writelane<r * 8 + k>(v_sym, rd.pos);
                                 const uint32_t tot = len + s_lb[k];
-                                pos += tot;
-                                win <<= tot;
+                                rd.pos += tot;
+                                rd.win <<= tot;
                             };
                             sym(std::integral_constant<int, 0>{});
                             if (nslots > 1u) {
@@ -728,7 +737,6 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         err = ST_HUFFMAN;
                         break;
                     }
-                    rd.pos = pos;
                     // ---- FILTER: lane k runs channel min_ch + k through the block's rows (src/mlp.c:1243-1306)
                     //      (parse pass: the residuals stay as they are, k_chain_filter runs the recursion)
                     if (!PARSE) {

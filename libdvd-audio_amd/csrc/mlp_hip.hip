@@ -444,8 +444,8 @@ __global__ __launch_bounds__(1024) void k_check_ranges(const uint64_t *__restric
     const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     auto end_of = [&](uint32_t i) {
         const uint64_t o = off[i], l = len[i];
-        return (o <= total_bytes && l <= total_bytes - o) ? o + l : total_bytes;     // (a range that leaves the buffer
-    };                                                                               //  is bad itself; it blocks all of it)
+        return (o <= total_bytes && l <= total_bytes - o && (o & 15u) == 0) ? o + l : 0;   // (a range that is refused
+    };                                                                                     //  stands in nobody's way)
     unsigned long long m = 0;
     for (uint32_t i = lo; i < hi; i++) {
         const unsigned long long e = end_of(i);
@@ -464,7 +464,9 @@ __global__ __launch_bounds__(1024) void k_check_ranges(const uint64_t *__restric
     for (uint32_t i = lo; i < hi; i++) {
         const uint64_t o = off[i], l = len[i];
         const bool ok = (o & 15u) == 0 && o <= total_bytes && l <= total_bytes - o && o >= run;
-        const uint64_t so = o > run ? o : run;
+        // (a refused stream becomes an empty range where the ascending order wants it: the streams behind it keep
+        //  theirs -- ONE bad entry does not cost the rest of the batch)
+        const uint64_t so = ok ? o : run;
         soff[i] = so < total_bytes ? so : total_bytes;
         slen[i] = ok ? l : 0;
         if (!ok)

@@ -27,7 +27,12 @@ struct SegRec {
     uint32_t prev;      // previous live segment of the same stream (0xFFFFFFFF: none), filled by k_link
 };
 constexpr uint32_t SYNC_PARAMS = 0x00FFFFFFu;   // the five stream parameters of a packed sync (dvda_params_equal)
-constexpr uint32_t MAX_DROP = 4;                // mismatching major syncs one segment walks through
+// mismatching major syncs ONE segment walks through in a row.  The reference (src/mlp.c:449-460) drops any number;
+// the bound is there because every candidate walks on its own -- a stream whose major syncs all differ from one
+// another would cost n^2 / 2 steps -- and k_mark_dead looks this far back for the walk that lands on a candidate.
+// A run longer than this (65 consecutive access units that ALL carry a major sync with parameters other than the
+// stream's: nothing an encoder writes) is reported as DVDA_ST_SYNC_CHANGE | DVDA_ST_IRREGULAR, not decoded.
+constexpr uint32_t MAX_DROP = 64;
 
 struct StreamRec {
     uint32_t first_seg;   // index of the stream's first segment (0xFFFFFFFF = none)

@@ -24,8 +24,8 @@ def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checks
     xor-free additive checksum} and the slowest rank's time.  `dist` is torch.distributed (already
     initialised) or None for a single process."""
     import torch
-    tot = torch.tensor([float(pcm_frames), float(samples), float(comp_bytes), float(errors)],
-                       dtype=torch.float64, device=device)
+    # (counters are integers and are summed as integers: float64 is exact only to 2^53)
+    tot = torch.tensor([int(pcm_frames), int(samples), int(comp_bytes), int(errors)], dtype=torch.int64, device=device)
     chk = torch.tensor([int(checksum) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
     tmax = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:

@@ -559,10 +559,18 @@ def test_changed_major_syncs_are_dropped_like_the_reference(pkg, oracle, S):
         assert inf.status & ~hip.ST_BENIGN == 0, hex(inf.status)
         assert bool(inf.status & hip.ST["SYNC_CHANGE"]) == bool(drops)
         assert inf.pcm_frames == r and np.array_equal(got, want)
-    # five in a row are more than one segment walks through: reported, never passed as clean
-    five, _ = stream_tools.change_sync_params(clean, (2, 3, 4, 5, 6), g1_bps=0)
-    _, inf5 = hip.decode_streams([five])
-    assert inf5[0].status & hip.ST["IRREGULAR"]
+    # ten in a row (round 2 stopped at five): still what the reference does -- ten units dropped, the rest exact
+    ten, _ = stream_tools.change_sync_params(clean, tuple(range(1, 11)), g1_bps=0)
+    pcm10, inf10 = _both(hip, [ten, clean])
+    want, r, st = oracle.decode(ten, 6, frames)
+    assert r == frames - 80 * 10 and st == 2
+    assert inf10[0].status & ~hip.ST_BENIGN == 0 and inf10[0].pcm_frames == r and np.array_equal(pcm10[0], want)
+    # past the walk's bound (64 in a row: csrc/mlp_index.h MAX_DROP): reported, never passed as clean
+    cfg_l = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=80, restart_interval=1)
+    long_clean, _ = syn.stream(cfg_l, 616 + S)
+    many, _ = stream_tools.change_sync_params(long_clean, tuple(range(2, 72)), g1_bps=0)
+    _, infm = hip.decode_streams([many])
+    assert infm[0].status & hip.ST["IRREGULAR"]
     # streaming tier, PES-payload sized packets
     dec = hip.MLPDecoder(2, 2, 1, 1, 12)
     samples = [[] for _ in range(6)]
@@ -755,6 +763,10 @@ def test_stream_ranges_are_checked_not_trusted(pkg, oracle):
     assert infos[0].status == 0 and infos[1].status == 0 and infos[2].status & bad
     infos, host = run([offs[0], offs[1] + 2, offs[2]], [lens[0], lens[1] - 2, lens[2]])
     assert infos[0].status == 0 and infos[1].status & bad and infos[2].status == 0 and np.array_equal(host[2], want)
+    # ONE bad entry does not cost the streams behind it: a range in the middle that leaves the buffer
+    infos, host = run(offs, [lens[0], lens[1] + (1 << 40), lens[2]])
+    assert infos[0].status == 0 and infos[1].status & bad and infos[1].pcm_frames == 0
+    assert infos[2].status == 0 and np.array_equal(host[2], want) and np.array_equal(host[0], want)
     # the same with streams of different shapes in the batch (the lanes are then dealt by stream shape, and the
     # refused stream's major syncs must take no lane): 6-ch title, 2-ch title, the 2-ch title's bytes once more
     cfg2 = syn.make_cfg(assignment=1, rate_code=0, n_aus=40)
