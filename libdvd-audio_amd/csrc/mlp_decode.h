@@ -2166,6 +2166,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 //   collect != 0: streams that the sequential pass has to decode (ST_TIMING / ST_SEQ on any segment) are
 //                 appended to seq_list and counted in summary->seq_streams (reset by the host before)
 //   last != 0   : the last pass is through: a segment still waiting for one is reported, never passed as clean
+constexpr uint32_t FIN_GROUP = 16;
 __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg,
                                                   const uint32_t *__restrict__ seg_fbase,
                                                   const uint32_t *__restrict__ seg_status,
@@ -2174,8 +2175,11 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
                                                   DecodeSummary *__restrict__ summary,
                                                   uint32_t *__restrict__ seq_list, uint32_t collect, uint32_t last)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0 && collect) {
+    // FIN_GROUP lanes per stream share the walk over its segments (a title of the bench batch has 64: one lane per
+    // stream walked them one dependent load after the other, 56 us for 4 096 streams)
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = t / FIN_GROUP, j = t % FIN_GROUP;
+    if (t == 0 && collect) {
         // the fast pass's partial sums into the summary proper (and out of the way of the next fold)
         unsigned long long rows = 0;
         uint32_t segs = 0, mx = 0;
@@ -2192,7 +2196,7 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
         summary->chain_max_rows = summary->chain_max_rows > mx ? summary->chain_max_rows : mx;
     }
     if (s >= n_streams)
-        return;
+        return;                                     // (whole groups leave: the shuffles below stay inside a group)
     StreamRec r = streams[s];
     if (r.first_seg == 0xFFFFFFFFu) {
         r.status |= 1u << 0;
@@ -2205,17 +2209,30 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
         // decode-time bits are rebuilt from the segments every time (a later pass clears what it
         // repairs); only what the index found stays
         uint32_t st = r.status & ~(0x3FCu | ST_DEFERRED | ST_OVERFLOW | ST_GENERAL);
-        bool waits = false;
-        for (uint32_t i = r.first_seg; i < r.first_seg + r.n_seg; i++) {
+        uint32_t waits = 0;
+        for (uint32_t i = r.first_seg + j; i < r.first_seg + r.n_seg; i += FIN_GROUP) {
             const uint32_t ss = seg_status[i];
             rows += seg_rows[i];
             st |= ss | (seg[i].flags & ~SEG_DEAD);      // (what the index found on the segment stays)
             if ((ss & ST_DEFERRED) && !(ss & ST_GENERAL) && !(ss & ~ST_INFO)) {
-                waits = true;
+                waits = 1;
                 if (last)
                     st |= ST_CAPACITY;  // deferred and never decoded (cannot happen; never silently)
             }
         }
+        uint32_t rlo = (uint32_t)rows, rhi = (uint32_t)(rows >> 32);
+#pragma unroll
+        for (int o = FIN_GROUP / 2; o > 0; o >>= 1) {
+            st |= __shfl_xor(st, o, FIN_GROUP);
+            waits |= __shfl_xor(waits, o, FIN_GROUP);
+            const uint32_t l2 = __shfl_xor(rlo, o, FIN_GROUP), h2 = __shfl_xor(rhi, o, FIN_GROUP);
+            const uint32_t sum = rlo + l2;
+            rhi += h2 + (sum < rlo ? 1u : 0u);
+            rlo = sum;
+        }
+        if (j != 0)
+            return;
+        rows = ((uint64_t)rhi << 32) | rlo;
         if (collect && waits)
             atomicAdd(&summary->waiting, 1u);
         r.frames = seg_fbase[r.first_seg + r.n_seg] - seg_fbase[r.first_seg];
@@ -2224,7 +2241,8 @@ __global__ __launch_bounds__(256) void k_finalize(const SegRec *__restrict__ seg
         if (collect && (st & (ST_TIMING | ST_SEQ)))
             seq_list[atomicAdd(&summary->seq_streams, 1u)] = s;
     }
-    streams[s] = r;
+    if (j == 0)
+        streams[s] = r;
 }
 
 // every (book, 9-bit peek) through the device decode (dvda_mlp_hip_selftest_huff)

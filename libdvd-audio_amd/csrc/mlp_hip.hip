@@ -759,7 +759,7 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     }
     HIP_TRY(hipEventRecord(c->ev[2 * slot + 1], st));
     c->ev_count++;
-    const dim3 fgrid((c->n_streams + 255) / 256);
+    const dim3 fgrid((unsigned)(((uint64_t)c->n_streams * FIN_GROUP + 255) / 256));
     hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                        c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
     HIP_TRY(hipGetLastError());
