@@ -74,6 +74,11 @@ unsigned dvda_read(DVDA_Track_Reader *reader, unsigned pcm_frames, int buffer[])
 /* ---- additions of this library (not in the reference API) */
 /* HIP device used by track readers opened afterwards (default 0) */
 void dvda_hip_set_device(int device);
+/* on != 0: MLP track readers opened afterwards are decoded straight into the WAV payload dvda2wav would write
+ * (the output stage -- dvda_read's interleave + write_signed at the stream's bit depth -- runs inside the decode
+ * kernels, DVDA_PCM_WAV24 / DVDA_PCM_WAV16): no int32 PCM buffer, no packing pass.  Such a reader serves
+ * dvda_hip_reader_wav_payload() only; dvda_read() on it returns 0.  Default off (the reference API's int samples). */
+void dvda_hip_set_wav_output(int on);
 /* status word of the decode behind a reader: DVDA_ST_* bits of dvda_mlp_hip.h (0 = clean) */
 unsigned dvda_hip_reader_status(const DVDA_Track_Reader *reader);
 /* PCM frames the reader holds in total */

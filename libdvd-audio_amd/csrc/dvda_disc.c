@@ -42,7 +42,9 @@
 
 static int g_device = 0;
 
+static int g_wav_output = 0;
 void dvda_hip_set_device(int device) { g_device = device; }
+void dvda_hip_set_wav_output(int on) { g_wav_output = on != 0; }
 
 /* ------------------------------------------------------------------ records */
 struct ifo_title {
@@ -92,6 +94,9 @@ struct DVDA_Track_Reader_s {
     int32_t *pcm;              /* host copy of d_pcm, made by the first dvda_read() */
     int32_t *d_pcm;            /* device copy, kept for the GPU WAV packer */
     uint8_t *wav;              /* host payload produced by dvda_hip_reader_wav_payload */
+    uint8_t *d_wav;            /* MLP reader opened under dvda_hip_set_wav_output(1): the decode kernels wrote the WAV
+                                  payload themselves (DVDA_PCM_WAV24 / WAV16); there is no int32 PCM for dvda_read() */
+    uint64_t wav_bytes;
 };
 
 /* ------------------------------------------------------------------ files */
@@ -503,6 +508,7 @@ static void reader_free(DVDA_Track_Reader *r)
     if (!r)
         return;
     free(r->pcm);
+    (void)hipFree(r->d_wav);
     free(r->wav);
     if (r->d_pcm)
         (void)hipFree(r->d_pcm);
@@ -631,9 +637,19 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         stride = (stride + 3) & ~(uint64_t)3;
         if (stride == 0)
             stride = 4;
+        /* dvda_hip_set_wav_output(1): the decode writes the payload dvda2wav would write -- interleaved, little-endian,
+         * write_signed at the stream's own bit depth -- and nothing else: no int32 PCM, no separate packing pass
+         * (SURVEY 8(f-3) fused into the decode, DVDA_PCM_WAV24 / WAV16) */
+        const unsigned wbits = g_wav_output ? bits_of(info.group0_bps) : 0;
+        const int direct = wbits == 16 || wbits == 24;
+        if (direct && dvda_mlp_hip_set_pcm_layout(ctx, wbits == 24 ? DVDA_PCM_WAV24 : DVDA_PCM_WAV16) != DVDA_HIP_OK)
+            goto fail;
         for (int attempt = 0; attempt < 2; attempt++) {
             meta[3] = stride;
-            if (!dev_alloc((void **)&d_pcm, stride * info.channels * sizeof(int32_t)) ||
+            /* (as packed bytes the track takes 3/4 or 1/2 of the int32 words; the buffer is sized in int32 words
+             *  either way: the decode's offsets are in those units) */
+            const uint64_t words = direct ? (stride * info.channels * (wbits / 8) + 3) / 4 + 4 : stride * info.channels;
+            if (!dev_alloc((void **)&d_pcm, words * sizeof(int32_t)) ||
                 hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
                 goto fail;
             if (dvda_mlp_hip_decode(ctx, d_pcm, d_meta + 2, d_meta + 3, NULL) != DVDA_HIP_OK ||
@@ -666,7 +682,12 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         r->interleaved = 1;            /* decoded frame-major: dvda_read() copies frames straight out */
         if (r->channels == 0 || r->channels != info.channels)
             goto fail;
-        r->d_pcm = d_pcm;              /* the host copy is made by the first dvda_read() */
+        if (direct) {
+            r->d_wav = (uint8_t *)d_pcm;
+            r->wav_bytes = r->frames * r->channels * (wbits / 8);
+        } else {
+            r->d_pcm = d_pcm;          /* the host copy is made by the first dvda_read() */
+        }
         d_pcm = NULL;
     }
     goto done;
@@ -848,6 +869,8 @@ unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *r)
 
 unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
 {
+    if (r->d_wav)
+        return 0;               /* opened under dvda_hip_set_wav_output(1): the track exists as WAV payload only */
     if (!r->pcm) {
         /* PCM of the whole track, fetched once */
         const size_t bytes = r->stride * r->channels * sizeof(int32_t);
@@ -882,6 +905,17 @@ unsigned long long dvda_hip_reader_wav_payload(DVDA_Track_Reader *r, const unsig
     *payload = NULL;
     if ((bits != 16 && bits != 24) || left == 0)
         return 0;
+    if (r->d_wav) {
+        /* the decode wrote the payload: one copy to the host */
+        free(r->wav);
+        r->wav = malloc(r->wav_bytes ? r->wav_bytes : 1);
+        if (!r->wav || r->served != 0 ||
+            hipMemcpy(r->wav, r->d_wav, r->wav_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            return 0;
+        r->served = r->frames;
+        *payload = r->wav;
+        return r->wav_bytes;
+    }
     free(r->wav);
     r->wav = malloc(bytes);
     if (!r->wav || !dev_alloc((void **)&d_out, bytes))

@@ -21,7 +21,7 @@ EXPORTS = [
     "dvda_track_pts_length", "dvda_track_first_sector", "dvda_track_last_sector",
     "dvda_open_track_reader", "dvda_close_track_reader", "dvda_codec", "dvda_bits_per_sample",
     "dvda_sample_rate", "dvda_channel_count", "dvda_riff_wave_channel_mask", "dvda_read",
-    "dvda_hip_set_device", "dvda_hip_reader_status", "dvda_hip_reader_total_frames",
+    "dvda_hip_set_device", "dvda_hip_set_wav_output", "dvda_hip_reader_status", "dvda_hip_reader_total_frames",
     "dvda_hip_reader_wav_payload",
 ]
 
@@ -61,6 +61,8 @@ def lib():
         L.dvda_read.argtypes = [vp, u, ctypes.POINTER(ctypes.c_int)]
         L.dvda_hip_set_device.restype = None
         L.dvda_hip_set_device.argtypes = [ctypes.c_int]
+        L.dvda_hip_set_wav_output.restype = None
+        L.dvda_hip_set_wav_output.argtypes = [ctypes.c_int]
         L.dvda_hip_reader_total_frames.restype = ctypes.c_ulonglong
         L.dvda_hip_reader_total_frames.argtypes = [vp]
         L.dvda_hip_reader_wav_payload.restype = ctypes.c_ulonglong
@@ -95,13 +97,15 @@ def layout(audio_ts, titleset=1):
     return out
 
 
-def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0):
+def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0, fused=False):
     """Decodes one track on the GPU.  Returns a dict: codec ("PCM"/"MLP"), bits, rate, channels,
     mask, status, and pcm = int32 [frames, channels] (interleaved, RIFF-WAVE order) read with
     dvda_read() in `chunk`-frame calls -- or, with wav=True, payload = the WAV data bytes packed
-    on the GPU."""
+    on the GPU; fused=True (with wav=True) opens the reader under dvda_hip_set_wav_output(1): MLP tracks are decoded
+    straight into that payload, no int32 PCM and no packing pass."""
     L = lib()
     L.dvda_hip_set_device(device)
+    L.dvda_hip_set_wav_output(1 if (fused and wav) else 0)
     d = L.dvda_open(audio_ts.encode(), None)
     if not d:
         raise IOError("not an AUDIO_TS directory: %s" % audio_ts)

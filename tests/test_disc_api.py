@@ -115,6 +115,27 @@ def test_pcm_tracks_and_gpu_wav_payload(pkg, oracle):
         assert w["payload"] == oracle.wav_pack(a["pcm"].T, 24)
 
 
+@pytest.mark.gpu
+def test_mlp_tracks_decoded_straight_into_the_wav_payload(pkg, oracle):
+    """dvda_hip_set_wav_output(1): an MLP track reader holds the WAV payload the decode kernels wrote themselves
+    (DVDA_PCM_WAV24) -- no int32 PCM, no packing pass.  Byte for byte what the int32 decode + GPU packer give, and what
+    the oracle's packing of the oracle's PCM gives; dvda_read() on such a reader returns nothing."""
+    syn, disc = pkg.synth, pkg.disc
+    with tempfile.TemporaryDirectory() as tmp:
+        titles, streams = _titles(pkg, seeds=(31, 32))
+        ats = disc.write_disc_titles(tmp, titles)
+        for ti, (tracks, (b, f, asg)) in enumerate(zip(titles, streams), 1):
+            nch = syn.channels(asg)
+            for ki in range(1, len(tracks) + 1):
+                plain = pkg.discdec.read_track(ats, 1, ti, ki)
+                packed = pkg.discdec.read_track(ats, 1, ti, ki, wav=True)
+                fused = pkg.discdec.read_track(ats, 1, ti, ki, wav=True, fused=True)
+                assert fused["status"] & ~pkg.hipdec.ST_BENIGN == 0 and fused["frames"] == plain["frames"]
+                assert fused["payload"] == packed["payload"] == oracle.wav_pack(plain["pcm"].T, plain["bits"])
+                assert len(fused["payload"]) == plain["frames"] * nch * plain["bits"] // 8
+    pkg.discdec.lib().dvda_hip_set_wav_output(0)
+
+
 REF_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_ref")
 NATIVE_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_native")
 

@@ -127,6 +127,9 @@ int main(int argc, char *argv[])
         usage(argv[0]);
         return 0;
     }
+    /* this tool only ever writes WAV files: MLP tracks are decoded straight into the payload (DVDA_NO_FUSED_WAV=1
+       in the environment brings the int32 decode + packing pass back, for comparison) */
+    dvda_hip_set_wav_output(getenv("DVDA_NO_FUSED_WAV") == NULL);
     DVDA *dvda = dvda_open(audio_ts, cdrom);
     DVDA_Titleset *ts = dvda ? dvda_open_titleset(dvda, titleset_num) : NULL;
     if (!ts) {
