@@ -800,7 +800,11 @@ def plumbing_rank(args, rank, world):
                           "config": {"workload": args.workload, "titles_all_ranks": summ["checksum"],
                                      "samples_all_ranks": summ["samples"],
                                      "compressed_bytes_all_ranks": summ["compressed_bytes"]},
-                          "seconds_max_over_ranks": summ["seconds"]}))
+                          "seconds_max_over_ranks": summ["seconds"],
+                          "ranks": {"seconds_min": summ["seconds_min"], "compressed_bytes_max": summ["bytes_max"],
+                                    "compressed_bytes_min": summ["bytes_min"],
+                                    "load_imbalance": round(summ["bytes_max"] * world / max(summ["compressed_bytes"], 1), 4),
+                                    "bit_exact_on_every_rank": summ["all_verified"]}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -952,7 +956,8 @@ def main():
     #      few words over xGMI; nothing on the data path is exchanged)
     checksum = int(b.d_pcm.to(torch.int64).sum().item())
     summ = pkg.shard.reduce_summary(dist if world > 1 else None, dev if backend == "nccl" else torch.device("cpu"),
-                                    b.rows_total, b.samples, b.comp_bytes, 0, checksum, elapsed)
+                                    b.rows_total, b.samples, b.comp_bytes, 0, checksum, elapsed,
+                                    verified=bool(bit_exact) or checked == 0)
     elapsed_max = summ["seconds"]
     job_samples = float(summ["samples"])
 
@@ -1008,6 +1013,17 @@ def main():
             },
             "roofline": roofline_record(b, kernel_ms, launches, prof["hbm_bytes_per_launch"] if prof else None, issue),
         }
+        if world > 1:
+            # the shard as it ran: the slowest and the fastest rank's step, the largest rank's share of the compressed
+            # bytes against the mean (greedy longest-processing-time deal, shard.py), every rank's own sample check
+            mean_bytes = summ["compressed_bytes"] / world
+            out["ranks"] = {"ms_per_step_max": round(summ["seconds"] / args.steps * 1e3, 4),
+                            "ms_per_step_min": round(summ["seconds_min"] / args.steps * 1e3, 4),
+                            "compressed_bytes_max": summ["bytes_max"], "compressed_bytes_min": summ["bytes_min"],
+                            "load_imbalance": round(summ["bytes_max"] / mean_bytes, 4) if mean_bytes else None,
+                            "bit_exact_on_every_rank": summ["all_verified"],
+                            "titles_checked_per_rank": checked}
+            out["config"]["bit_exact"] = bool(bit_exact) and summ["all_verified"]
         if serial:
             out["serial_step"] = serial
         if latency:

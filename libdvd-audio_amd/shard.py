@@ -19,19 +19,25 @@ def shard_titles(sizes, world, rank):
     return np.flatnonzero(owner == rank)
 
 
-def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checksum, seconds):
+def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checksum, seconds, verified=True):
     """The path's one collective: all ranks learn {sum frames, sum samples, sum bytes, sum errors,
-    xor-free additive checksum} and the slowest rank's time.  `dist` is torch.distributed (already
+    xor-free additive checksum}, the slowest and the fastest rank's time, the largest and the smallest rank's share
+    of the compressed bytes (the load balance of the shard) and whether EVERY rank's bit-exact check passed.  `dist` is torch.distributed (already
     initialised) or None for a single process."""
     import torch
     # (counters are integers and are summed as integers: float64 is exact only to 2^53)
     tot = torch.tensor([int(pcm_frames), int(samples), int(comp_bytes), int(errors)], dtype=torch.int64, device=device)
     chk = torch.tensor([int(checksum) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
-    tmax = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    tmax = torch.tensor([float(seconds), float(comp_bytes)], dtype=torch.float64, device=device)
+    # (the fastest rank's time, the smallest share, and "every rank's sample check passed" travel as minima)
+    tmin = torch.tensor([float(seconds), float(comp_bytes), 1.0 if verified else 0.0], dtype=torch.float64, device=device)
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     return {"pcm_frames": int(tot[0].item()), "samples": int(tot[1].item()),
             "compressed_bytes": int(tot[2].item()), "errors": int(tot[3].item()),
-            "checksum": int(chk[0].item()), "seconds": float(tmax[0].item())}
+            "checksum": int(chk[0].item()), "seconds": float(tmax[0].item()),
+            "seconds_min": float(tmin[0].item()), "bytes_max": int(tmax[1].item()), "bytes_min": int(tmin[1].item()),
+            "all_verified": bool(tmin[2].item() > 0.5)}

@@ -120,6 +120,10 @@ def test_bench_launcher_starts_two_ranks_over_gloo():
     assert rec["config"]["titles_all_ranks"] == 24               # weak: every rank brings its own 12 titles
     assert rec["config"]["samples_all_ranks"] == 24 * 8 * 80 * 6
     assert abs(rec["seconds_max_over_ranks"] - 0.002) < 1e-9     # max over ranks, not rank 0's
+    # ... and what the N > 1 line says about the shard itself: fastest rank, balance, every rank's own check
+    assert abs(rec["ranks"]["seconds_min"] - 0.001) < 1e-9 and rec["ranks"]["bit_exact_on_every_rank"] is True
+    assert rec["ranks"]["compressed_bytes_max"] >= rec["ranks"]["compressed_bytes_min"] > 0
+    assert 1.0 <= rec["ranks"]["load_imbalance"] < 1.2
 
 
 def test_bench_c4_shards_the_1024_units_strongly():
