@@ -37,6 +37,8 @@ namespace mlp {
 #define DVDA_CHK_GROUP 8
 #endif
 constexpr int CHK_GROUP = DVDA_CHK_GROUP;       // lanes per segment
+constexpr int CHK_RUN = 64 / CHK_GROUP;         // consecutive chunks' partial sums a lane joins per pass
+static_assert(CHK_GROUP == 2 || CHK_GROUP == 4 || CHK_GROUP == 8, "2, 4 or 8 lanes per segment (measured: 181 / 165 / 173 us)");
 constexpr int CHK_THREADS = 256;
 
 // low n bytes of a dword kept (n <= 0: none, n >= 4: all)
@@ -45,10 +47,40 @@ __device__ __forceinline__ uint32_t chk_mask_lt(int32_t n)
     return n <= 0 ? 0u : n >= 4 ? 0xFFFFFFFFu : (1u << (8 * n)) - 1u;
 }
 
-__device__ __forceinline__ uint32_t chk_be16(const uint8_t *b, uint64_t p)
+__device__ __forceinline__ uint32_t chk_swap16(uint32_t h) { return ((h & 0xFFu) << 8) | ((h >> 8) & 0xFFu); }
+
+// The header bytes k_au_check looks at, of the access unit at even offset `cur`: big-endian halfwords at cur + 0, 4, 6,
+// 8, 10 and the byte at cur + 20 -- from TWO 16-byte loads at the dword in front of cur (a lane issues six loads per
+// access unit now, not fourteen: the kernel is bound by the number of small loads, each of which the address unit
+// walks lane by lane)
+struct ChkHdr {
+    uint32_t h0, h4, h6, h8, h10, b20;
+};
+__device__ __forceinline__ ChkHdr chk_header(const uint8_t *b, uint64_t cur)
 {
-    const uint32_t h = *reinterpret_cast<const uint16_t *>(b + p);      // p is even: frames start at even offsets
-    return ((h & 0xFFu) << 8) | (h >> 8);
+    const uint4 *p = reinterpret_cast<const uint4 *>(b + (cur & ~(uint64_t)3));
+    const uint4 x = p[0], y = p[1];
+    const uint32_t sh = (uint32_t)(cur & 3u) * 8u;          // 0 or 16
+    const uint32_t a0 = __builtin_amdgcn_alignbit(x.y, x.x, sh), a1 = __builtin_amdgcn_alignbit(x.z, x.y, sh),
+                   a2 = __builtin_amdgcn_alignbit(x.w, x.z, sh);
+    ChkHdr r;
+    r.h0 = chk_swap16(a0);
+    r.h4 = chk_swap16(a1);
+    r.h6 = chk_swap16(a1 >> 16);
+    r.h8 = chk_swap16(a2);
+    r.h10 = chk_swap16(a2 >> 16);
+    r.b20 = (y.y >> sh) & 0xFFu;                            // byte cur + 20 = byte 4 (+ cur & 3) of the second block
+    return r;
+}
+// big-endian halfwords at cur + 32, 34, 36 (the substream info words of a major-sync unit)
+__device__ __forceinline__ void chk_info32(const uint8_t *b, uint64_t cur, uint32_t &i0, uint32_t &i1, uint32_t &i2)
+{
+    const uint4 z = *reinterpret_cast<const uint4 *>(b + ((cur + 32u) & ~(uint64_t)3));
+    const uint32_t sh = (uint32_t)(cur & 3u) * 8u;
+    const uint32_t a0 = __builtin_amdgcn_alignbit(z.y, z.x, sh), a1 = __builtin_amdgcn_alignbit(z.z, z.y, sh);
+    i0 = chk_swap16(a0);
+    i1 = chk_swap16(a0 >> 16);
+    i2 = chk_swap16(a1);
 }
 
 // CRC-8 from state 0 of the bytes [lo, hi) of the 16-byte chunk v (the others count as zero), and the XOR of those
@@ -76,15 +108,15 @@ __global__ __launch_bounds__(CHK_THREADS) void k_au_check(const uint8_t *__restr
                                                            const StreamRec *__restrict__ streams,
                                                            uint32_t *__restrict__ seg_check)
 {
-    __shared__ uint8_t s_slice[16 * 256];
-    __shared__ uint8_t s_log[256];
-    __shared__ uint8_t s_exp[512];
-    for (int i = threadIdx.x; i < 16 * 256; i += CHK_THREADS)
-        s_slice[i] = d_chk.slice[i];
-    for (int i = threadIdx.x; i < 256; i += CHK_THREADS)
-        s_log[i] = d_chk.log[i];
-    for (int i = threadIdx.x; i < 512; i += CHK_THREADS)
-        s_exp[i] = d_chk.exp[i];
+    __shared__ __attribute__((aligned(16))) uint8_t s_slice[16 * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_log[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_exp[512];
+    for (int i = threadIdx.x; i < 16 * 256 / 16; i += CHK_THREADS)
+        reinterpret_cast<uint4 *>(s_slice)[i] = reinterpret_cast<const uint4 *>(d_chk.slice)[i];
+    for (int i = threadIdx.x; i < 256 / 16; i += CHK_THREADS)
+        reinterpret_cast<uint4 *>(s_log)[i] = reinterpret_cast<const uint4 *>(d_chk.log)[i];
+    for (int i = threadIdx.x; i < 512 / 16; i += CHK_THREADS)
+        reinterpret_cast<uint4 *>(s_exp)[i] = reinterpret_cast<const uint4 *>(d_chk.exp)[i];
     __syncthreads();
 
     uint32_t n_seg = *n_seg_ptr;
@@ -109,26 +141,17 @@ __global__ __launch_bounds__(CHK_THREADS) void k_au_check(const uint8_t *__restr
         uint64_t cur = sr.off;
         // header bytes of the unit at `cur`, requested one unit ahead: size field, the place a major sync sits,
         // the substream count behind it
-        uint32_t h0 = chk_be16(bytes, cur), h4 = chk_be16(bytes, cur + 4), h6 = chk_be16(bytes, cur + 6);
-        uint32_t h8 = chk_be16(bytes, cur + 8), h10 = chk_be16(bytes, cur + 10), b20 = bytes[cur + 20];
+        ChkHdr H = chk_header(bytes, cur);
         for (uint32_t f = 0; f < sr.nframes && !(done[0] && done[1]); f++) {
-            const uint32_t fsize = 2u * (h0 & 0xFFFu);
+            const uint32_t fsize = 2u * (H.h0 & 0xFFFu);
             const uint64_t frame_end = cur + fsize;
-            uint32_t i0 = h4, i1 = h6, i2 = h8;                 // substream info words (frames without a major sync)
-            const bool dropped = f != 0 && sr.ndrop != 0 && fsize >= 32u && h4 == 0xF872u && h6 == 0x6FBBu &&
-                                 ((b20 >> 4) == 1u || (b20 >> 4) == 2u);        // src/mlp.c:449-460, as k_decode
-            if (f == 0) {
-                i0 = chk_be16(bytes, cur + 32);
-                i1 = chk_be16(bytes, cur + 34);
-                i2 = chk_be16(bytes, cur + 36);
-            }
+            uint32_t i0 = H.h4, i1 = H.h6, i2 = H.h8;           // substream info words (frames without a major sync)
+            const bool dropped = f != 0 && sr.ndrop != 0 && fsize >= 32u && H.h4 == 0xF872u && H.h6 == 0x6FBBu &&
+                                 ((H.b20 >> 4) == 1u || (H.b20 >> 4) == 2u);    // src/mlp.c:449-460, as k_decode
+            if (f == 0)
+                chk_info32(bytes, cur, i0, i1, i2);
             // the next unit's header leaves now (the buffer is readable 64 bytes past its end)
-            h0 = chk_be16(bytes, frame_end);
-            h4 = chk_be16(bytes, frame_end + 4);
-            h6 = chk_be16(bytes, frame_end + 6);
-            h8 = chk_be16(bytes, frame_end + 8);
-            h10 = chk_be16(bytes, frame_end + 10);
-            b20 = bytes[frame_end + 20];
+            H = chk_header(bytes, frame_end);
             const uint64_t pos = cur + (f == 0 ? 32u : 4u);
             cur = frame_end;
             if (dropped)
@@ -168,39 +191,55 @@ __global__ __launch_bounds__(CHK_THREADS) void k_au_check(const uint8_t *__restr
                 const uint64_t end_m = n_data ? data_hi - 1u : ss_lo;       // the CRC runs over [ss_lo, end_m); the
                                                                             // last data byte is XORed in raw ("final_crc")
                 // the trailer and the last data byte: every lane asks (one address each), together with the rest
-                const uint32_t last = bytes[data_hi - (n_data ? 1u : 0u)];
-                const uint32_t pb = bytes[data_hi], cb = bytes[data_hi + 1];
-                // ---- whole chunks inside [ss_lo, end_m): their partial sums, eight chunks per lane and load
+                const uint64_t tb = data_hi - (n_data ? 1u : 0u);           // last data byte (if any), parity, CRC-8:
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(bytes + (tb & ~(uint64_t)3));     // in two dwords
+                const uint64_t tw = ((uint64_t)tp[1] << 32 | tp[0]) >> (8u * (uint32_t)(tb & 3u));
+                const uint32_t last = (uint32_t)tw & 0xFFu;
+                const uint32_t pb = (uint32_t)(tw >> (n_data ? 8 : 0)) & 0xFFu, cb = (uint32_t)(tw >> (n_data ? 16 : 8)) & 0xFFu;
+                // the ragged ends -- the chunk ss_lo starts inside of (lane 0), the chunk end_m ends inside of (lane 1) --
+                // are the only bytes read again; asked for HERE, with everything else of this unit: one memory round
+                // trip per access unit (behind the partial sums' loop they cost a second one: 173 -> 1xx us)
+                const uint64_t bh = ss_lo & ~(uint64_t)15, bt = end_m & ~(uint64_t)15;
+                const uint4 v_edge = *reinterpret_cast<const uint4 *>(bytes + (j == 1 ? bt : bh));
+                // ---- whole chunks inside [ss_lo, end_m): their partial sums, CHK_RUN chunks per lane and pass
                 const uint64_t ci0 = (ss_lo + 15u) >> 4, ci1 = end_m >> 4;  // chunk indices [ci0, ci1)
                 uint32_t red = 0;                                           // crc | parity << 8 of this lane's share
-                for (uint64_t cg = ci0 & ~(uint64_t)7; cg < ci1; cg += 8u * CHK_GROUP) {
-                    const uint64_t c_first = cg + 8u * j;
+                // (a lane takes CHK_RUN consecutive chunks per pass -- CHK_RUN / 8 loads of 16 bytes that leave together;
+                //  a pass of the group covers 64 chunks, 1 KB: most access units whole)
+                for (uint64_t cg = ci0 & ~(uint64_t)7; cg < ci1; cg += 64u) {
+                    const uint64_t c_first = cg + (uint64_t)CHK_RUN * j;
                     uint32_t acc = 0, par = 0;
                     if (c_first < ci1) {
-                        const uint4 pv = *reinterpret_cast<const uint4 *>(parts + c_first);
-                        const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+                        uint4 pv[CHK_RUN / 8];
 #pragma unroll
-                        for (int t = 0; t < 8; t++) {
-                            const uint32_t pt = (t & 1) ? pw[t >> 1] >> 16 : pw[t >> 1] & 0xFFFFu;
+                        for (int q = 0; q < CHK_RUN / 8; q++)
+                            pv[q] = *reinterpret_cast<const uint4 *>(parts + c_first + 8u * q);
+#pragma unroll
+                        for (int t = 0; t < CHK_RUN; t++) {
+                            const uint4 &v4 = pv[t >> 3];
+                            const uint32_t w = ((t >> 1) & 3) == 0 ? v4.x : ((t >> 1) & 3) == 1 ? v4.y : ((t >> 1) & 3) == 2 ? v4.z : v4.w;
+                            const uint32_t pt = (t & 1) ? w >> 16 : w & 0xFFFFu;
                             const bool in = c_first + (uint32_t)t >= ci0 && c_first + (uint32_t)t < ci1;
-                            acc = (uint32_t)s_slice[15 * 256 + acc] ^ (in ? pt & 0xFFu : 0u);   // Horner: times x^128, plus the chunk
+                            // Horner: times x^128 (one chunk on), plus the chunk.  (Eight independent look-ups in eight
+                            // tables x^(128 k) instead of this chain were measured: slower, 196 vs 175 us -- the
+                            // kernel is bound by the number of small loads it issues, not by this chain.)
+                            acc = (uint32_t)s_slice[15 * 256 + acc] ^ (in ? pt & 0xFFu : 0u);
                             par ^= in ? pt >> 8 : 0u;
                         }
-                        // the lane's last chunk ends d bytes in front of the message's end (d < 0 when the run of
-                        // eight reaches past it: the exponent is taken mod 255; 8160 = 32 * 255 keeps it positive)
-                        const int64_t d = (int64_t)end_m - (int64_t)(16u * (c_first + 8u));
-                        acc = shift(acc, (8u * (uint32_t)(d + 8160)) % 255u);
+                        // the lane's last chunk ends d bytes in front of the message's end (d < 0 when the run
+                        // reaches past it: the exponent is taken mod 255; 16320 = 64 * 255 keeps it positive)
+                        const int64_t d = (int64_t)end_m - (int64_t)(16u * (c_first + (uint64_t)CHK_RUN));
+                        acc = shift(acc, (8u * (uint32_t)(d + 16320)) % 255u);
                     }
                     red ^= acc | (par << 8);
                 }
                 // ---- the ragged ends: the chunk ss_lo starts inside of, the chunk end_m ends inside of
                 {
-                    const uint64_t bh = ss_lo & ~(uint64_t)15, bt = end_m & ~(uint64_t)15;
                     const bool head = (ss_lo & 15u) != 0 && end_m > ss_lo;
                     const bool tail = (end_m & 15u) != 0 && end_m > ss_lo && !(head && bt == bh);
                     if ((j == 0 && head) || (j == 1 && tail)) {
                         const uint64_t B = j == 0 ? bh : bt;
-                        const uint4 v = *reinterpret_cast<const uint4 *>(bytes + B);
+                        const uint4 v = v_edge;
                         const int32_t lo = j == 0 ? (int32_t)(ss_lo - B) : 0;
                         const int32_t hi = end_m - B < 16u ? (int32_t)(end_m - B) : 16;
                         const uint32_t r = chk_masked_chunk(v, lo, hi, s_slice);

@@ -339,7 +339,7 @@ static int ensure_byte_ws(dvda_mlp_hip_ctx *c, uint64_t total_bytes)
         c->d_parts = nullptr;
         c->masks_cap = 0;
         if (ws_malloc((void **)&c->d_masks, chunks) != hipSuccess ||
-            ws_malloc((void **)&c->d_parts, (chunks + 8) * sizeof(uint16_t)) != hipSuccess)
+            ws_malloc((void **)&c->d_parts, (chunks + 72) * sizeof(uint16_t)) != hipSuccess)
             return DVDA_HIP_ENOMEM;
         c->masks_cap = chunks;
     }
