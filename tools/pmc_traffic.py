@@ -56,5 +56,7 @@ if vals.get(("decode_fast", "GRBM_GUI_ACTIVE")) and j["roofline"].get("kernel_ms
     # shader clock during the kernel = busy cycles / its duration (the profiled run's own duration would be
     # better; the bench's kernel_ms of the same build is what is at hand)
     out["gui_active_cycles_per_launch"] = int(mean(("decode_fast", "GRBM_GUI_ACTIVE")))
+    # (the counter is summed over the 8 XCDs)
+    out["shader_clock_ghz"] = round(out["gui_active_cycles_per_launch"] / 8 / (j["roofline"]["kernel_ms"] * 1e-3) / 1e9, 2)
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out))
