@@ -224,7 +224,8 @@ int dvda_mlp_hip_bounds_violations(unsigned long long *out4);
  * is decoded by the wave-cooperative kernel instead (csrc/mlp_coop.h: one wave per (segment, substream), the
  * bit-serial symbol scan in scalar registers, residuals / filter / rematrix at the width they have): BASELINE
  * configs[3]'s 1 024 single access units, a single title, a streaming-tier packet.  64 forces that kernel for any
- * batch; 1 / 2 never use it. */
+ * batch; 1 / 2 never use it; 3 = the lane kernels picked per batch as under 0, never the cooperative kernel (tests
+ * and soaks that want the lane kernels on small batches). */
 int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
 
 /* Per-segment results of the last decode (blocks on `stream`). */

@@ -230,7 +230,17 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
         if (lane == 0)
             atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
+        // (range-checked build: the segment's planes, block records and per-unit records lie inside the workspaces)
+        if (!DVDA_RANGE_OK((uint64_t)pl.x * 8u, 8ull * seg_R, a.caps.res, BT_RES) ||
+            !DVDA_RANGE_OK(8ull * pl.x + 128ull * pl.y, (uint64_t)S * cap, a.caps.brec, BT_BREC) ||
+            !DVDA_RANGE_OK((uint64_t)(pl.x / 40u) * FREC_WORDS, (uint64_t)(sr.nframes - sr.ndrop) * FREC_WORDS, a.caps.frec, BT_FREC)) {
+            if (lane == 0)
+                atomicOr(&a.seg_status[segi], ST_CAPACITY);
+            return;             // (both waves of the workgroup: the test is the same for them)
+        }
     }
+    if (!DVDA_RANGE_OK(segi * 2u, 2, a.caps.lanes, BT_META))       // (the per-lane workspaces: FIR history, channel range)
+        return;
     const uint32_t nthreads = two ? (uint32_t)COOP_THREADS : 64u;
     const uint32_t tid = two ? threadIdx.x : lane;
 

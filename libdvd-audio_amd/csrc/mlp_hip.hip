@@ -727,10 +727,11 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     // index knows) exits at once
     // (64: always the wave-cooperative kernel; 0: the device picks it for small batches -- coop_takes() -- and the
     //  lane kernels for everything else; 1 / 2 force a lane kernel)
-    const bool coop_only = c->lanes_per_seg == 64;
-    const uint32_t force = coop_only ? 0u : c->lanes_per_seg;
+    // (3: the lane kernels, picked per batch as under 0, but never the cooperative kernel)
+    const bool coop_only = c->lanes_per_seg == 64, lanes_only = c->lanes_per_seg == 3;
+    const uint32_t force = (coop_only || lanes_only) ? 0u : c->lanes_per_seg;
     const bool run1 = force != 2 && !coop_only, run2 = force != 1 && !coop_only;
-    a.coop = coop_only ? 64u : force;
+    a.coop = coop_only ? 64u : lanes_only ? 3u : force;
     const uint64_t ms = c->max_segments;
     const unsigned blocks1 = (unsigned)((ms + DEC_THREADS - 1) / DEC_THREADS);            // one lane per segment
     const unsigned blocks2 = (unsigned)((2 * ms + DEC_THREADS - 1) / DEC_THREADS);        // lane pairs
@@ -739,7 +740,7 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     const uint32_t slot = (uint32_t)(c->ev_count % EV_RING);
     HIP_TRY(hipEventRecord(c->ev[2 * slot], st));
     // ---- fast pass (timed: the dominant kernel)
-    if (coop_only || force == 0) {
+    if (coop_only || (force == 0 && !lanes_only)) {
         const unsigned cblocks = (unsigned)(coop_only || ms < COOP_MAX_SEG ? ms : COOP_MAX_SEG);
         hipLaunchKernelGGL(k_coop<false>, dim3(cblocks), dim3(COOP_THREADS), 0, st, a);
     }
@@ -908,7 +909,7 @@ extern "C" int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *c, uint32_t layout)
 
 extern "C" int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *c, uint32_t lanes)
 {
-    if (!c || (lanes > 2 && lanes != 64))
+    if (!c || (lanes > 3 && lanes != 64))
         return DVDA_HIP_EINVAL;
     c->lanes_per_seg = lanes;
     return DVDA_HIP_OK;

@@ -53,7 +53,8 @@ def batches(n, seed0, syn, hip):
                 b = b[:int(rng.randint(8, len(b)))]                                         # cut short
             batch.append(b)
             meta.append((asg, S, f, kind))
-        lanes = [0, 0, 0, 2][int(rng.randint(0, 4))]
+        lanes = [0, 3, 0, 2][int(rng.randint(0, 4))]     # 0: the library's choice (small batches: the cooperative kernel), 3: the
+                                                          # lane kernels picked per batch, 2: the two-wave kernel for everything
         layout = [hip.PCM_PLANAR, hip.PCM_INTERLEAVED][it & 1]
         if batch:
             yield it, batch, meta, lanes, layout
