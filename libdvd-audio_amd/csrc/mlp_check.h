@@ -101,31 +101,12 @@ __device__ __forceinline__ uint32_t chk_masked_chunk(const uint4 &v, int32_t lo,
     return cc | (px << 8);
 }
 
-__global__ __launch_bounds__(CHK_THREADS) void k_au_check(const uint8_t *__restrict__ bytes,
-                                                           const uint16_t *__restrict__ parts,
-                                                           const SegRec *__restrict__ seg,
-                                                           const uint32_t *__restrict__ n_seg_ptr, uint32_t max_seg,
-                                                           const StreamRec *__restrict__ streams,
-                                                           uint32_t *__restrict__ seg_check)
+// the check of segment g by the CHK_GROUP lanes j = 0 .. CHK_GROUP - 1 of one group (all of them call this together)
+__device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uint8_t *__restrict__ bytes,
+                                               const uint16_t *__restrict__ parts, const SegRec *__restrict__ seg,
+                                               const StreamRec *__restrict__ streams, uint32_t *__restrict__ seg_check,
+                                               const uint8_t *s_slice, const uint8_t *s_log, const uint8_t *s_exp)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_slice[16 * 256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_log[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_exp[512];
-    for (int i = threadIdx.x; i < 16 * 256 / 16; i += CHK_THREADS)
-        reinterpret_cast<uint4 *>(s_slice)[i] = reinterpret_cast<const uint4 *>(d_chk.slice)[i];
-    for (int i = threadIdx.x; i < 256 / 16; i += CHK_THREADS)
-        reinterpret_cast<uint4 *>(s_log)[i] = reinterpret_cast<const uint4 *>(d_chk.log)[i];
-    for (int i = threadIdx.x; i < 512 / 16; i += CHK_THREADS)
-        reinterpret_cast<uint4 *>(s_exp)[i] = reinterpret_cast<const uint4 *>(d_chk.exp)[i];
-    __syncthreads();
-
-    uint32_t n_seg = *n_seg_ptr;
-    if (n_seg > max_seg)
-        n_seg = max_seg;
-    const uint32_t g = (blockIdx.x * CHK_THREADS + threadIdx.x) / CHK_GROUP;
-    const uint32_t j = threadIdx.x & (CHK_GROUP - 1);
-    if (g >= n_seg)
-        return;                                 // (whole groups leave: the shuffles below stay inside a group)
     const SegRec sr = seg[g];
     uint32_t bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     bool done[2] = {false, false};              // the decode lane of that substream stops here or earlier anyway
@@ -270,6 +251,34 @@ __global__ __launch_bounds__(CHK_THREADS) void k_au_check(const uint8_t *__restr
         seg_check[2 * (size_t)g] = bad[0];
         seg_check[2 * (size_t)g + 1] = bad[1];
     }
+}
+
+__global__ __launch_bounds__(CHK_THREADS) void k_au_check(const uint8_t *__restrict__ bytes,
+                                                           const uint16_t *__restrict__ parts,
+                                                           const SegRec *__restrict__ seg,
+                                                           const uint32_t *__restrict__ n_seg_ptr, uint32_t max_seg,
+                                                           const StreamRec *__restrict__ streams,
+                                                           uint32_t *__restrict__ seg_check)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_slice[16 * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_log[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_exp[512];
+    for (int i = threadIdx.x; i < 16 * 256 / 16; i += CHK_THREADS)
+        reinterpret_cast<uint4 *>(s_slice)[i] = reinterpret_cast<const uint4 *>(d_chk.slice)[i];
+    for (int i = threadIdx.x; i < 256 / 16; i += CHK_THREADS)
+        reinterpret_cast<uint4 *>(s_log)[i] = reinterpret_cast<const uint4 *>(d_chk.log)[i];
+    for (int i = threadIdx.x; i < 512 / 16; i += CHK_THREADS)
+        reinterpret_cast<uint4 *>(s_exp)[i] = reinterpret_cast<const uint4 *>(d_chk.exp)[i];
+    __syncthreads();
+
+    uint32_t n_seg = *n_seg_ptr;
+    if (n_seg > max_seg)
+        n_seg = max_seg;
+    const uint32_t g = (blockIdx.x * CHK_THREADS + threadIdx.x) / CHK_GROUP;
+    const uint32_t j = threadIdx.x & (CHK_GROUP - 1);
+    if (g >= n_seg)
+        return;                                 // (whole groups leave: the shuffles below stay inside a group)
+    au_check_group(g, j, bytes, parts, seg, streams, seg_check, s_slice, s_log, s_exp);
 }
 
 } // namespace mlp

@@ -115,6 +115,7 @@ struct dvda_mlp_hip_ctx {
     uint32_t n_streams;
     uint64_t tiles;
     bool indexed;
+    bool small_input;          // the last index call's input was at most SMALL_INPUT_BYTES
     bool decoded;              // a decode call has run on the current index (the next one resets the segments first)
     uint32_t lanes_per_seg;
     uint32_t pcm_layout;           // DVDA_PCM_PLANAR / DVDA_PCM_INTERLEAVED
@@ -435,11 +436,11 @@ __global__ void k_reset_segments(uint32_t *seg_status, uint32_t *seg_rows, uint3
 // starts before the end of any stream in front of it, is misaligned or leaves the buffer gets length 0 (nothing of
 // it is decoded) and DVDA_ST_IRREGULAR | DVDA_ST_ENVELOPE, and the offsets the index works with are made ascending (max with the
 // furthest end so far) whatever the caller passed.  One workgroup: a running maximum over the streams in order.
-__global__ __launch_bounds__(1024) void k_check_ranges(const uint64_t *__restrict__ off, const uint64_t *__restrict__ len,
-                                                       uint32_t n, uint64_t total_bytes, uint64_t *__restrict__ soff,
-                                                       uint64_t *__restrict__ slen, StreamRec *__restrict__ streams)
+__device__ __forceinline__ void check_ranges_block(const uint64_t *__restrict__ off, const uint64_t *__restrict__ len,
+                                                   uint32_t n, uint64_t total_bytes, uint64_t *__restrict__ soff,
+                                                   uint64_t *__restrict__ slen, StreamRec *__restrict__ streams,
+                                                   unsigned long long *s_max)
 {
-    __shared__ unsigned long long s_max[1024];
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     auto end_of = [&](uint32_t i) {
@@ -475,6 +476,23 @@ __global__ __launch_bounds__(1024) void k_check_ranges(const uint64_t *__restric
         run = e > run ? e : run;
     }
 }
+
+__global__ __launch_bounds__(1024) void k_check_ranges(const uint64_t *__restrict__ off, const uint64_t *__restrict__ len,
+                                                       uint32_t n, uint64_t total_bytes, uint64_t *__restrict__ soff,
+                                                       uint64_t *__restrict__ slen, StreamRec *__restrict__ streams)
+{
+    __shared__ unsigned long long s_max[1024];
+    check_ranges_block(off, len, n, total_bytes, soff, slen, streams, s_max);
+}
+
+// An input of at most SMALL_INPUT_BYTES is decoded by the cooperative kernel whatever the index finds in it (the lane
+// kernels' two launches -- 9 us of early exits -- are not even enqueued).
+// (Tried in round 3 and removed: the index of such an input as ONE workgroup of 1 024 threads running every phase
+//  behind k_sync_mask with barriers where the big path has kernel boundaries.  49 us for BASELINE configs[3]'s 1 024
+//  streams against 11 launches x 4.5 us: what a small launch costs is its own chain of dependent memory accesses --
+//  find_stream's binary search, the size chain, the neighbours' records -- not the launch, and one workgroup walks
+//  those chains eight deep where the grid walks them side by side.  profiles/r03_c4_timeline.txt.)
+constexpr uint64_t SMALL_INPUT_BYTES = 4096u * 1024u;
 
 // the index's kernels, in order, on `st`
 static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_bytes, uint64_t total_bytes,
@@ -542,6 +560,7 @@ extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, u
     c->tiles = tiles;
     c->d_n_cand = c->d_tile_base + tiles;
 
+    c->small_input = total_bytes <= SMALL_INPUT_BYTES;
     // The launch sequence depends on the call's arguments only.  A caller that indexes the same buffers again
     // (third call on: seen, captured, replayed) gets it as ONE graph launch; capture needs a real stream (not
     // the legacy default stream), anything going wrong with it switches the graph off for this context.
@@ -728,7 +747,9 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     // (64: always the wave-cooperative kernel; 0: the device picks it for small batches -- coop_takes() -- and the
     //  lane kernels for everything else; 1 / 2 force a lane kernel)
     // (3: the lane kernels, picked per batch as under 0, but never the cooperative kernel)
-    const bool coop_only = c->lanes_per_seg == 64, lanes_only = c->lanes_per_seg == 3;
+    // (a small input is the cooperative kernel's whatever it holds: SMALL_INPUT_BYTES)
+    const bool coop_only = c->lanes_per_seg == 64 || (c->lanes_per_seg == 0 && c->small_input);
+    const bool lanes_only = c->lanes_per_seg == 3;
     const uint32_t force = (coop_only || lanes_only) ? 0u : c->lanes_per_seg;
     const bool run1 = force != 2 && !coop_only, run2 = force != 1 && !coop_only;
     a.coop = coop_only ? 64u : lanes_only ? 3u : force;

@@ -100,6 +100,39 @@ __device__ const CheckTables d_chk = make_check();
 // While the chunk is in registers anyway: its part of the substream check (mlp_check.h) -- the CRC-8 of the
 // chunk's 16 bytes from state 0 (sixteen table look-ups; the LDS pipe is idle in this kernel, which is bound by
 // HBM) and the XOR of its bytes, two bytes per chunk into parts[].  k_au_check puts them together per substream.
+// one chunk: -> its candidate mask (returned) and its partial sums (crc0 | xor << 8)
+__device__ __forceinline__ uint32_t mask_chunk(const uint8_t *__restrict__ bytes, uint64_t total_bytes, uint64_t chunk,
+                                               const uint8_t *s_slice, uint32_t &part)
+{
+    // 48-byte window: the pattern of the last offset (chunk*16+14) ends at +22
+    const uint4 *q = reinterpret_cast<const uint4 *>(bytes) + chunk;
+    const uint4 a = q[0], c = q[1];
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        // halfwords j+2, j+3 of the window hold bytes p+4..p+7
+        const int h = j + 2;
+        const uint32_t lo = (h & 1) ? (w[h >> 1] >> 16) : (w[h >> 1] & 0xFFFFu);
+        const uint32_t hi = ((h + 1) & 1) ? (w[(h + 1) >> 1] >> 16) : (w[(h + 1) >> 1] & 0xFFFFu);
+        if (lo == 0x72F8u && hi == 0xBB6Fu) {
+            if (sync_frame_at(bytes, chunk * 16 + 2 * j, total_bytes))
+                m |= 1u << j;
+        }
+    }
+    // byte i of the chunk carries x^(8 (16 - i)): table 15 - i
+    uint32_t c0 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        c0 ^= s_slice[(15 - 4 * k) * 256 + (w[k] & 0xFFu)] ^ s_slice[(14 - 4 * k) * 256 + ((w[k] >> 8) & 0xFFu)] ^
+              s_slice[(13 - 4 * k) * 256 + ((w[k] >> 16) & 0xFFu)] ^ s_slice[(12 - 4 * k) * 256 + (w[k] >> 24)];
+    uint32_t px = w[0] ^ w[1] ^ w[2] ^ w[3];
+    px ^= px >> 16;
+    px = (px ^ (px >> 8)) & 0xFFu;
+    part = c0 | (px << 8);
+    return m;
+}
+
 __global__ __launch_bounds__(IDX_THREADS) void k_sync_mask(const uint8_t *__restrict__ bytes,
                                                            uint64_t total_bytes,
                                                            uint8_t *__restrict__ masks,
@@ -118,36 +151,11 @@ __global__ __launch_bounds__(IDX_THREADS) void k_sync_mask(const uint8_t *__rest
         const uint64_t chunk = tile0 + (uint64_t)k * IDX_THREADS + threadIdx.x;
         if (chunk >= n_chunks)
             break;
-        // 48-byte window: the pattern of the last offset (chunk*16+14) ends at +22
-        const uint4 *q = reinterpret_cast<const uint4 *>(bytes) + chunk;
-        const uint4 a = q[0], c = q[1];
-        uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-        uint32_t m = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            // halfwords j+2, j+3 of the window hold bytes p+4..p+7
-            const int h = j + 2;
-            const uint32_t lo = (h & 1) ? (w[h >> 1] >> 16) : (w[h >> 1] & 0xFFFFu);
-            const uint32_t hi = ((h + 1) & 1) ? (w[(h + 1) >> 1] >> 16) : (w[(h + 1) >> 1] & 0xFFFFu);
-            if (lo == 0x72F8u && hi == 0xBB6Fu) {
-                if (sync_frame_at(bytes, chunk * 16 + 2 * j, total_bytes))
-                    m |= 1u << j;
-            }
-        }
+        uint32_t part;
+        const uint32_t m = mask_chunk(bytes, total_bytes, chunk, s_slice, part);
         masks[chunk] = (uint8_t)m;
         cnt += __popc(m);
-        {
-            // byte i of the chunk carries x^(8 (16 - i)): table 15 - i
-            uint32_t c0 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                c0 ^= s_slice[(15 - 4 * k) * 256 + (w[k] & 0xFFu)] ^ s_slice[(14 - 4 * k) * 256 + ((w[k] >> 8) & 0xFFu)] ^
-                      s_slice[(13 - 4 * k) * 256 + ((w[k] >> 16) & 0xFFu)] ^ s_slice[(12 - 4 * k) * 256 + (w[k] >> 24)];
-            uint32_t px = w[0] ^ w[1] ^ w[2] ^ w[3];
-            px ^= px >> 16;
-            px = (px ^ (px >> 8)) & 0xFFu;
-            parts[chunk] = (uint16_t)(c0 | (px << 8));
-        }
+        parts[chunk] = (uint16_t)part;
     }
     // block reduce
     for (int o = 32; o > 0; o >>= 1)
@@ -322,22 +330,13 @@ constexpr uint32_t SEG_DEAD = 1u << 24;   // DVDA_ST_FALSE_SYNC: candidate insid
                                           // or in bytes that belong to no stream
 
 // Pass 3: one lane per candidate walks the size chain to the next major sync.
-__global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes,
-                                               const uint64_t *__restrict__ stream_off,
-                                               const uint64_t *__restrict__ stream_len,
-                                               uint32_t n_streams,
-                                               const uint64_t *__restrict__ cand_off,
-                                               const uint32_t *__restrict__ n_cand_ptr,
-                                               uint32_t max_cand, SegRec *__restrict__ seg,
-                                               uint32_t *__restrict__ seg_frames,
-                                               StreamRec *__restrict__ streams, uint32_t *__restrict__ cls)
+__device__ __forceinline__ void chase_one(uint32_t i, const uint8_t *__restrict__ bytes,
+                                          const uint64_t *__restrict__ stream_off,
+                                          const uint64_t *__restrict__ stream_len, uint32_t n_streams,
+                                          const uint64_t *__restrict__ cand_off, SegRec *__restrict__ seg,
+                                          uint32_t *__restrict__ seg_frames, StreamRec *__restrict__ streams,
+                                          uint32_t *__restrict__ cls)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_cand = *n_cand_ptr;
-    if (n_cand > max_cand)
-        n_cand = max_cand;
-    if (i >= n_cand)
-        return;
     const uint64_t off = cand_off[i];
     const uint32_t s = find_stream(stream_off, n_streams, off);
     const uint64_t s_begin = stream_off[s];
@@ -421,21 +420,34 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
     }
 }
 
-
-// Pass 3b (before the scan): a sync pattern can occur inside payload or padding bytes.  Such a
-// false candidate is not a frame start of the real chain: the previous candidate's size-chain walk
-// passes over it and lands on a later candidate.  It is marked dead (no frames, no lanes) instead
-// of being trusted; what cannot be resolved this way stays DVDA_ST_IRREGULAR.
-__global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ stream_off,
-                                                   const uint64_t *__restrict__ stream_len,
-                                                   const uint32_t *__restrict__ n_cand_ptr, uint32_t max_cand,
-                                                   SegRec *__restrict__ seg, uint32_t *__restrict__ seg_frames,
-                                                   const StreamRec *__restrict__ streams)
+__global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes,
+                                               const uint64_t *__restrict__ stream_off,
+                                               const uint64_t *__restrict__ stream_len,
+                                               uint32_t n_streams,
+                                               const uint64_t *__restrict__ cand_off,
+                                               const uint32_t *__restrict__ n_cand_ptr,
+                                               uint32_t max_cand, SegRec *__restrict__ seg,
+                                               uint32_t *__restrict__ seg_frames,
+                                               StreamRec *__restrict__ streams, uint32_t *__restrict__ cls)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_cand = *n_cand_ptr;
     if (n_cand > max_cand)
         n_cand = max_cand;
+    if (i >= n_cand)
+        return;
+    chase_one(i, bytes, stream_off, stream_len, n_streams, cand_off, seg, seg_frames, streams, cls);
+}
+
+
+// Pass 3b (before the scan): a sync pattern can occur inside payload or padding bytes.  Such a
+// false candidate is not a frame start of the real chain: the previous candidate's size-chain walk
+// passes over it and lands on a later candidate.  It is marked dead (no frames, no lanes) instead
+// of being trusted; what cannot be resolved this way stays DVDA_ST_IRREGULAR.
+__device__ __forceinline__ void mark_dead_one(uint32_t i, uint32_t n_cand, const uint64_t *__restrict__ stream_off,
+                                              const uint64_t *__restrict__ stream_len, SegRec *__restrict__ seg,
+                                              uint32_t *__restrict__ seg_frames, const StreamRec *__restrict__ streams)
+{
     if (i >= n_cand || i == 0)
         return;
     const uint32_t s = seg[i].stream;
@@ -471,6 +483,19 @@ __global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_mark_dead(const uint64_t *__restrict__ stream_off,
+                                                   const uint64_t *__restrict__ stream_len,
+                                                   const uint32_t *__restrict__ n_cand_ptr, uint32_t max_cand,
+                                                   SegRec *__restrict__ seg, uint32_t *__restrict__ seg_frames,
+                                                   const StreamRec *__restrict__ streams)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = *n_cand_ptr;
+    if (n_cand > max_cand)
+        n_cand = max_cand;
+    mark_dead_one(i, n_cand, stream_off, stream_len, seg, seg_frames, streams);
+}
+
 // a stream's shape for the lane packing: PCM frames of its first segment, then sample rate and assignment
 __device__ __forceinline__ uint32_t stream_shape_key(const SegRec &r)
 {
@@ -480,19 +505,12 @@ __device__ __forceinline__ uint32_t stream_shape_key(const SegRec &r)
 
 // Pass 4 (after the exclusive scan of seg_frames): per-stream totals and the
 // landing check.  One lane per segment.
-__global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ stream_off,
-                                              const uint64_t *__restrict__ stream_len,
-                                              const uint32_t *__restrict__ n_cand_ptr,
-                                              uint32_t max_cand, SegRec *__restrict__ seg,
-                                              const uint32_t *__restrict__ seg_fbase,
-                                              StreamRec *__restrict__ streams, uint32_t n_streams,
-                                              uint32_t *__restrict__ shape_key, uint32_t *__restrict__ hetero)
+__device__ __forceinline__ void link_one(uint32_t i, uint32_t n_cand, bool overflow,
+                                         const uint64_t *__restrict__ stream_off,
+                                         const uint64_t *__restrict__ stream_len, SegRec *__restrict__ seg,
+                                         const uint32_t *__restrict__ seg_fbase, StreamRec *__restrict__ streams,
+                                         uint32_t n_streams, uint32_t *__restrict__ shape_key, uint32_t *__restrict__ hetero)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_cand = *n_cand_ptr;
-    const bool overflow = n_cand > max_cand;
-    if (n_cand > max_cand)
-        n_cand = max_cand;
     if (i >= n_cand)
         return;
     if (overflow && i == n_cand - 1) {
@@ -560,6 +578,22 @@ __global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ strea
         streams[s].frames = seg_fbase[j] - seg_fbase[streams[s].first_seg];
         (void)s_end;
     }
+}
+
+__global__ __launch_bounds__(256) void k_link(const uint64_t *__restrict__ stream_off,
+                                              const uint64_t *__restrict__ stream_len,
+                                              const uint32_t *__restrict__ n_cand_ptr,
+                                              uint32_t max_cand, SegRec *__restrict__ seg,
+                                              const uint32_t *__restrict__ seg_fbase,
+                                              StreamRec *__restrict__ streams, uint32_t n_streams,
+                                              uint32_t *__restrict__ shape_key, uint32_t *__restrict__ hetero)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_cand = *n_cand_ptr;
+    const bool overflow = n_cand > max_cand;
+    if (n_cand > max_cand)
+        n_cand = max_cand;
+    link_one(i, n_cand, overflow, stream_off, stream_len, seg, seg_fbase, streams, n_streams, shape_key, hetero);
 }
 
 // ---- lane packing for heterogeneous batches.  A wave advances its 64 segments in lockstep: segments of
