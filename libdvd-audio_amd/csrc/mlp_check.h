@@ -159,6 +159,13 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
                 break;                          // both decode lanes stop here with DVDA_ST_EOF
             if (!check0)
                 continue;
+            // (from here on everything is an offset from `ub`, the 128-byte boundary in front of the unit's data: an
+            //  access unit is at most 8 190 bytes, so 32-bit arithmetic -- this kernel is bound by VALU issue, and
+            //  64-bit address arithmetic was a third of its instructions)
+            const uint64_t ub = data0 & ~(uint64_t)127;
+            const uint8_t *const ubytes = bytes + ub;
+            const uint16_t *const uparts = parts + (ub >> 4);
+            const uint32_t d0 = (uint32_t)(data0 - ub);
             for (uint32_t s = 0; s < S; s++) {
                 if (done[s])
                     continue;
@@ -166,35 +173,35 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
                     done[s] = true;             // (that lane stops with DVDA_ST_EOF)
                     continue;
                 }
-                const uint64_t ss_lo = data0 + start[s];
-                const uint64_t data_hi = data0 + end[s] - 2u;       // parity byte here, CRC-8 byte behind it
-                const uint32_t n_data = (uint32_t)(data_hi - ss_lo);
-                const uint64_t end_m = n_data ? data_hi - 1u : ss_lo;       // the CRC runs over [ss_lo, end_m); the
+                const uint32_t ss_lo = d0 + start[s];
+                const uint32_t data_hi = d0 + end[s] - 2u;          // parity byte here, CRC-8 byte behind it
+                const uint32_t n_data = data_hi - ss_lo;
+                const uint32_t end_m = n_data ? data_hi - 1u : ss_lo;       // the CRC runs over [ss_lo, end_m); the
                                                                             // last data byte is XORed in raw ("final_crc")
                 // the trailer and the last data byte: every lane asks (one address each), together with the rest
-                const uint64_t tb = data_hi - (n_data ? 1u : 0u);           // last data byte (if any), parity, CRC-8:
-                const uint32_t *tp = reinterpret_cast<const uint32_t *>(bytes + (tb & ~(uint64_t)3));     // in two dwords
-                const uint64_t tw = ((uint64_t)tp[1] << 32 | tp[0]) >> (8u * (uint32_t)(tb & 3u));
+                const uint32_t tb = data_hi - (n_data ? 1u : 0u);           // last data byte (if any), parity, CRC-8:
+                const uint32_t *tp = reinterpret_cast<const uint32_t *>(ubytes + (tb & ~3u));            // in two dwords
+                const uint64_t tw = ((uint64_t)tp[1] << 32 | tp[0]) >> (8u * (tb & 3u));
                 const uint32_t last = (uint32_t)tw & 0xFFu;
                 const uint32_t pb = (uint32_t)(tw >> (n_data ? 8 : 0)) & 0xFFu, cb = (uint32_t)(tw >> (n_data ? 16 : 8)) & 0xFFu;
                 // the ragged ends -- the chunk ss_lo starts inside of (lane 0), the chunk end_m ends inside of (lane 1) --
                 // are the only bytes read again; asked for HERE, with everything else of this unit: one memory round
-                // trip per access unit (behind the partial sums' loop they cost a second one: 173 -> 1xx us)
-                const uint64_t bh = ss_lo & ~(uint64_t)15, bt = end_m & ~(uint64_t)15;
-                const uint4 v_edge = *reinterpret_cast<const uint4 *>(bytes + (j == 1 ? bt : bh));
+                // trip per access unit
+                const uint32_t bh = ss_lo & ~15u, bt = end_m & ~15u;
+                const uint4 v_edge = *reinterpret_cast<const uint4 *>(ubytes + (j == 1 ? bt : bh));
                 // ---- whole chunks inside [ss_lo, end_m): their partial sums, CHK_RUN chunks per lane and pass
-                const uint64_t ci0 = (ss_lo + 15u) >> 4, ci1 = end_m >> 4;  // chunk indices [ci0, ci1)
+                const uint32_t ci0 = (ss_lo + 15u) >> 4, ci1 = end_m >> 4;  // chunk indices [ci0, ci1) from ub on
                 uint32_t red = 0;                                           // crc | parity << 8 of this lane's share
                 // (a lane takes CHK_RUN consecutive chunks per pass -- CHK_RUN / 8 loads of 16 bytes that leave together;
                 //  a pass of the group covers 64 chunks, 1 KB: most access units whole)
-                for (uint64_t cg = ci0 & ~(uint64_t)7; cg < ci1; cg += 64u) {
-                    const uint64_t c_first = cg + (uint64_t)CHK_RUN * j;
+                for (uint32_t cg = ci0 & ~7u; cg < ci1; cg += 64u) {
+                    const uint32_t c_first = cg + (uint32_t)CHK_RUN * j;
                     uint32_t acc = 0, par = 0;
                     if (c_first < ci1) {
                         uint4 pv[CHK_RUN / 8];
 #pragma unroll
                         for (int q = 0; q < CHK_RUN / 8; q++)
-                            pv[q] = *reinterpret_cast<const uint4 *>(parts + c_first + 8u * q);
+                            pv[q] = *reinterpret_cast<const uint4 *>(uparts + c_first + 8u * q);
 #pragma unroll
                         for (int t = 0; t < CHK_RUN; t++) {
                             const uint4 &v4 = pv[t >> 3];
@@ -202,14 +209,13 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
                             const uint32_t pt = (t & 1) ? w >> 16 : w & 0xFFFFu;
                             const bool in = c_first + (uint32_t)t >= ci0 && c_first + (uint32_t)t < ci1;
                             // Horner: times x^128 (one chunk on), plus the chunk.  (Eight independent look-ups in eight
-                            // tables x^(128 k) instead of this chain were measured: slower, 196 vs 175 us -- the
-                            // kernel is bound by the number of small loads it issues, not by this chain.)
+                            // tables x^(128 k) instead of this chain were measured: slower, 196 vs 175 us.)
                             acc = (uint32_t)s_slice[15 * 256 + acc] ^ (in ? pt & 0xFFu : 0u);
                             par ^= in ? pt >> 8 : 0u;
                         }
                         // the lane's last chunk ends d bytes in front of the message's end (d < 0 when the run
                         // reaches past it: the exponent is taken mod 255; 16320 = 64 * 255 keeps it positive)
-                        const int64_t d = (int64_t)end_m - (int64_t)(16u * (c_first + (uint64_t)CHK_RUN));
+                        const int32_t d = (int32_t)end_m - (int32_t)(16u * (c_first + (uint32_t)CHK_RUN));
                         acc = shift(acc, (8u * (uint32_t)(d + 16320)) % 255u);
                     }
                     red ^= acc | (par << 8);
@@ -219,19 +225,18 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
                     const bool head = (ss_lo & 15u) != 0 && end_m > ss_lo;
                     const bool tail = (end_m & 15u) != 0 && end_m > ss_lo && !(head && bt == bh);
                     if ((j == 0 && head) || (j == 1 && tail)) {
-                        const uint64_t B = j == 0 ? bh : bt;
-                        const uint4 v = v_edge;
+                        const uint32_t B = j == 0 ? bh : bt;
                         const int32_t lo = j == 0 ? (int32_t)(ss_lo - B) : 0;
                         const int32_t hi = end_m - B < 16u ? (int32_t)(end_m - B) : 16;
-                        const uint32_t r = chk_masked_chunk(v, lo, hi, s_slice);
-                        const int64_t d = (int64_t)end_m - (int64_t)(B + 16u);
+                        const uint32_t r = chk_masked_chunk(v_edge, lo, hi, s_slice);
+                        const int32_t d = (int32_t)end_m - (int32_t)(B + 16u);
                         red ^= shift(r & 0xFFu, (8u * (uint32_t)(d + 8160)) % 255u) | (r & 0xFF00u);
                     }
                 }
 #pragma unroll
                 for (int o = CHK_GROUP / 2; o > 0; o >>= 1)
                     red ^= __shfl_xor(red, o, CHK_GROUP);
-                const uint32_t n_m = (uint32_t)(end_m - ss_lo);
+                const uint32_t n_m = end_m - ss_lo;
                 const uint32_t crc = (red & 0xFFu) ^ shift(0x3Cu, (8u * n_m) % 255u);
                 const uint32_t fin = n_data ? (crc ^ last) : 0u;
                 const uint32_t parity = ((red >> 8) ^ (n_data ? last : 0u)) & 0xFFu;        // XOR of [ss_lo, data_hi)
