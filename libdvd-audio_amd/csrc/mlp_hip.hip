@@ -393,9 +393,15 @@ static void exscan(dvda_mlp_hip_ctx *c, hipStream_t st, const uint32_t *in, uint
 // one dispatch for the things an index call starts from: empty stream records, and the per-segment status /
 // row counters / end-of-segment notes at zero (a note of the batch before must not vouch for a segment of this one)
 __global__ void k_init_streams(StreamRec *s, uint32_t n, uint32_t *seg_status, uint32_t *seg_rows, uint32_t *yield_req,
-                               uint32_t *seg_meta, uint32_t n_seg)
+                               uint32_t *seg_meta, uint32_t n_seg, uint32_t *cls, uint32_t *summary_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4)
+        cls[i] = 0;                 // substream classes, "the batch mixes shapes" (a memset of its own cost a launch)
+    // the decode summary and its partial sums start from zero: the first decode call on this index finds them so
+    // (its own memset was a launch and a host gap in front of the fast pass: 13 us of a small batch's 165)
+    if (i < (1 + SUMMARY_PARTS) * sizeof(DecodeSummary) / sizeof(uint32_t))
+        summary_words[i] = 0;
     if (i < n_seg) {
         seg_status[i] = 0;
         seg_rows[i] = 0;
@@ -500,11 +506,13 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
 {
     const uint64_t tiles = c->tiles;
     const uint32_t ms = c->max_segments;
-    (void)hipMemsetAsync(c->d_cls, 0, 4 * sizeof(uint32_t), st);
     {
-        const uint32_t n_init = n_streams > ms ? n_streams : ms;
+        uint32_t n_init = n_streams > ms ? n_streams : ms;
+        if (n_init < 1024)
+            n_init = 1024;              // (the summary's 520 words are zeroed by this grid too)
         hipLaunchKernelGGL(k_init_streams, dim3((n_init + 255) / 256), dim3(256), 0, st, c->d_streams,
-                           n_streams, c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, ms);
+                           n_streams, c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, ms, c->d_cls,
+                           reinterpret_cast<uint32_t *>(c->d_summary));
         hipLaunchKernelGGL(k_check_ranges, dim3(1), dim3(1024), 0, st, d_stream_off, d_stream_len, n_streams, total_bytes,
                            c->d_soff, c->d_slen, c->d_streams);
         d_stream_off = c->d_soff;
@@ -521,15 +529,22 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
     hipLaunchKernelGGL(k_mark_dead, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
                        c->d_n_cand, ms, c->d_seg, c->d_seg_frames, c->d_streams);
     exscan(c, st, c->d_seg_frames, c->d_seg_fbase, 0u, c->d_n_cand, ms);
+    // (a small input is decoded by the cooperative kernel, which has a workgroup per segment and no use for the lane
+    //  packing: its four launches -- 18 us of early exits on a batch of one shape -- are left out, and k_link notes
+    //  "mixes shapes" where no kernel looks, so that the lane kernels, should a caller force them, keep index order)
+    const bool pack = !(total_bytes <= SMALL_INPUT_BYTES);
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
-                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams, n_streams, c->d_shape_key, c->d_cls + 2);
+                       c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams, n_streams, c->d_shape_key,
+                       c->d_cls + (pack ? 2 : 3));
     // lane packing by stream shape (identity, and next to free, when the batch has one shape)
+    if (pack) {
     hipLaunchKernelGGL(k_stream_rank, dim3((n_streams + 255) / 256), dim3(256), 0, st, c->d_shape_key, c->d_streams,
                        n_streams, c->d_rank, c->d_sorted_cnt, c->d_cls + 2);
     exscan(c, st, c->d_sorted_cnt, c->d_sorted_base, n_streams, nullptr, n_streams);
     (void)hipMemsetAsync(c->d_lane_seg, 0xFF, (size_t)ms * sizeof(uint32_t), st);     // lanes that are dealt nothing
     hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, st, c->d_seg, c->d_streams, c->d_n_cand, ms,
                        c->d_rank, c->d_sorted_base, c->d_cls + 2, c->d_lane_seg);
+    }
     // parity / CRC-8 of every substream, byte-parallel (16 lanes per segment): the decode lanes only compare
     hipLaunchKernelGGL(k_au_check, dim3((unsigned)(((uint64_t)ms * CHK_GROUP + CHK_THREADS - 1) / CHK_THREADS)),
                        dim3(CHK_THREADS), 0, st, d_bytes, c->d_parts, c->d_seg, c->d_n_cand, ms, c->d_streams, c->d_seg_check);
@@ -736,10 +751,11 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     a.yield_req = c->d_yield;
     a.seg_check = c->d_seg_check;
     a.caps = ws_caps(c);
-    HIP_TRY(hipMemsetAsync(c->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary), st));
-    if (c->decoded)
+    if (c->decoded) {               // (the first decode on an index finds the summary zeroed by the index)
+        HIP_TRY(hipMemsetAsync(c->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary), st));
         hipLaunchKernelGGL(k_reset_segments, dim3((unsigned)((c->max_segments + 255) / 256)), dim3(256), 0, st,
                            c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, c->max_segments);
+    }
     c->decoded = true;
     // which kernels: one lane per segment for the streams with one substream, the two-wave layout for those
     // with two -- both unless the caller forced one; a kernel whose class is absent from the batch (the
