@@ -49,12 +49,25 @@ constexpr int COOP_STAGE_DW = 2048 + 8;         // an access unit is at most 8 1
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// DVDA_EXP_STAMP builds: where a wave's time goes (dbg[16 + i]: 0 staging + framing, 1 block headers, 2 scan,
+// 3 residuals, 4 filter, 5 the substreams' meeting + rematrix + output, 6 the rest)
+#if defined(DVDA_EXP_STAMP)
+#define COOP_STAMP(i)                                                    \
+    do {                                                                 \
+        const unsigned long long t_ = clock64();                         \
+        cstamp[i] += t_ - cstamp_t;                                      \
+        cstamp_t = t_;                                                   \
+    } while (0)
+#else
+#define COOP_STAMP(i) ((void)0)
+#endif
+
 // v[LANE] = s (one v_writelane_b32 with the lane as an inline constant; this compiler has no builtin for it)
 template <int LANE>
 __device__ __forceinline__ void coop_writelane(uint32_t &v, uint32_t s)
 {
     static_assert(LANE >= 0 && LANE < 64, "lane");
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(rfl(s)), "n"(LANE));
 }
 
 // wave-uniform MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206) over the access unit
@@ -69,7 +82,7 @@ struct UReader {
     uint64_t win;
     uint32_t pos, thr;
     const uint32_t *pnext;
-    uint32_t pend;
+    uint32_t pend;              // the dword behind the window, on its way from LDS (a vector register)
     __device__ __forceinline__ void seek(uint32_t p)
     {
         const uint32_t i = (p >> 5) < (uint32_t)COOP_STAGE_DW - 3u ? p >> 5 : (uint32_t)COOP_STAGE_DW - 3u;
@@ -82,7 +95,7 @@ struct UReader {
     }
     __device__ __forceinline__ void refill()
     {
-        if (pos >= thr) {
+        if (__builtin_expect(pos >= thr, 0)) {
             win |= (uint64_t)rfl(pend) << (pos - thr);      // 32 - (bits left) = pos - thr
             thr += 32u;
             pnext++;
@@ -244,7 +257,12 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     const uint32_t nthreads = two ? (uint32_t)COOP_THREADS : 64u;
     const uint32_t tid = two ? threadIdx.x : lane;
 
+#if defined(DVDA_EXP_STAMP)
+    unsigned long long cstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cstamp_t = clock64();
+#endif
     for (uint32_t f = 0; f < sr.nframes && !stop; f++) {
+        COOP_STAMP(6);
         // ================================================================ the access unit into LDS
         // (frames start at even offsets; the stage starts at the dword that holds the first byte)
         const uint64_t base_b = cur & ~(uint64_t)3;
@@ -304,6 +322,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             } else {
                 const uint32_t ss_end_bit = data0_bit + 8u * (check0 ? my_end - 2u : my_end);
                 rd.seek(data0_bit + 8u * my_start);
+                COOP_STAMP(0);
                 uint32_t blocks_in_frame = 0;
                 bool last_block = false;
                 // ======================================================== blocks (src/mlp.c:714-807)
@@ -638,19 +657,23 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         break;
                     }
                     blocks_in_frame++;
+                    COOP_STAMP(1);
                     // ---- what the lanes need of the block's parameters
                     my_pk = P.pk[slot];
                     my_sho = P.sho[slot];
                     // the scan's own copy of what it needs per slot: length of the "1 + bits" codes, whether there is
                     // a code book at all (as a mask), LSB count
-                    uint32_t s_lena[6], s_cbm[6], s_lb[6];
+                    // (per slot: length of the "1 + bits" codes; for the other form min(z', cap) + add with cap = 6,
+                    //  add = 3 -- both 0 when the slot has no code book, so that no code costs no select; LSB count)
+                    // (both totals with the slot's LSB count already in them: the symbol's bits, code and LSBs)
+                    uint32_t s_tota[6], s_cap[6], s_totl[6];
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
                         const uint32_t pkk = (uint32_t)k < nslots ? rfl(P.pk[k]) : 0u;
-                        const uint32_t cb = pkk & 3u;
-                        s_lena[k] = cb ? 4u - cb : 0u;
-                        s_cbm[k] = cb ? 0xFFFFFFFFu : 0u;
-                        s_lb[k] = (pkk >> 2) & 31u;
+                        const uint32_t cb = pkk & 3u, lbk = (pkk >> 2) & 31u;
+                        s_tota[k] = (cb ? 4u - cb : 0u) + lbk;
+                        s_cap[k] = cb ? 6u : 0u;
+                        s_totl[k] = (cb ? 3u : 0u) + lbk;
                     }
                     const uint32_t nbyp = (uint32_t)__popc(bypass_mask);
                     // ================================================ rows of the block, eight at a time
@@ -665,8 +688,11 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     for (uint32_t r0 = 0; r0 < block_size; r0 += 8) {
                         const uint32_t nr = block_size - r0 < 8u ? block_size - r0 : 8u;
                         uint32_t v_sym = 0;             // lane (frame * 8 + slot): bit position of that symbol; slot 7: the row's start
-                        auto scan_row = [&](auto R) {
+                        // (NS symbols a row -- 2, 4 or 6: a slot past the substream's last has no code book and no LSBs,
+                        //  its "symbol" is no bits long and costs less than a test per symbol would)
+                        auto scan_row = [&](auto R, auto NS_) {
                             constexpr int r = decltype(R)::value;
+                            constexpr int NS = decltype(NS_)::value;
                             coop_writelane<r * 8 + 7>(v_sym, rd.pos);
                             // the row's bypassed LSBs (at most one per matrix) sit in front of its symbols
                             rd.refill();
@@ -679,40 +705,48 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                                 // and a one in the seven bits behind the first two (length z' + 3, capped: an invalid
                                 // code is found by the lane that decodes the symbol)
                                 const uint32_t top = (uint32_t)(rd.win >> 32);
-                                const uint32_t z = (uint32_t)__builtin_clz((int)(((top << 2) & 0xFE000000u) | 0x01000000u));
-                                const uint32_t len_l = ((z > 6u ? 6u : z) + 3u) & s_cbm[k];
-                                uint32_t esc = top >> 31;
-                                asm volatile("" : "+s"(esc));          // (a scalar compare and select, not a 64-bit vector compare)
-                                const uint32_t len = esc ? s_lena[k] : len_l;
+                                // (zeros behind the first two bits; the cap takes in "none of the next 30 is set", where
+                                //  the instruction answers -1, as well as seven and more)
+                                uint32_t z;
+                                asm("s_flbit_i32_b32 %0, %1" : "=s"(z) : "s"(rfl(top << 2)));
+                                const uint32_t tot_l = (z < s_cap[k] ? z : s_cap[k]) + s_totl[k];
+                                // (the code's first bit picks the form: one scalar compare and select -- left to itself the
+                                //  compiler makes a branch, or a 64-bit vector compare, of it)
+                                uint32_t tot;
+                                asm("s_cmp_lt_i32 %1, 0\n\ts_cselect_b32 %0, %2, %3" : "=s"(tot) : "s"(rfl(top)), "s"(rfl(s_tota[k])), "s"(rfl(tot_l)) : "scc");
                                 coop_writelane<r * 8 + k>(v_sym, rd.pos);
-                                const uint32_t tot = len + s_lb[k];
                                 rd.pos += tot;
                                 rd.win <<= tot;
                             };
                             sym(std::integral_constant<int, 0>{});
-                            if (nslots > 1u) {
-                                sym(std::integral_constant<int, 1>{});
-                                if (nslots > 2u) {
-                                    sym(std::integral_constant<int, 2>{});
-                                    if (nslots > 3u) {
-                                        sym(std::integral_constant<int, 3>{});
-                                        if (nslots > 4u) {
-                                            sym(std::integral_constant<int, 4>{});
-                                            if (nslots > 5u)
-                                                sym(std::integral_constant<int, 5>{});
-                                        }
-                                    }
-                                }
+                            sym(std::integral_constant<int, 1>{});
+                            if constexpr (NS > 2) {
+                                sym(std::integral_constant<int, 2>{});
+                                sym(std::integral_constant<int, 3>{});
+                            }
+                            if constexpr (NS > 4) {
+                                sym(std::integral_constant<int, 4>{});
+                                sym(std::integral_constant<int, 5>{});
                             }
                         };
-                        scan_row(std::integral_constant<int, 0>{});
-                        if (nr > 1u) scan_row(std::integral_constant<int, 1>{});
-                        if (nr > 2u) scan_row(std::integral_constant<int, 2>{});
-                        if (nr > 3u) scan_row(std::integral_constant<int, 3>{});
-                        if (nr > 4u) scan_row(std::integral_constant<int, 4>{});
-                        if (nr > 5u) scan_row(std::integral_constant<int, 5>{});
-                        if (nr > 6u) scan_row(std::integral_constant<int, 6>{});
-                        if (nr > 7u) scan_row(std::integral_constant<int, 7>{});
+                        auto scan_rows = [&](auto NS_) {
+                            scan_row(std::integral_constant<int, 0>{}, NS_);
+                            if (nr > 1u) scan_row(std::integral_constant<int, 1>{}, NS_);
+                            if (nr > 2u) scan_row(std::integral_constant<int, 2>{}, NS_);
+                            if (nr > 3u) scan_row(std::integral_constant<int, 3>{}, NS_);
+                            if (nr > 4u) scan_row(std::integral_constant<int, 4>{}, NS_);
+                            if (nr > 5u) scan_row(std::integral_constant<int, 5>{}, NS_);
+                            if (nr > 6u) scan_row(std::integral_constant<int, 6>{}, NS_);
+                            if (nr > 7u) scan_row(std::integral_constant<int, 7>{}, NS_);
+                        };
+                        const uint32_t ns_u = rfl(nslots);
+                        if (ns_u <= 2u)
+                            scan_rows(std::integral_constant<int, 2>{});
+                        else if (ns_u <= 4u)
+                            scan_rows(std::integral_constant<int, 4>{});
+                        else
+                            scan_rows(std::integral_constant<int, 6>{});
+                        COOP_STAMP(2);
                         // ---- RESIDUALS: one lane per symbol (src/mlp.c:1226-1238)
                         {
                             const uint32_t o = v_sym;
@@ -742,6 +776,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                                 s_byp[row] = bits;
                             }
                         }
+                        COOP_STAMP(3);
                     }
                     if (bad_code) {
                         err = ST_HUFFMAN;
@@ -788,6 +823,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                             }
                         }
                     }
+                    COOP_STAMP(4);
                     frame_rows += block_size;
                     // ---- "last block" bit (src/mlp.c:729); the substream tail is padding
                     last_block = rd.read(1) != 0;
@@ -820,10 +856,16 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             const uint32_t seg_row0 = frames_out * rpa;
             for (uint32_t rb = 0; rb < rpa; rb += 64u) {
                 const uint32_t row = rb + lane;
+                const uint32_t nrow_u = rpa - rb < 64u ? rpa - rb : 64u;
                 uint32_t sd = seed;
-                for (uint32_t i = 0; i < lane; i++) {
+                for (uint32_t i = 0; i < (lane < nrow_u ? lane : 0u); i++) {
                     const uint32_t shifted = (sd >> 7) & 0xFFFFu;
                     sd = (sd << 16) ^ shifted ^ (shifted << 5);
+                }
+                {
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)sd, (int)(nrow_u - 1u));
+                    const uint32_t sh2 = (sl >> 7) & 0xFFFFu;
+                    seed = (sl << 16) ^ sh2 ^ (sh2 << 5);
                 }
                 if (row < rpa) {
                     int32_t *dst = planes + res_index(seg_row0 + row, 0);
@@ -832,11 +874,6 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         dst[4 * c] = s_val[c][row];
                     dst[4 * 6] = (int32_t)s_byp[row];
                     dst[4 * 7] = (int32_t)sd;
-                }
-                const uint32_t adv = rpa - rb < 64u ? rpa - rb : 64u;
-                for (uint32_t i = 0; i < adv; i++) {
-                    const uint32_t sh2 = (seed >> 7) & 0xFFFFu;
-                    seed = (seed << 16) ^ sh2 ^ (sh2 << 5);
                 }
             }
             if (lane == 0) {
@@ -857,10 +894,19 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             for (uint32_t rb = 0; rb < rpa; rb += 64u) {
                 const uint32_t row = rb + lane;
                 // the noise generator steps once per PCM frame (src/mlp.c:1327-1334): this lane's frame is `lane` steps on
+                // (lane L steps L times, lanes past the pass's last row not at all: the wave runs the loop as often
+                //  as the pass has rows, and the generator's state behind the pass is one step on from the last
+                //  row's -- a second, wave-uniform loop over the same steps used to compute it again)
+                const uint32_t nrow_u = rpa - rb < 64u ? rpa - rb : 64u;
                 uint32_t sd = seed;
-                for (uint32_t i = 0; i < lane; i++) {
+                for (uint32_t i = 0; i < (lane < nrow_u ? lane : 0u); i++) {
                     const uint32_t shifted = (sd >> 7) & 0xFFFFu;
                     sd = (sd << 16) ^ shifted ^ (shifted << 5);
+                }
+                {
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)sd, (int)(nrow_u - 1u));
+                    const uint32_t sh2 = (sl >> 7) & 0xFFFFu;
+                    seed = (sl << 16) ^ sh2 ^ (sh2 << 5);
                 }
                 int32_t ch[6];
 #pragma unroll
@@ -889,14 +935,6 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     for (int c = 0; c < 6; c++)
                         if ((uint32_t)c <= max_mat_ch)
                             ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
-                }
-                // the generator's state after this step's frames (64, or what is left of the unit)
-                {
-                    const uint32_t adv = rpa - rb < 64u ? rpa - rb : 64u;
-                    for (uint32_t i = 0; i < adv; i++) {
-                        const uint32_t sh2 = (seed >> 7) & 0xFFFFu;
-                        seed = (seed << 16) ^ sh2 ^ (sh2 << 5);
-                    }
                 }
                 // ---- RIFF order (src/mlp.c:416-438, 527-533), the caller's layout
                 const uint64_t orow = au_row0 + row;
@@ -948,6 +986,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                 rows_written += nvalid;
             }
         }
+        COOP_STAMP(5);
         if (!dropped && !quit)
             frames_out++;
         // (the segment behind this one continues its history: both go to the chain passes -- looked at after the
@@ -973,6 +1012,11 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         }
     }
 
+#if defined(DVDA_EXP_STAMP)
+    if (lane == 0 && a.dbg)
+        for (int i = 0; i < 8; i++)
+            atomicAdd(&a.dbg[8 + i], cstamp[i]);
+#endif
     if (PARSE) {
         // ---- end of this (segment, substream)'s records; the segment's channel range and whether any of its blocks
         //      runs IIR taps, for the filter pass

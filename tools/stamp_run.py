@@ -9,7 +9,14 @@ import numpy as np, torch
 import libdvd_audio_amd as pkg
 syn, hip = pkg.synth, pkg.hipdec
 SS = 1
-if len(sys.argv) > 1 and sys.argv[1] in ("fuzz_fast", "fuzz_all"):
+if len(sys.argv) > 1 and sys.argv[1] in ("one", "c4"):
+    # small batches (the cooperative kernel): ONE title of 512 units / configs[3]'s 1 024 single units
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512 if sys.argv[1] == "one" else 1)
+    n = 1 if sys.argv[1] == "one" else 1024
+    flat, offs, sizes, frames = syn.batch(cfg, 1, n)
+    nchs = np.full(n, 6, np.int64)
+    nseg = 1024
+elif len(sys.argv) > 1 and sys.argv[1] in ("fuzz_fast", "fuzz_all"):
     # the bench's fuzz sub-record shape (8 configurations x 512 titles of 64 access units)
     from bench import gen_mixed
     SF = syn.SF
@@ -46,5 +53,11 @@ for role in range(2 if SS == 2 else 1):
     v = np.array(list(out)[8 * role:8 * role + 8], dtype=np.float64)
     print("role", role, "(two-wave layout: 0 = first substream's wave, rematrixes; 1 = last substream's wave)" if SS == 2 else "")
     for nme, x in zip(names, v):
+        print("  %-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / max(v.sum(), 1), x))
+v = np.array(list(out)[8:16], dtype=np.float64)
+if v.sum() > 0:
+    print("cooperative kernel (k_coop), shares of its waves' time:")
+    for nme, x in zip(["staging + framing", "block headers", "symbol scan", "residuals", "filter", "meeting + rematrix + output",
+                       "loop frame", "-"], v):
         print("  %-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / max(v.sum(), 1), x))
 print(ctx.kernel_time())
