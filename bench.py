@@ -217,6 +217,7 @@ class Batch:
         self.d_out_off = torch.from_numpy(self.out_off).to(dev)
         self.d_stride = torch.from_numpy(self.all_frames).to(dev)
         self.n_segments = n_segments
+        self.small = n_segments <= 4096
         self.depth = max(1, depth)
         self.ctxs, self._tstreams, self.streams, self.d_pcms = [], [], [], []
         for _ in range(self.depth):
@@ -246,7 +247,9 @@ class Batch:
             # the decodes themselves run one after the other (two fast-pass kernels side by side only take each
             # other's issue slots): this slot's decode waits for the previous slot's; what overlaps is this
             # slot's INDEX -- bound by HBM -- with that decode -- bound by instruction issue
-            if self._turn > 1:
+            # (a small batch -- one the cooperative kernel decodes, a few workgroups per compute unit -- leaves most
+            #  of the device idle: there the slots' decodes run side by side as well)
+            if self._turn > 1 and not self.small:
                 self._tstreams[k].wait_event(self._done[(k - 1) % self.depth])
             ctx.decode_async(self.d_pcms[k].data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), st)
             self._done[k].record(self._tstreams[k])
@@ -389,7 +392,29 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     syn, hip = pkg.synth, pkg.hipdec
     out = {}
 
-    def run(name, flat, offs, sizes, frames, nchs, nseg, replicas, layout, lanes, benign=0, note=None):
+    def in_flight(depth, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign, k_steps, name):
+        """the same small batch with `depth` decode contexts in flight (own HIP stream and PCM buffer each, the
+        non-blocking decode call): a batch the cooperative kernel decodes leaves most of the device idle, a feeder
+        with more than one such batch to decode overlaps them.  Every slot's PCM must be the same."""
+        bp = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, 1, layout, 0, nseg, depth=depth,
+                   chained=chained)
+        dtp, _, _ = bp.timed(k_steps, 2 * depth)
+        bp.check_status(benign=benign)
+        same = bp.slots_equal()
+        okp = bp.verify_sample(flat, offs, sizes, np.linspace(0, bp.n_streams - 1, num=min(8, bp.n_streams), dtype=np.int64))
+        if not (same and okp):
+            raise SystemExit("sub-record %s: the pipelined decode differs (slots equal %s, oracle %s)" % (name, same, okp))
+        r = {"contexts_in_flight": depth, "value": round(bp.samples * k_steps / dtp / 1e6, 1), "unit": "Msamples/s",
+             "ms_per_step": round(dtp / k_steps * 1e3, 4), "steps": k_steps, "slots_bit_identical": same,
+             "what": "%d decode contexts in flight on their own HIP streams, non-blocking decode call; a step is still "
+                     "one index + one decode of the whole batch" % depth}
+        bp.close()
+        del bp
+        torch.cuda.empty_cache()
+        return r
+
+    def run(name, flat, offs, sizes, frames, nchs, nseg, replicas, layout, lanes, benign=0, note=None, flight=0,
+            chained=False):
         t_run = time.perf_counter()
         b = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, replicas, layout, lanes, nseg)
         dt, kms, launches = b.timed(steps, warmup)
@@ -409,10 +434,13 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         if note:
             rec["note"] = note
         out[name] = rec
-        sys.stderr.write("bench: sub-record %s %.1f s\n" % (name, time.perf_counter() - t_run))
         b.close()
         del b
         torch.cuda.empty_cache()
+        if flight > 1:
+            rec["in_flight"] = in_flight(flight, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign,
+                                         max(steps, 30), name)
+        sys.stderr.write("bench: sub-record %s %.1f s\n" % (name, time.perf_counter() - t_run))
 
     rate = 1
     # ---- planar layout: the order the mlp.h contract appends to `samples`
@@ -518,13 +546,14 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     one = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=512, profile=1, features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(one, 7, 1)
     run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 0,
-        benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 512 access units (the low-parallelism case)")
+        benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 512 access units (the low-parallelism case)", flight=4,
+        chained=True)
     long_one = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=8192, profile=1,
                             features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(long_one, 9, 1)
     run("chained_single_long_title", flat, offs, sizes, frames, np.full(1, 6), 8192 // 8 + 2, 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 8 192 access units (68 s of 96 kHz audio): the filter "
-                                   "pass's serial recurrence is what bounds it")
+                                   "pass's serial recurrence is what bounds it", flight=4, chained=True)
     out["mixed_corpus_c5"] = mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup)
     # ---- BASELINE configs[3] on this GPU: 1 024 independent single-access-unit streams in ONE batch -- the low-
     #      parallelism regime, decoded by the wave-cooperative kernel (csrc/mlp_coop.h); throughput back to back and
@@ -555,8 +584,10 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
                              "what": "one batch: index + decode enqueued and waited for, host clock"},
                  "note": "BASELINE configs[3]: 1 024 independent 6-ch/96 kHz streams of ONE access unit (major sync + "
                          "restart header + raw lead-in), one batch, one GPU; kernel picked by the library (wave-cooperative)"}
-    sys.stderr.write("bench: sub-record c4 %.1f s\n" % (time.perf_counter() - t_run))
     b4.close()
+    out["c4"]["in_flight"] = in_flight(3, flat4, offs4, sizes4, frames4, np.full(1024, 6), 1024, "interleaved", False, 0,
+                                       400, "c4")
+    sys.stderr.write("bench: sub-record c4 %.1f s\n" % (time.perf_counter() - t_run))
     return out
 
 
