@@ -43,9 +43,11 @@ for w in which:
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=128, profile=1, features=SF["CHAINED"])
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
         run(w, flat, offs, sizes, frames, np.full(1024, 6), 1024 * 17, 1, "interleaved")
-    elif w in ("chained1", "chained2"):
-        S = 1 if w == "chained1" else 2
-        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=512, profile=1, features=SF["CHAINED"])
+    elif w in ("chained1", "chained2", "chained1_500", "chained2_500"):
+        # (_500: titles of 500 access units -- the chains' workspaces then do not start at multiples of a power of two)
+        S = 1 if w.startswith("chained1") else 2
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=500 if w.endswith("_500") else 512, profile=1,
+                           features=SF["CHAINED"])
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
         run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 65, 4, "interleaved")
     elif w == "two":
