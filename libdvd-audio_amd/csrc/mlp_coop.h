@@ -45,7 +45,12 @@ namespace mlp {
 constexpr int COOP_THREADS = 128;
 constexpr int COOP_ROWS = 160;                  // PCM frames per access unit at standard timing, at most (192 kHz)
 constexpr int COOP_VSTRIDE = COOP_ROWS + 1;     // s_val[channel][frame]: odd stride, conflict-free both ways
-constexpr int COOP_STAGE_DW = 2048 + 8;         // an access unit is at most 8 190 bytes (12-bit size field)
+// The stage holds an access unit of up to 4 096 bytes: at DVD-Audio's rates a unit carries at most 160 frames x 2
+// channels or 80 x 6 -- under 2 KB of residuals even uncompressed -- and what the 12-bit size field allows beyond that
+// (8 190 bytes) goes to the sequential pass (ST_SEQ).  Twice the stage was 15.3 KB of LDS per workgroup and ten
+// workgroups per CU; with this and the WAV staging bytes inside the stage (free by the time a unit is written out)
+// it is 10 KB and sixteen: four waves per SIMD where a batch has that many segments.
+constexpr int COOP_STAGE_DW = 1024 + 8;
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -150,12 +155,15 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     if (!PARSE && !coop_takes(a))
         return;
     __shared__ uint32_t s_stage[COOP_STAGE_DW];
-    __shared__ int32_t s_val[MAXCH][COOP_VSTRIDE];      // residuals -> filtered values, MLP channel order
+    __shared__ int32_t s_val[6][COOP_VSTRIDE];          // residuals -> filtered values, MLP channel order (channels 0..5:
+                                                        // max_matrix_channel < 6 is checked at the restart header)
     __shared__ uint32_t s_byp[COOP_ROWS];               // bypassed LSBs of the row (last substream's)
     __shared__ CoopSub s_sub[2];
     __shared__ uint32_t s_err[2];
     __shared__ uint32_t s_yield;
-    __shared__ uint8_t s_wav[64 * 6 * 3 + 16];          // packed WAV payload of one output step
+    uint8_t *const s_wav = reinterpret_cast<uint8_t *>(s_stage);    // packed WAV payload of one output step (64 * 6 * 3
+                                                                    // bytes): the unit's bytes are done with by then
+    static_assert(64 * 6 * 3 + 16 <= COOP_STAGE_DW * 4, "the WAV staging bytes fit the stage");
 
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
@@ -271,7 +279,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         const uint32_t bit0 = (uint32_t)(cur & 3u) * 8u;
         const uint32_t hdr = rfl((uint32_t)((((uint64_t)hdr_dw << 32) | hdr_dw1) << bit0 >> 32));
         const uint32_t fsize = 2u * ((hdr >> 16) & 0xFFFu);
-        const uint32_t ndw = (fsize + (uint32_t)(cur & 3u) + 3u) / 4u + 2u;         // + what a peek may touch behind it
+        const uint32_t ndw_all = (fsize + (uint32_t)(cur & 3u) + 3u) / 4u + 2u;     // + what a peek may touch behind it
+        const bool too_big = ndw_all > (uint32_t)COOP_STAGE_DW;                     // (more than the stage holds: not here)
+        const uint32_t ndw = too_big ? (uint32_t)COOP_STAGE_DW : ndw_all;
         for (uint32_t i = tid; i < ndw; i += nthreads)
             s_stage[i] = __builtin_bswap32(reinterpret_cast<const uint32_t *>(a.bytes + base_b)[i]);
         if (two)
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         rd.w = s_stage;
         rd.seek(bit0 + 32u);
         const uint64_t frame_end = cur + fsize;
-        uint32_t err = 0;
+        uint32_t err = too_big ? ST_SEQ : 0u;       // the sequential pass decodes such a stream, in order
         bool dropped = false;
         // ---- major sync: the segment's first unit has one (validated by the index).  Any other unit that carries a
         //      valid one was walked through by the index because its stream parameters differ: the reference drops
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             rd.seek(save);
         }
         uint32_t frame_rows = 0;
-        if (!dropped) {
+        if (!dropped && !too_big) {
             // ---- substream info "1u 1u 1u 1p 12u" (+16p) (src/mlp.c:463-468, 660-667)
             uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0;
             bool bad = false;
