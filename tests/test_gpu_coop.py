@@ -127,3 +127,38 @@ def test_the_library_picks_it_for_small_batches_and_not_for_large_ones(pkg, orac
     for i in range(0, 4200, 97):
         want, r, st = oracle.decode(streams[i], 2, int(frames[i]))
         assert st == 0 and infos[i].status == 0 and np.array_equal(pcm[i], want)
+
+
+def padded_unit(b, which, new_size):
+    """stream `b` with access unit `which` grown to `new_size` bytes by zero bytes behind its last substream (the
+    reference ignores what follows the last substream of a frame, src/mlp.c:463-468: the size field says where the
+    next frame starts)"""
+    pos = 0
+    for _ in range(which):
+        pos += 2 * (((int(b[pos]) & 0x0F) << 8) | int(b[pos + 1]))
+    size = 2 * (((int(b[pos]) & 0x0F) << 8) | int(b[pos + 1]))
+    assert new_size % 2 == 0 and size < new_size <= 8190
+    out = np.concatenate([b[:pos + size], np.zeros(new_size - size, np.uint8), b[pos + size:]])
+    w = new_size // 2
+    out[pos] = (int(b[pos]) & 0xF0) | (w >> 8)
+    out[pos + 1] = w & 0xFF
+    return out
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_an_access_unit_larger_than_the_stage(pkg, oracle, coop, S):
+    """The kernel stages an access unit of up to 4 KB in LDS; the 12-bit size field allows 8 190 bytes.  Such a unit
+    (here: padded behind its last substream) sends the stream to the sequential pass: same PCM, DVDA_ST_SEQ set."""
+    syn, hip = pkg.synth, pkg.hipdec
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=24)
+    streams = []
+    for i, (which, size) in enumerate([(5, 4200), (0, 6000), (23, 8190), (9, 4090)]):
+        b, f = syn.stream(cfg, 4400 + i)
+        streams.append((padded_unit(b, which, size), f, size))
+    pcm, infos = hip.decode_streams([b for b, _, _ in streams])
+    for (b, f, size), got, inf in zip(streams, pcm, infos):
+        want, r, st = oracle.decode(b, 6, f)
+        assert st == 0 and r == f
+        assert inf.status & ~hip.ST_BENIGN == 0 and inf.pcm_frames == f
+        assert bool(inf.status & hip.ST["SEQ"]) == (size > 4096)
+        assert np.array_equal(got, want)
