@@ -580,6 +580,609 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
 }
 
+// ---------------------------------------------------------------------------------- filter + rematrix, fused
+// Round 4.  The filter pass above leaves a channel's filtered values where its residuals were (10.8 GB of plane
+// lines read and written per bench-size batch) and the rematrix pass reads them again (5.4 GB) to write 4 GB of
+// PCM: three of the four transfers are the planes going round.  k_chain_fused walks a chain's planes ONCE and
+// writes PCM once.  A workgroup is two waves and eight chains:
+//
+//   wave 0, the FILTER wave: lane p of a chain loads piece p of every 128-byte plane line (pieces 0..5: four PCM
+//     frames of channel p's residuals, 6: their bypassed LSBs, 7: their noise seeds -- a chain's eight lanes take
+//     whole lines), FU_DEPTH units of eight PCM frames in flight per lane; lanes 0..5 run the recursion of their
+//     channel over the unit (fir_step8, a block's parameters waiting in registers from the block before it on:
+//     k_chain_filter's scheme) and put it, [plane][frame], into one of two exchange tiles in LDS, with a header:
+//     where the unit goes in the output, which access-unit record it is rematrixed with;
+//   wave 1, the OUTPUT wave: lane f of a chain takes PCM frame f of the unit the filter wave left in the OTHER tile
+//     one turn earlier -- its six channels, bypassed LSBs, noise seed --, rematrixes it with the record of the
+//     frame's access unit (src/mlp.c:504-525: the parameters the unit's LAST block left), shifts, orders
+//     (src/mlp.c:416-438, 527-533) and stores: a unit leaves as 192 contiguous bytes (six channels, frame-major).
+//
+// One LDS-only barrier per unit (s_waitcnt lgkmcnt(0); s_barrier: the filter wave's loads in flight are not waited
+// for) hands a tile over; the two halves of a unit's work -- ~110 wave-instructions each, both latency-bound
+// dependency chains on a wave that has its SIMD to itself -- run side by side on two SIMDs instead of one after
+// the other on one (the first, single-wave version of this kernel: 10.9 ms against 6.5 for the two passes).
+// The output wave loads NOTHING from global memory: the access-unit records reach LDS by the filter wave's
+// global_load_lds (gfx950's direct-to-LDS load: no register, so no wait is ever inserted for it), issued two
+// access units ahead of their use; completion is implied by program order -- the filter wave has since waited for
+// plane loads it issued later, and loads return in order.
+// The filter wave's loop is FLAT: every turn every live chain does one unit, and what happens between two units --
+// a segment ends, the next one is set up, the unit pipeline is refilled -- happens between two barriers, so both
+// waves count the same turns whatever the chains of the group look like.
+constexpr int FU_DEPTH = 8;         // units of eight PCM frames a filter lane keeps in flight (a power of two)
+constexpr int FU_XS = 72;           // dwords of exchange tile per chain: 8 planes x 8 frames, + 8 so that the chains of a
+                                    // half-wave fall on different LDS banks
+constexpr int FU_THREADS = 128;
+constexpr int FU_RECS = 4;          // access-unit records per chain in LDS (ring by record number)
+constexpr uint32_t FU_DONE = 0xD0E5u;
+
+// 16 bytes per lane from `src` (per lane) straight into LDS at lds_base + lane * 16 (gfx950's global_load_lds; lds_base
+// is wave-uniform: it travels in M0).  Inline asm on purpose: a load the compiler knows of makes it wait -- vmcnt(0) --
+// in front of every LDS access that might alias the target, i.e. once per turn, and the ring would be empty before
+// each unit.  Unknown to the compiler, these loads only make ITS waits more conservative (they sit in the same in-order
+// queue), and the one wait that matters for them is written out where the ring is read.
+__device__ __forceinline__ uint32_t fu_lds(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// "this value is used here": a loaded value the compiler has not waited for yet is waited for at this point, not at
+// some later turn of the loop (where its wait would also stand in front of everything the ring has in flight)
+template <class T>
+__device__ __forceinline__ void fu_use(T &v)
+{
+    asm volatile("" : "+v"(v));
+}
+__device__ __forceinline__ void fu_dma16(const void *src, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory", "m0");
+}
+
+__global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chain_fused(ChainArgs a)
+{
+    __shared__ int32_t s_x[2][8 * FU_XS];
+    __shared__ uint4 s_hdr[2][8];                   // per tile and chain: valid | new record << 1, record ring slot, output row (64 bit)
+    __shared__ uint32_t s_ctl[2];                   // per tile: FU_DONE when the filter wave is through
+    __shared__ uint32_t s_rec[FU_RECS][64][4];      // access-unit records, words 0..31 (lane cl * 8 + j holds words 4j..4j+3)
+    __shared__ uint32_t s_rec2[FU_RECS][64][4];     // ... words 32..35 (lane cl * 8 holds them)
+    __shared__ uint32_t s_b[8][8 * 6 * 3 / 4];      // packed WAV payload of a unit, per chain: 8 frames x 18 bytes at most
+    __shared__ int4 s_ring[FU_DEPTH][2][64];        // the filter wave's units in flight: ring place, line of the unit, lane
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cl = lane >> 3, p = lane & 7u;   // chain of the group; plane (filter wave) / PCM frame of the unit (output wave)
+    const uint32_t ci = blockIdx.x * 8u + cl;
+    const uint32_t n = chain_n_seg(a);
+    const uint32_t n_chains = a.plan[n].z;
+    if (blockIdx.x * 8u >= n_chains)
+        return;                                     // (the whole workgroup: no barrier is left waiting)
+    if (threadIdx.x < 2)
+        s_ctl[threadIdx.x] = 0;
+    if (threadIdx.x < 16)
+        (&s_hdr[0][0])[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    bool alive = ci < n_chains;
+    uint32_t seg = alive ? DVDA_AT(a.head_list, ci, a.caps.max_seg, BT_C_HEAD) : 0u;
+    const SegRec r0 = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
+    const StreamRec sr = DVDA_AT(a.streams, r0.stream, a.caps.max_streams, BT_STREAMS);
+    const uint32_t S = (sr.sync >> 24) & 0xFu;
+    const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
+    const uint32_t assignment = (sr.sync >> 16) & 0x1F;
+    const uint32_t nch_out = channel_count(assignment);
+    if (S == 0 || S > 2 || rpa == 0 || nch_out == 0)
+        alive = false;
+
+    if (wv == 1) {
+        // ================================================================================ the output wave
+        const uint32_t wavepk = wave_pack(assignment);
+        const uint64_t out_stride = a.out_stride[r0.stream];
+        int32_t *const out = a.pcm + a.out_off[r0.stream];
+        const bool direct6 = a.interleaved && !a.wav_bits && nch_out == 6u && (wavepk & 0xFFFFFFu) == 0x543210u &&
+                             (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+        uint32_t fw0 = 0, f_outch = 0, f_qss = 0, f_oshift = 0, f_rec = 0;
+        int32_t mc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};     // matrices 0 and 1: six channels + the two noise taps
+        for (uint32_t j = 0;; j++) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const uint32_t t = j & 1u;
+            if (s_ctl[t] == FU_DONE)
+                break;
+            const uint4 hd = s_hdr[t][cl];
+            if (!(hd.x & 1u))
+                continue;
+            const int32_t *const X = s_x[t] + cl * FU_XS;
+            int32_t ch[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                ch[q] = X[q * 8 + p];
+            const uint32_t bypass_bits = (uint32_t)X[6 * 8 + p];
+            const uint32_t seed = (uint32_t)X[7 * 8 + p];
+            if (p == 0)
+                s_hdr[t][cl].x = 0;                 // taken (a chain that pauses leaves no unit here next time)
+            if (hd.x & 2u) {
+                // ---- the unit opens an access unit: its record from the ring slot the filter wave names
+                f_rec = hd.y & (FU_RECS - 1);
+                const uint32_t *R0 = &s_rec[f_rec][cl * 8u][0];
+                fw0 = R0[0];
+                f_outch = R0[1];
+                f_qss = R0[2];
+                f_oshift = R0[3];
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t w = R0[4 + m * 5 + q];
+                        mc[m][2 * q] = lo16(w);
+                        mc[m][2 * q + 1] = hi16(w);
+                    }
+                }
+                // (words 6, 7 of a matrix's eight: channels 6 and 7 do not exist here -- max_matrix_channel < 6 is
+                //  checked at the restart header -- so those two places carry the matrix's noise taps instead)
+                mc[0][6] = lo16(R0[8]);
+                mc[0][7] = hi16(R0[8]);
+                mc[1][6] = lo16(R0[13]);
+                mc[1][7] = hi16(R0[13]);
+            }
+            const uint32_t noise_shift = fw0 & 0xFFu, matrix_len = (fw0 >> 8) & 0xFFu, mmc = fw0 >> 16;
+            const uint32_t shifted = (seed >> 7) & 0xFFFFu;
+            const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
+            const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
+            auto place = [&](int64_t acc, uint32_t m) {
+                const uint32_t oc = nib(f_outch, m);
+                const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(f_qss, oc)) + ((bypass_bits >> m) & 1u));
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    ch[q] = (uint32_t)q == oc ? nv : ch[q];
+            };
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                if (matrix_len > (uint32_t)m) {
+                    int64_t acc = (int64_t)n0 * (int64_t)mc[m][6] + (int64_t)n1 * (int64_t)mc[m][7];
+#pragma unroll
+                    for (int q = 0; q < 6; q++)
+                        acc += (int64_t)ch[q] * (int64_t)mc[m][q];
+                    place(acc, (uint32_t)m);
+                }
+            }
+            for (uint32_t m = 2; m < matrix_len; m++) {             // (rare: more than the two matrices discs carry)
+                uint32_t M[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const uint32_t wd = 4u + m * 5u + (uint32_t)q;
+                    M[q] = wd < 32u ? s_rec[f_rec][cl * 8u + (wd >> 2)][wd & 3u] : s_rec2[f_rec][cl * 8u][wd & 3u];
+                }
+                int64_t acc = (int64_t)n0 * (int64_t)lo16(M[4]) + (int64_t)n1 * (int64_t)hi16(M[4]);
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    acc += (int64_t)ch[q] * (int64_t)((q & 1) ? hi16(M[q >> 1]) : lo16(M[q >> 1]));
+                place(acc, m);
+            }
+            if (f_oshift) {
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if ((uint32_t)q <= mmc)
+                        ch[q] = (int32_t)((uint32_t)ch[q] << nib(f_oshift, q));
+            }
+            // ---- RIFF order and the four PCM layouts
+            const uint64_t urow = ((uint64_t)hd.w << 32) | hd.z;            // the unit's first output row
+            const uint64_t orow = urow + p;
+            if (a.wav_bits) {
+                const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
+                uint8_t *const sb = reinterpret_cast<uint8_t *>(s_b[cl]);
+#pragma unroll
+                for (int q = 0; q < 6; q++)
+                    if ((uint32_t)q < nch_out) {
+                        const uint32_t v = wav_signed(ch[q], a.wav_bits);
+                        uint8_t *e = sb + p * spf + nib(wavepk, q) * nb;
+                        e[0] = (uint8_t)v;
+                        e[1] = (uint8_t)(v >> 8);
+                        if (nb == 3u)
+                            e[2] = (uint8_t)(v >> 16);
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t nvalid = urow >= out_stride ? 0u : (out_stride - urow < 8u ? (uint32_t)(out_stride - urow) : 8u);
+                const uint32_t ndw = nvalid * spf >> 2;                     // (8 frames are a whole number of dwords)
+                uint32_t *const od = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + urow * spf);
+                for (uint32_t d = p; d < ndw; d += 8u)
+                    od[d] = s_b[cl][d];
+                for (uint32_t bb = (ndw << 2) + p; bb < nvalid * spf; bb += 8u)   // (the capacity ends inside the unit)
+                    reinterpret_cast<uint8_t *>(od)[bb] = sb[bb];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else if (orow < out_stride) {
+                if (direct6) {
+                    int2 *dst = reinterpret_cast<int2 *>(out + orow * 6u);
+                    dst[0] = make_int2(ch[0], ch[1]);
+                    dst[1] = make_int2(ch[2], ch[3]);
+                    dst[2] = make_int2(ch[4], ch[5]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 6; q++)
+                        if ((uint32_t)q < nch_out)
+                            out[a.interleaved ? orow * nch_out + nib(wavepk, q) : (uint64_t)nib(wavepk, q) * out_stride + orow] = ch[q];
+                }
+            }
+        }
+        return;
+    }
+
+    // ==================================================================================== the filter wave
+    const size_t TL = a.total_lanes;
+    uint64_t out_stride = a.out_stride[r0.stream];
+    int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t ih[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t ic[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool iir = false;
+    uint32_t shift = 0, qmask = 0xFFFFFFFFu;
+    uint32_t prev_meta0 = 0, prev_meta1 = 0;                // channel ranges of the segment the histories come from
+    // which substream and slot plane p belongs to in a segment whose substreams carry meta0 / meta1
+    auto slot_of = [&](uint32_t m0, uint32_t m1, uint32_t &sub, uint32_t &k) {
+        const uint32_t lo1 = m1 & 0xFu;
+        sub = (S == 2u && p >= lo1) ? 1u : 0u;
+        const uint32_t m = sub ? m1 : m0;
+        const uint32_t lo = m & 0xFu, hi = (m >> 4) & 0xFu;
+        k = p - lo;
+        return p < 6u && p >= lo && p <= hi;
+    };
+    auto stop_chain = [&](uint32_t why) {                   // the chain ends here: what follows cannot be decoded by this pass
+        if (p == 0 && why != ST_SEQ)                        // (ST_SEQ needs nothing: the whole stream is decoded again, in order)
+            atomicOr(&a.seg_status[seg], why & ~ST_INFO);
+        alive = false;
+    };
+    if (alive) {
+        // ---- the history the chain starts from (k_chain_filter's rules)
+        const uint32_t ss0 = a.seg_status[seg];
+        if (ss0 & ST_CHAINED) {
+            uint32_t m0 = DVDA_AT(a.seg_meta, (size_t)seg * 2, a.caps.lanes, BT_C_META);
+            uint32_t m1 = S == 2u ? DVDA_AT(a.seg_meta, (size_t)seg * 2 + 1, a.caps.lanes, BT_C_META) : 0u;
+            fu_use(m0);
+            fu_use(m1);
+            uint32_t sub, k;
+            const bool mine = slot_of(m0, m1, sub, k);
+            if (seg == sr.first_seg) {
+                if (a.init_fir) {
+                    if (mine) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            h[j] = a.init_fir[((size_t)r0.stream * 2 + sub) * 48 + k * 8 + j];
+                    }
+                } else {
+                    stop_chain(ST_ENVELOPE);     // FIR taps on a fresh decoder: the reference reads out of bounds
+                }
+            } else {
+                const uint32_t pv = chain_prev_live(a, seg, sr.first_seg);
+                const uint32_t ps = a.seg_status[pv] | (a.seg[pv].flags & ST_FATAL_INDEX);
+                prev_meta0 = a.seg_meta[(size_t)pv * 2];
+                prev_meta1 = S == 2u ? a.seg_meta[(size_t)pv * 2 + 1] : 0u;
+                if ((ps & ~ST_INFO) || (ps & ST_CHAIN) || !(prev_meta0 & 0x100u) || (S == 2u && !(prev_meta1 & 0x100u))) {
+                    stop_chain((ps & ~ST_INFO) ? (ps & ~ST_INFO) : ST_ENVELOPE);     // nothing to continue from
+                } else {
+                    uint32_t psub, pk;
+                    if (slot_of(prev_meta0, prev_meta1, psub, pk)) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            h[j] = a.fir_ws[(size_t)(pk * 8 + j) * TL + (size_t)pv * 2 + psub];
+                    }
+                }
+            }
+        }
+    }
+
+    // (nothing loaded so far is still on its way when the turns begin: a load the compiler has not seen used makes it
+    //  wait, with vmcnt(0), wherever a later turn reuses the register -- in front of everything the ring has in flight)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        fu_use(h[j]);
+    fu_use(prev_meta0);
+    fu_use(prev_meta1);
+    fu_use(out_stride);
+    fu_use(seg);
+    // ---- the segment in work
+    bool run = false;                       // units of it are left
+    uint32_t u = 0, nu = 0;
+    const int4 *Q = nullptr;                // line l, piece p: Q[l * 8]
+    const uint32_t *F0 = nullptr;           // its access units' records
+    uint32_t n_au = 0, recno = 0;           // record ring: number of the record of the segment's first access unit
+    uint64_t row0 = 0;
+    uint32_t sub = 0, k = 0, meta0 = 0, meta1 = 0;
+    bool filt = false, seg_iir = false, overrun = false;
+    const uint32_t *rp = nullptr, *rp_end = nullptr;
+    uint32_t left = 0xFFFFFFFFu, nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nw4 = 0, tgt = 0;
+    bool n_has = false;
+    uint32_t srow = 0, next_row = 0xFFFFFFFFu;      // IIR segments: frame by frame
+
+    auto preload = [&](uint32_t row_now) __attribute__((always_inline)) {
+        overrun = overrun || rp >= rp_end;
+        const uint32_t nr = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
+        n_has = false;
+        tgt = nr;
+        left = nr - row_now;                                  // (terminator: 0xFFFFFFFF, never reached)
+        if (nr != 0xFFFFFFFFu) {
+            const uint32_t m = rp[1];
+            const uint32_t mask = m & 0xFFu, imask = (m >> 8) & 0xFFu;
+            const uint32_t below = (1u << k) - 1u;
+            const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) + BREC_IIR_WORDS * __popc(imask & below);
+            if ((mask >> k) & 1u) {
+                n_has = true;
+                nw0 = w[0];
+                nw1 = w[1];
+                nw2 = w[2];
+                nw3 = w[3];
+                nw4 = w[4];
+            }
+            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
+        }
+        // (the record waits in registers from here on: loaded now, not "some time before it is applied")
+        fu_use(nw0);
+        fu_use(nw1);
+        fu_use(nw2);
+        fu_use(nw3);
+        fu_use(nw4);
+        fu_use(left);
+        fu_use(tgt);
+    };
+    auto apply = [&]() __attribute__((always_inline)) {
+        if (n_has) {
+            shift = nw0 & 0xFu;
+            qmask = 0xFFFFFFFFu << ((nw0 >> 4) & 0xFu);
+            c[0] = lo16(nw1);
+            c[1] = hi16(nw1);
+            c[2] = lo16(nw2);
+            c[3] = hi16(nw2);
+            c[4] = lo16(nw3);
+            c[5] = hi16(nw3);
+            c[6] = lo16(nw4);
+            c[7] = hi16(nw4);
+        }
+        preload(tgt);
+    };
+    // IIR segments: a block that sets filter parameters starts at `srow` (src/mlp.c:1033-1068, 1260-1270)
+    auto apply_records = [&]() __attribute__((always_inline)) {
+        while (next_row == srow) {
+            if (rp >= rp_end) {
+                overrun = true;
+                next_row = 0xFFFFFFFFu;
+                break;
+            }
+            const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
+            if ((mask >> k) & 1u) {
+                const uint32_t below = (1u << k) - 1u;
+                const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) + BREC_IIR_WORDS * __popc(imask & below);
+                const uint32_t pk = w[0];
+                shift = pk & 0xFu;
+                qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    c[2 * j] = lo16(w[1 + j]);
+                    c[2 * j + 1] = hi16(w[1 + j]);
+                }
+                if (pk & (1u << 16)) {
+                    iir = ((pk >> 12) & 0xFu) != 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        ic[2 * j] = iir ? lo16(w[5 + j]) : 0;
+                        ic[2 * j + 1] = iir ? hi16(w[5 + j]) : 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        ih[j] = iir ? (int32_t)w[9 + j] : 0;
+                }
+            }
+            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
+            next_row = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
+            overrun = overrun || rp >= rp_end;
+        }
+    };
+    auto slow_step = [&](int32_t residual) __attribute__((always_inline)) {
+        apply_records();
+        const int32_t v = iir ? iir_step_one(h, c, ih, ic, shift, qmask, residual) : fir_step_one(h, c, shift, qmask, residual);
+        srow++;
+        return v;
+    };
+    // the recursion over one unit of this lane's channel
+    auto filter_unit = [&](int4 &x, int4 &y) __attribute__((always_inline)) {
+        if (!filt)
+            return;
+        if (__builtin_expect(seg_iir, 0)) {
+            x.x = slow_step(x.x);
+            x.y = slow_step(x.y);
+            x.z = slow_step(x.z);
+            x.w = slow_step(x.w);
+            y.x = slow_step(y.x);
+            y.y = slow_step(y.y);
+            y.z = slow_step(y.z);
+            y.w = slow_step(y.w);
+            return;
+        }
+        if (left == 0)
+            apply();
+        if (left >= 8u) {
+            fir_step8(h, c, shift, qmask, x, y);
+            left -= 8u;
+        } else {
+            // a block starts inside the unit (test streams; encoders cut blocks at multiples of eight frames)
+            auto one = [&](int32_t residual) __attribute__((always_inline)) {
+                while (left == 0)
+                    apply();
+                left--;
+                return fir_step_one(h, c, shift, qmask, residual);
+            };
+            x.x = one(x.x);
+            x.y = one(x.y);
+            x.z = one(x.z);
+            x.w = one(x.w);
+            y.x = one(y.x);
+            y.y = one(y.y);
+            y.z = one(y.z);
+            y.w = one(y.w);
+        }
+    };
+    // access unit `au` of the segment, record number recno + au: into its ring slot, straight from memory
+    // (the slot differs from chain to chain, the LDS base of one load instruction cannot: one instruction per slot value)
+    auto dma_rec = [&](uint32_t au) {
+        const uint32_t slot = (recno + au) & (FU_RECS - 1);
+        const uint32_t *src = F0 + (size_t)au * FREC_WORDS + p * 4u;
+#pragma unroll
+        for (int b = 0; b < FU_RECS; b++) {
+            if (au < n_au && slot == (uint32_t)b) {
+                fu_dma16(src, fu_lds(&s_rec[b][0][0]));
+                if (p == 0)
+                    fu_dma16(src + 32, fu_lds(&s_rec2[b][0][0]));
+            }
+        }
+    };
+    // unit w of the segment (the last one again past its end: the count of loads in flight stays what the wait
+    // below assumes) into ring place `place` -- wave-uniform: the ring is indexed by the turn
+    auto dma_unit = [&](uint32_t w, uint32_t place) {
+        const int4 *N = Q + (size_t)(w < nu ? w : nu - 1u) * 16u;
+        fu_dma16(N, fu_lds(&s_ring[place][0][0]));          // (no instruction offset: it would move the LDS address too)
+        fu_dma16(N + 8, fu_lds(&s_ring[place][1][0]));
+    };
+
+    uint32_t turn = 0;                      // wave-uniform: every lane takes every turn
+    for (;;) {
+        {
+            const uint32_t t = turn & 1u;
+            const uint32_t place = __builtin_amdgcn_readfirstlane(turn) & (uint32_t)(FU_DEPTH - 1);
+            if (run) {
+                // ---- one unit.  Its two lines were asked for FU_DEPTH turns ago (or by the segment's set-up) and every
+                //      turn since has asked for two more: all but the 2 (FU_DEPTH - 1) newest loads of this wave done
+                //      means they are there (loads return in order; whatever else the wave loaded or stored in between
+                //      only makes them older)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (FU_DEPTH - 1)) : "memory");
+                int4 xa = s_ring[place][0][lane], xb = s_ring[place][1][lane];
+                filter_unit(xa, xb);
+                int32_t *const X = s_x[t] + cl * FU_XS;
+                reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
+                reinterpret_cast<int4 *>(X + p * 8)[1] = xb;
+                const uint32_t row = u * 8u;
+                const uint32_t au = row / rpa;
+                const bool opens = au * rpa == row;
+                if (p == 0) {
+                    const uint64_t urow = row0 + row;
+                    s_hdr[t][cl] = make_uint4(1u | (opens ? 2u : 0u), (recno + au) & (FU_RECS - 1), (uint32_t)urow, (uint32_t)(urow >> 32));
+                }
+                if (opens)
+                    dma_rec(au + 2u);       // two access units ahead: there when the output wave opens that unit
+                dma_unit(u + (uint32_t)FU_DEPTH, place);
+                u++;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            turn++;
+            if (run && u == nu) {
+                // ---- the segment is through: its history (what a later call, or the next chain, continues from), its status
+                run = false;
+                if (filt) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        a.fir_ws[(size_t)(k * 8 + j) * TL + (size_t)seg * 2 + sub] = h[j];
+                }
+                const bool any_over = ((__ballot(overrun) >> (lane & 56u)) & 0xFFull) != 0;
+                if (p == 0)
+                    atomicOr(&a.seg_status[seg], any_over ? ST_CAPACITY : ST_GENERAL);      // decoded -- or a records walk that left its records
+                prev_meta0 = meta0;
+                prev_meta1 = meta1;
+                recno += n_au;
+                // ---- on to the next segment of the stream while it continues this history
+                uint32_t nxt = seg + 1;
+                while (nxt < n && a.seg[nxt].stream == r0.stream && (a.seg[nxt].flags & SEG_DEAD))
+                    nxt++;
+                if (any_over || nxt >= n || a.seg[nxt].stream != r0.stream) {
+                    alive = false;
+                } else {
+                    const uint4 pn = a.plan[nxt], qn = a.plan[nxt + 1];
+                    if (qn.y == pn.y || qn.z != pn.z)
+                        alive = false;                  // not deferred, or the head of the next chain
+                    else
+                        seg = nxt;
+                }
+            }
+            if (alive && !run) {
+                // ---- set the segment up (between two barriers: the output wave sees no unit of this chain meanwhile)
+                const SegRec r = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
+                const uint32_t ss = a.seg_status[seg];
+                meta0 = DVDA_AT(a.seg_meta, (size_t)seg * 2, a.caps.lanes, BT_C_META);
+                meta1 = S == 2u ? DVDA_AT(a.seg_meta, (size_t)seg * 2 + 1, a.caps.lanes, BT_C_META) : 0u;
+                uint32_t fail = 0;
+                if (ss & ~ST_INFO)
+                    fail = ss & ~ST_INFO;               // the parse pass stopped on an error here
+                else if ((ss & (ST_TIMING | ST_SEQ)) || !(meta0 & 0x100u) || (S == 2u && !(meta1 & 0x100u)))
+                    fail = ST_SEQ;                      // the sequential pass takes the stream
+                else if ((ss & ST_CHAINED) && ((prev_meta0 && ((prev_meta0 ^ meta0) & 0xFFu)) ||
+                                               (S == 2u && prev_meta1 && ((prev_meta1 ^ meta1) & 0xFFu))))
+                    fail = ST_ENVELOPE;                 // a substream's channel range changes under a running history
+                const uint32_t R = (r.nframes - r.ndrop) * rpa;
+                const uint4 pl = DVDA_AT(a.plan, seg, a.caps.max_seg + 1u, BT_C_PLAN);
+                if (!fail && (R == 0 ||
+                              !DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES) ||
+                              !DVDA_RANGE_OK((size_t)(pl.x / 40u) * FREC_WORDS, (size_t)(r.nframes - r.ndrop) * FREC_WORDS, a.caps.frec, BT_C_FREC)))
+                    fail = ST_CAPACITY;
+                if (fail) {
+                    stop_chain(fail);
+                } else {
+                    filt = slot_of(meta0, meta1, sub, k);
+                    seg_iir = ((meta0 | meta1) & 0x200u) != 0;       // (chain-uniform: every lane goes frame by frame then)
+                    row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
+                    if (p == 0) {
+                        a.seg_rows[seg] = R;
+                        if (row0 + R > out_stride)
+                            atomicOr(&a.seg_status[seg], ST_OVERFLOW);          // rows = the size needed
+                    }
+                    Q = reinterpret_cast<const int4 *>(a.res + (size_t)pl.x * 8u) + p;
+                    F0 = a.frec + (size_t)(pl.x / 40u) * FREC_WORDS;
+                    n_au = r.nframes - r.ndrop;
+                    rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
+                    // (the parse pass ends a substream's records with a terminator inside its brec_capacity(R) words; a
+                    //  walk that gets there without meeting it stops, and the segment is reported)
+                    rp_end = (a.brec + a.caps.brec) - (rp + brec_capacity(R)) >= 0 ? rp + brec_capacity(R) - 1
+                                                                                  : a.brec + (a.caps.brec ? a.caps.brec - 1 : 0);
+                    nu = R >> 3;                        // (a segment is a whole number of 40-frame access units)
+                    u = 0;
+                    overrun = false;
+                    left = 0xFFFFFFFFu;
+                    srow = 0;
+                    next_row = 0xFFFFFFFFu;
+                    if (filt) {
+                        if (seg_iir)
+                            next_row = rp[0];
+                        else
+                            preload(0);
+                    }
+                    // the first two access units' records, then the unit pipeline: unit w of the segment is taken in
+                    // turn (turn + w), i.e. from ring place (turn + w) % FU_DEPTH -- the ring is indexed by the turn, so a
+                    // chain that starts a segment joins the ring at the phase the wave is in
+                    dma_rec(0);
+                    dma_rec(1);
+                    {
+                        const uint32_t t0 = __builtin_amdgcn_readfirstlane(turn);
+#pragma unroll
+                        for (int w = 0; w < FU_DEPTH; w++)
+                            dma_unit((uint32_t)w, (t0 + (uint32_t)w) & (uint32_t)(FU_DEPTH - 1));
+                    }
+                    run = true;
+                    // (everything the set-up loaded is in its registers when the turns go on)
+                    fu_use(row0);
+                    fu_use(nu);
+                    fu_use(n_au);
+                    fu_use(meta0);
+                    fu_use(meta1);
+                    fu_use(sub);
+                    fu_use(k);
+                    fu_use(prev_meta0);
+                    fu_use(prev_meta1);
+                    fu_use(seg);
+                }
+            }
+        }
+        if (!__any(alive))
+            break;
+    }
+    if (lane == 0)
+        s_ctl[turn & 1u] = FU_DONE;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------- rematrix
 // One lane per PCM frame of a deferred segment: noise, matrices, output shift (src/mlp.c:1308-1358, 515-525),
 // RIFF channel order (src/mlp.c:416-438, 527-533).  grid = (deferred segments, ceil(longest segment / 256)).

@@ -230,6 +230,14 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     }
     if (threadIdx.x < 2)
         s_err[threadIdx.x] = 0;
+    // (channels no substream of the stream covers -- a gap between the two substreams, fewer coded channels than the
+    //  assignment has -- reach the rematrix and the planes as zeros, the same on every run, not as what an earlier
+    //  workgroup left in LDS; every wave that stays clears the whole tile, the barrier below orders it for two)
+    for (uint32_t i = lane; i < 6u * COOP_VSTRIDE; i += 64u)
+        (&s_val[0][0])[i] = 0;
+    for (uint32_t i = lane; i < (uint32_t)COOP_ROWS; i += 64u)
+        s_byp[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (two)
         __syncthreads();
 

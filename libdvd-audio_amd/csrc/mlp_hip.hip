@@ -883,6 +883,11 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
                                    dim3(DEC_THREADS), 0, st, a);
             }
         }
+        static const bool split = getenv("DVDA_CHAIN_SPLIT") && atoi(getenv("DVDA_CHAIN_SPLIT")) != 0;
+        if (!split) {
+            // filter + rematrix in one walk over the planes: two waves per eight chains (at most one chain per deferred segment)
+            hipLaunchKernelGGL(k_chain_fused, dim3((unsigned)(((uint64_t)segs + 7) / 8)), dim3(FU_THREADS), 0, st, ca);
+        } else {
         // filter: 16 lanes per chain (at most one chain per deferred segment)
         hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);
         // rematrix: one lane per PCM frame
@@ -890,6 +895,7 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         //  the walk between several workgroups)
         ca.remat_blocks = (max_rows + 4095) / 4096 ? (max_rows + 4095) / 4096 : 1;
         hipLaunchKernelGGL(k_chain_rematrix, dim3(segs * ca.remat_blocks), dim3(256), 0, st, ca);
+        }
         HIP_TRY(hipMemsetAsync(&c->d_summary->seq_streams, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);

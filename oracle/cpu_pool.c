@@ -78,9 +78,9 @@ static void *worker(void *arg)
 #endif
             if (r != (long)p->frames)
                 atomic_store(&p->failed, 1);
-            /* (a decode still running at the deadline is not counted: it would add to `done` without its time) */
-            if (idx < p->n || now_s() <= p->deadline)
-                atomic_fetch_add(&p->done, 1);
+            /* (every finished decode counts, also one that was running at the deadline: *seconds is taken after
+               the threads have joined, so its time is in the denominator too -- counted and timed together) */
+            atomic_fetch_add(&p->done, 1);
         }
     }
     free(scratch);
