@@ -7,14 +7,16 @@
 //
 //   parse    k_decode<.., PARSE>   one lane per deferred (segment, substream), all in parallel: the bitstream
 //            (mlp_decode.h)        parse with everything but the filter -- residuals, bypassed LSBs and noise
-//                                  seeds into eight planes per segment, the filter parameters of every block
-//                                  that sets them into block records, the rematrix parameters each access unit
+//            or k_coop<PARSE>      seeds into eight planes per segment, the filter parameters of every block
+//            (mlp_coop.h)          that sets them into block records, the rematrix parameters each access unit
 //                                  ends with into one record per unit
-//   filter   k_chain_filter        one lane per (chain, substream, channel): the recursion and nothing else,
-//                                  through every segment of the chain, in place on the channel's plane
-//   rematrix k_chain_rematrix      one lane per PCM frame: noise, matrices, output shift, RIFF order -- per
-//                                  access unit with the parameters its LAST block left (src/mlp.c:504-525), which
-//                                  is also what a segment with mid-frame parameter changes (ST_MIDFRAME) needs
+//   filter + k_chain_fused         eight chains per two-wave workgroup, the planes walked ONCE: the filter wave runs
+//   rematrix                       the recursion (one lane per channel, through every segment of the chain), the
+//                                  output wave, one unit of eight PCM frames behind it, does noise, matrices,
+//                                  output shift and RIFF order -- per access unit with the parameters its LAST
+//                                  block left (src/mlp.c:504-525), which is also what a segment with mid-frame
+//                                  parameter changes (ST_MIDFRAME) needs -- and writes the PCM.  (Rounds 2 and 3:
+//                                  two passes, k_chain_filter in place on the planes and k_chain_rematrix behind it.)
 //
 // k_chain_plan + a 3-channel scan + k_chain_lists lay out the workspaces and list the deferred segments and
 // the chain heads.  Streams with non-standard timing, IIR taps or restart headers inside a frame go to the
@@ -38,6 +40,8 @@ struct ChainArgs {
     uint4 *plan;                   // [max_seg + 1]: exclusive scan of (rows, deferred, heads, 0); [n] = totals
     uint32_t *def_list;            // deferred segments, in order
     uint32_t *head_list;           // first segment of every chain
+    uint32_t *chain_order;         // the chains, longest first (k_chain_hist / k_chain_scan / k_chain_scatter)
+    uint32_t *chain_hist;          // [2 * CHAIN_BUCKETS]: chains per length class, then where each class starts / fills
     int32_t *res;
     const uint32_t *brec;
     const uint32_t *frec;
@@ -49,8 +53,8 @@ struct ChainArgs {
     const uint64_t *out_stride;
     uint32_t interleaved;
     uint32_t wav_bits;             // 0, or 16 / 24: packed WAV payload instead of int32 values
-    uint32_t remat_blocks;         // k_chain_rematrix: workgroups per segment (1 unless segments are very long)
     WsCaps caps;                   // what the workspaces hold (block-record walks stop there; the range-checked build)
+    unsigned long long *dbg;       // diagnostic builds only (DVDA_EXP_STAMP): per-phase cycle sums of k_chain_fused
 };
 
 __device__ __forceinline__ uint32_t chain_n_seg(const ChainArgs &a)
@@ -249,6 +253,72 @@ __device__ __forceinline__ int32_t iir_step_one(int32_t (&h)[8], const int32_t (
     return v;
 }
 
+// Eight steps of the recursion for a lone wave.  fir_step_rot's sum is ONE chain of eight dependent 64-bit multiply-adds,
+// and a wave that has its SIMD to itself issues in order and waits out every one of them: ~900 cycles per unit of eight
+// PCM frames (measured, round 4: half of what the filter wave of k_chain_fused did with its time).  Only the tap on
+// the newest value depends on the step before.  So a step is cut in two: its TAIL -- the newest tap onto partial sum A,
+// plus partial sum B, shift, plus residual, mask: five dependent instructions -- and the two partial sums of the NEXT
+// step (taps 1, 3, 5, 7 and 2, 4, 6: nothing of them depends on the value the tail is producing), and the two are
+// dealt out alternately, so that no instruction needs the result of the one right before it.  The order is pinned by
+// empty volatile asm statements every value passes through (left to itself the optimizer sorts the sum back into one
+// chain, and the scheduler keeps each chain together).
+#define FU_PIN(v) asm volatile("" : "+v"(v))
+__device__ __forceinline__ void fir_unit8(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask, int4 &p,
+                                          int4 &q)
+{
+    int32_t x[16];                      // x[8 + t] = value of step t; x[7 - j] = h[j] (x[7]: the newest before the unit)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        x[7 - j] = h[j];
+    const int32_t r[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+    // partial sums of step 0: tap j multiplies x[7 - j]
+    int64_t a = (int64_t)c[7] * (int64_t)x[0];
+    a += (int64_t)c[5] * (int64_t)x[2];
+    a += (int64_t)c[3] * (int64_t)x[4];
+    a += (int64_t)c[1] * (int64_t)x[6];
+    int64_t b = (int64_t)c[6] * (int64_t)x[1];
+    b += (int64_t)c[4] * (int64_t)x[3];
+    b += (int64_t)c[2] * (int64_t)x[5];
+    FU_PIN(a);
+    FU_PIN(b);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int n = 8 + t;            // this step: tap j multiplies x[n - 1 - j]; the next one: x[n - j]
+        int64_t sum = a + (int64_t)c[0] * (int64_t)x[n - 1];
+        FU_PIN(sum);
+        int64_t an = (int64_t)c[7] * (int64_t)x[n - 7];
+        FU_PIN(an);
+        sum += b;
+        FU_PIN(sum);
+        int64_t bn = (int64_t)c[6] * (int64_t)x[n - 6];
+        FU_PIN(bn);
+        int32_t ss = (int32_t)(sum >> shift);
+        FU_PIN(ss);
+        an += (int64_t)c[5] * (int64_t)x[n - 5];
+        FU_PIN(an);
+        uint32_t v = (uint32_t)ss + (uint32_t)r[t];
+        FU_PIN(v);
+        bn += (int64_t)c[4] * (int64_t)x[n - 4];
+        FU_PIN(bn);
+        v &= qmask;
+        FU_PIN(v);
+        x[n] = (int32_t)v;
+        an += (int64_t)c[3] * (int64_t)x[n - 3];
+        FU_PIN(an);
+        bn += (int64_t)c[2] * (int64_t)x[n - 2];
+        FU_PIN(bn);
+        an += (int64_t)c[1] * (int64_t)x[n - 1];
+        FU_PIN(an);
+        a = an;
+        b = bn;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        h[j] = x[15 - j];
+    p = make_int4(x[8], x[9], x[10], x[11]);
+    q = make_int4(x[12], x[13], x[14], x[15]);
+}
+
 __device__ __forceinline__ void fir_step8(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask, int4 &p,
                                           int4 &q)
 {
@@ -262,357 +332,109 @@ __device__ __forceinline__ void fir_step8(int32_t (&h)[8], const int32_t (&c)[8]
     q.w = fir_step_rot<7>(h, c, shift, qmask, q.w);
 }
 
-#ifndef DVDA_CHAIN_DEPTH
-#define DVDA_CHAIN_DEPTH 8
-#endif
-constexpr int CHAIN_DEPTH = DVDA_CHAIN_DEPTH;     // units of eight PCM frames a lane of k_chain_filter keeps in flight
-
-// One lane per (chain, substream, channel slot): 16 lanes per chain (2 substreams x 8 slots, 6 used).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chain_filter(ChainArgs a)
+// ------------------------------------------------------------------------------------------ chains by length
+// k_chain_fused gives eight chains to a workgroup, and the workgroup lives as long as its longest chain: chains in
+// index order -- a title's two or three chains of a few hundred to a few thousand units side by side -- left most of a
+// workgroup's lanes idle most of the time, and the last workgroups to start ran alone (round 4, measured: 3.9 ms
+// where the units themselves are 1 ms of turns).  So the chains are dealt longest first: neighbours in the order are
+// alike in length, and the hardware starts workgroups in order, which is longest-processing-time-first over the
+// compute units.  A counting sort by length class (64 PCM frames a class; everything past the last class is "long"
+// and goes first): three small kernels; the order inside a class is whatever the atomics make it -- the output does
+// not depend on it.
+constexpr uint32_t CHAIN_BUCKETS = 1024;
+__device__ __forceinline__ uint32_t chain_bucket(const ChainArgs &a, uint32_t ci, uint32_t n_chains, uint32_t n)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ci = g >> 4, sub = (g >> 3) & 1u, k = g & 7u;
+    const uint32_t h = DVDA_AT(a.head_list, ci, a.caps.max_seg, BT_C_HEAD);
+    const uint32_t h2 = ci + 1 < n_chains ? DVDA_AT(a.head_list, ci + 1, a.caps.max_seg, BT_C_HEAD) : n;
+    const uint32_t rows = a.plan[h2].x - a.plan[h].x;          // deferred PCM frames from this head to the next
+    const uint32_t cls = rows >> 6;
+    return CHAIN_BUCKETS - 1u - (cls < CHAIN_BUCKETS ? cls : CHAIN_BUCKETS - 1u);   // longest first
+}
+
+__global__ __launch_bounds__(256) void k_chain_hist(ChainArgs a)
+{
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = chain_n_seg(a);
-    if (ci >= a.plan[n].z || k >= 6u)
-        return;
-    uint32_t seg = DVDA_AT(a.head_list, ci, a.caps.max_seg, BT_C_HEAD);
-    const SegRec r0 = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
-    const StreamRec sr = DVDA_AT(a.streams, r0.stream, a.caps.max_streams, BT_STREAMS);
-    const uint32_t S = (sr.sync >> 24) & 0xFu;
-    if (sub >= S)
-        return;
-    const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
-    const size_t TL = a.total_lanes;
-    const bool writer = sub == 0 && k == 0;         // the lane that publishes per-segment results
+    const uint32_t n_chains = a.plan[n].z;
+    if (ci < n_chains)
+        atomicAdd(&a.chain_hist[chain_bucket(a, ci, n_chains, n)], 1u);
+}
 
-    int32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int32_t ih[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // IIR history / taps (rare; cleared by every restart header,
-    int32_t ic[8] = {0, 0, 0, 0, 0, 0, 0, 0};       //  so nothing of them crosses a segment boundary)
-    bool iir = false;
-    uint32_t shift = 0, qmask = 0xFFFFFFFFu;
-    uint32_t prev_meta = 0;                         // channel range of the segment the history comes from
-    uint32_t fail = 0;                              // why the chain stops (status bits for what follows)
-    if (a.seg_status[seg] & ST_CHAINED) {
-        if (seg == sr.first_seg) {
-            if (a.init_fir) {
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    h[j] = a.init_fir[((size_t)r0.stream * 2 + sub) * 48 + k * 8 + j];
-            } else {
-                fail = ST_ENVELOPE;     // FIR taps on a fresh decoder: the reference reads out of bounds
-            }
-        } else {
-            const uint32_t p = chain_prev_live(a, seg, sr.first_seg);
-            const uint32_t ps = a.seg_status[p] | (a.seg[p].flags & ST_FATAL_INDEX);
-            prev_meta = a.seg_meta[(size_t)p * 2 + sub];
-            if ((ps & ~ST_INFO) || (ps & ST_CHAIN) || !(prev_meta & 0x100u)) {
-                fail = (ps & ~ST_INFO) ? (ps & ~ST_INFO) : ST_ENVELOPE;     // nothing to continue from
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    h[j] = a.fir_ws[(size_t)(k * 8 + j) * TL + (size_t)p * 2 + sub];
-            }
-        }
+// one workgroup: class counts -> class starts (exclusive scan), the counts' place becomes the fill cursors
+__global__ __launch_bounds__(CHAIN_BUCKETS) void k_chain_scan(ChainArgs a)
+{
+    __shared__ uint32_t s_v[CHAIN_BUCKETS];
+    const uint32_t v = a.chain_hist[threadIdx.x];
+    s_v[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < CHAIN_BUCKETS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= o ? s_v[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s_v[threadIdx.x] += t;
+        __syncthreads();
     }
+    a.chain_hist[CHAIN_BUCKETS + threadIdx.x] = s_v[threadIdx.x] - v;
+    a.chain_hist[threadIdx.x] = 0;
+}
 
-    for (;;) {
-        const SegRec r = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
-        const uint32_t ss = a.seg_status[seg];
-        const uint32_t meta = DVDA_AT(a.seg_meta, (size_t)seg * 2 + sub, a.caps.lanes, BT_C_META);
-        bool overrun = false;           // the walk over this segment's block records left the records: stop, say so
-        if (!fail) {
-            if (ss & ~ST_INFO)
-                fail = ss & ~ST_INFO;               // the parse pass stopped on an error here
-            else if ((ss & (ST_TIMING | ST_SEQ)) || !(meta & 0x100u))
-                fail = ST_SEQ;                      // the sequential pass takes the stream
-            else if (prev_meta && (ss & ST_CHAINED) && ((prev_meta ^ meta) & 0xFFu))
-                fail = ST_ENVELOPE;                 // the substream's channel range changes under a running history
-        }
-        if (fail) {
-            // the chain ends here: what follows cannot be decoded by these passes.  An error is handed on
-            // (the reference would have stopped at it); ST_SEQ needs nothing -- the whole stream is decoded
-            // again, in order
-            if (writer && fail != ST_SEQ)
-                atomicOr(&a.seg_status[seg], fail & ~ST_INFO);
-        } else {
-            const uint32_t min_ch = meta & 0xFu, max_ch = (meta >> 4) & 0xFu;
-            const uint32_t R = (r.nframes - r.ndrop) * rpa;
-            const uint4 pl = DVDA_AT(a.plan, seg, a.caps.max_seg + 1u, BT_C_PLAN);
-            if (k <= max_ch - min_ch && DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES)) {
-                // the segment's planes: element (row, plane) at res_index() -- four rows of all eight planes share
-                // a 128-byte line, so the lanes of a chain (one per channel) read and write the same lines together
-                int32_t *const P = a.res + (size_t)pl.x * 8u;
-                const uint32_t plane = min_ch + k;
-                int4 *const Q = reinterpret_cast<int4 *>(P) + plane;         // group g (4 rows) of this plane: Q[g * 8]
-                const uint32_t *rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
-                // (the parse pass ends a substream's records with a terminator inside its brec_capacity(R) words; a
-                //  walk that gets there without meeting it -- records this pass did not write -- stops, and the
-                //  segment is reported, instead of following whatever the memory behind holds)
-                const uint32_t *const rp_end = (a.brec + a.caps.brec) - (rp + brec_capacity(R)) >= 0 ? rp + brec_capacity(R) - 1
-                                                                                                    : a.brec + (a.caps.brec ? a.caps.brec - 1 : 0);
-                const uint32_t nu = R >> 3;         // units of eight PCM frames: two 16-byte pieces of this lane's plane
-                                                    // (a segment is a whole number of 40-frame access units)
-                if (meta & 0x200u) {
-                    // ---- some block of this segment runs IIR taps (rare on discs): unit by unit, frame by frame
-                    uint32_t row = 0;
-                    uint32_t next_row = rp[0];
-                    // a block that sets filter parameters starts at `row` (src/mlp.c:1033-1068, 1260-1270)
-                    auto apply_records = [&]() {
-                        while (next_row == row) {
-                            if (rp >= rp_end) {
-                                overrun = true;
-                                next_row = 0xFFFFFFFFu;
-                                break;
-                            }
-                            const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
-                            if ((mask >> k) & 1u) {
-                                const uint32_t below = (1u << k) - 1u;
-                                const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) +
-                                                    BREC_IIR_WORDS * __popc(imask & below);
-                                const uint32_t pk = w[0];
-                                shift = pk & 0xFu;
-                                qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
-#pragma unroll
-                                for (int j = 0; j < 4; j++) {
-                                    c[2 * j] = lo16(w[1 + j]);
-                                    c[2 * j + 1] = hi16(w[1 + j]);
-                                }
-                                if (pk & (1u << 16)) {
-                                    // the block (re)sets the IIR: taps and the history it starts from, or none
-                                    iir = ((pk >> 12) & 0xFu) != 0;
-#pragma unroll
-                                    for (int j = 0; j < 4; j++) {
-                                        ic[2 * j] = iir ? lo16(w[5 + j]) : 0;
-                                        ic[2 * j + 1] = iir ? hi16(w[5 + j]) : 0;
-                                    }
-#pragma unroll
-                                    for (int j = 0; j < 8; j++)
-                                        ih[j] = iir ? (int32_t)w[9 + j] : 0;
-                                }
-                            }
-                            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
-                            next_row = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
-                            overrun = overrun || rp >= rp_end;
-                        }
-                    };
-                    auto slow_step = [&](int32_t residual) {
-                        apply_records();
-                        const int32_t v = iir ? iir_step_one(h, c, ih, ic, shift, qmask, residual)
-                                              : fir_step_one(h, c, shift, qmask, residual);
-                        row++;
-                        return v;
-                    };
-                    for (uint32_t u = 0; u < nu; u++) {
-                        int4 *W = Q + (size_t)u * 16u;
-                        int4 x = W[0], y = W[8];
-                        x.x = slow_step(x.x);
-                        x.y = slow_step(x.y);
-                        x.z = slow_step(x.z);
-                        x.w = slow_step(x.w);
-                        y.x = slow_step(y.x);
-                        y.y = slow_step(y.y);
-                        y.z = slow_step(y.z);
-                        y.w = slow_step(y.w);
-                        W[0] = x;
-                        W[8] = y;
-                    }
-                } else {
-                    // ---- FIR taps only.  CHAIN_DEPTH units are in flight per lane: a lane has nothing else to hide
-                    //      the memory latency behind, and there is about one wave per SIMD.  The loads are
-                    //      unconditional (past the segment's end the last unit is asked for again) and whole turns
-                    //      of CHAIN_DEPTH units are straight-line code, so the waits the compiler inserts count
-                    //      exactly the operations issued since -- round 2's first version loaded under per-lane
-                    //      conditions and restarted its pipeline at every block that set parameters (on real
-                    //      streams: every block): 34 instructions per PCM frame and most of the time spent waiting.
-                    //      Here the eight steps of a unit run with the history renamed, not moved (fir_step_rot),
-                    //      a block's parameters wait in registers from the block before it on (five words: shift,
-                    //      quant step, eight taps) and take effect between two steps without the pipeline noticing.
-                    constexpr int D = CHAIN_DEPTH;
-                    uint32_t left = 0;               // PCM frames until the next block that sets parameters
-                    uint32_t nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nw4 = 0;    // its record for this slot, if it has one
-                    bool n_has = false;
-                    uint32_t tgt = 0;                // the frame it counts down to (records carry absolute frames)
-                    auto preload = [&](uint32_t row_now) {
-                        overrun = overrun || rp >= rp_end;
-                        const uint32_t nr = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
-                        n_has = false;
-                        tgt = nr;
-                        left = nr - row_now;                                  // (terminator: 0xFFFFFFFF, never reached)
-                        if (nr != 0xFFFFFFFFu) {
-                            const uint32_t m = rp[1];
-                            const uint32_t mask = m & 0xFFu, imask = (m >> 8) & 0xFFu;
-                            const uint32_t below = (1u << k) - 1u;
-                            const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) +
-                                                BREC_IIR_WORDS * __popc(imask & below);
-                            if ((mask >> k) & 1u) {
-                                n_has = true;
-                                nw0 = w[0];
-                                nw1 = w[1];
-                                nw2 = w[2];
-                                nw3 = w[3];
-                                nw4 = w[4];
-                            }
-                            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
-                        }
-                    };
-                    (void)ih;
-                    (void)ic;
-                    preload(0);
-                    // a block starts at the frame the countdown has reached: its parameters take effect, the record
-                    // behind it is asked for
-                    // (no loop in here: records are eight frames or more apart -- the parser checks the block size --
-                    //  and a loop around the loads would cost the compiler its count of what is in flight)
-                    auto apply = [&]() {
-                        if (n_has) {
-                            shift = nw0 & 0xFu;
-                            qmask = 0xFFFFFFFFu << ((nw0 >> 4) & 0xFu);
-                            c[0] = lo16(nw1);
-                            c[1] = hi16(nw1);
-                            c[2] = lo16(nw2);
-                            c[3] = hi16(nw2);
-                            c[4] = lo16(nw3);
-                            c[5] = hi16(nw3);
-                            c[6] = lo16(nw4);
-                            c[7] = hi16(nw4);
-                        }
-                        preload(tgt);
-                    };
-                    uint32_t u = 0;
-                    while (u < nu) {
-                        if (left != 0 && left < 8u) {
-                            // ---- a block starts inside this unit (encoders cut blocks at multiples of eight frames;
-                            //      the test generator does not): frame by frame, the history moved, not renamed
-                            int4 *W = Q + (size_t)u * 16u;
-                            int4 x = W[0], y = W[8];
-                            auto one = [&](int32_t residual) {
-                                while (left == 0)
-                                    apply();
-                                left--;
-                                return fir_step_one(h, c, shift, qmask, residual);
-                            };
-                            x.x = one(x.x);
-                            x.y = one(x.y);
-                            x.z = one(x.z);
-                            x.w = one(x.w);
-                            y.x = one(y.x);
-                            y.y = one(y.y);
-                            y.z = one(y.z);
-                            y.w = one(y.w);
-                            W[0] = x;
-                            W[8] = y;
-                            u++;
-                            continue;
-                        }
-                        // ---- units from here to the segment's end, or to the next one a block starts inside of
-                        int4 ua[D], ub[D];
-                        auto fetch = [&](int4 &x, int4 &y, uint32_t w) {
-                            const int4 *N = Q + (size_t)(w < nu ? w : nu - 1u) * 16u;
-                            x = N[0];
-                            y = N[8];
-                        };
-#pragma unroll
-                        for (int i = 0; i < D; i++)
-                            fetch(ua[i], ub[i], u + (uint32_t)i);
-                        bool stop = false;
-                        // (whole turns of D units are straight-line code but for the two tests per unit)
-                        for (; !stop && u + D <= nu; ) {
-#pragma unroll
-                            for (int i = 0; i < D; i++) {
-                                if (left == 0)
-                                    apply();
-                                if (left < 8u) {
-                                    stop = true;
-                                    break;
-                                }
-                                fir_step8(h, c, shift, qmask, ua[i], ub[i]);
-                                left -= 8u;
-                                int4 *W = Q + (size_t)u * 16u;
-                                W[0] = ua[i];
-                                W[8] = ub[i];
-                                fetch(ua[i], ub[i], u + (uint32_t)D);
-                                u++;
-                            }
-                        }
-                        if (!stop) {
-#pragma unroll
-                            for (int i = 0; i < D; i++) {
-                                if (u < nu) {
-                                    if (left == 0)
-                                        apply();
-                                    if (left < 8u)
-                                        break;
-                                    fir_step8(h, c, shift, qmask, ua[i], ub[i]);
-                                    left -= 8u;
-                                    int4 *W = Q + (size_t)u * 16u;
-                                    W[0] = ua[i];
-                                    W[8] = ub[i];
-                                    u++;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- the history at the segment's end (what a later call, or the next chain, continues from)
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                a.fir_ws[(size_t)(k * 8 + j) * TL + (size_t)seg * 2 + sub] = h[j];
-            // (a records walk that left its records, on any channel of the segment: reported, and the chain ends)
-            if (overrun) {
-                atomicOr(&a.seg_status[seg], ST_CAPACITY);
-                fail = ST_CAPACITY;
-            }
-            if (writer && !overrun)
-                atomicOr(&a.seg_status[seg], ST_GENERAL);       // filtered: the rematrix pass may take it
-            prev_meta = meta;
-        }
-        // ---- on to the next segment of the stream while it continues this history
-        uint32_t nxt = seg + 1;
-        while (nxt < n && a.seg[nxt].stream == r.stream && (a.seg[nxt].flags & SEG_DEAD))
-            nxt++;
-        if (nxt >= n || a.seg[nxt].stream != r.stream)
-            break;
-        const uint4 pn = a.plan[nxt], qn = a.plan[nxt + 1];
-        if (qn.y == pn.y || qn.z != pn.z)
-            break;                                  // not deferred, or the head of the next chain
-        seg = nxt;
-    }
+__global__ __launch_bounds__(256) void k_chain_scatter(ChainArgs a)
+{
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = chain_n_seg(a);
+    const uint32_t n_chains = a.plan[n].z;
+    if (ci >= n_chains)
+        return;
+    const uint32_t b = chain_bucket(a, ci, n_chains, n);
+    const uint32_t at = a.chain_hist[CHAIN_BUCKETS + b] + atomicAdd(&a.chain_hist[b], 1u);
+    DVDA_AT(a.chain_order, at, a.caps.max_seg, BT_C_HEAD) = ci;
 }
 
 // ---------------------------------------------------------------------------------- filter + rematrix, fused
-// Round 4.  The filter pass above leaves a channel's filtered values where its residuals were (10.8 GB of plane
-// lines read and written per bench-size batch) and the rematrix pass reads them again (5.4 GB) to write 4 GB of
-// PCM: three of the four transfers are the planes going round.  k_chain_fused walks a chain's planes ONCE and
-// writes PCM once.  A workgroup is two waves and eight chains:
+// Round 4.  Rounds 2 and 3 ran the recursion in place on the planes (k_chain_filter: 10.8 GB of plane lines read and
+// written per bench-size batch) and read them again to rematrix (k_chain_rematrix: 5.4 GB in, 4 GB of PCM out): three of
+// the four transfers were the planes going round.  k_chain_fused walks a chain's planes ONCE and writes PCM once.
+// A workgroup is two waves and eight chains:
 //
-//   wave 0, the FILTER wave: lane p of a chain loads piece p of every 128-byte plane line (pieces 0..5: four PCM
-//     frames of channel p's residuals, 6: their bypassed LSBs, 7: their noise seeds -- a chain's eight lanes take
-//     whole lines), FU_DEPTH units of eight PCM frames in flight per lane; lanes 0..5 run the recursion of their
-//     channel over the unit (fir_step8, a block's parameters waiting in registers from the block before it on:
-//     k_chain_filter's scheme) and put it, [plane][frame], into one of two exchange tiles in LDS, with a header:
-//     where the unit goes in the output, which access-unit record it is rematrixed with;
-//   wave 1, the OUTPUT wave: lane f of a chain takes PCM frame f of the unit the filter wave left in the OTHER tile
-//     one turn earlier -- its six channels, bypassed LSBs, noise seed --, rematrixes it with the record of the
-//     frame's access unit (src/mlp.c:504-525: the parameters the unit's LAST block left), shifts, orders
-//     (src/mlp.c:416-438, 527-533) and stores: a unit leaves as 192 contiguous bytes (six channels, frame-major).
+//   wave 0, the FILTER wave: lane p of a chain owns piece p of every 128-byte plane line (pieces 0..5: four PCM frames
+//     of channel p's residuals, 6: their bypassed LSBs, 7: their noise seeds -- a chain's eight lanes take whole lines).
+//     The lines come straight into an LDS ring by global_load_lds (gfx950's direct-to-LDS load), FU_RING units of
+//     eight PCM frames ahead; lanes 0..5 run the recursion of their channel over a unit (fir_unit8) and put it,
+//     [plane][frame], into an exchange tile.  A block's filter parameters come the same way: the block records have
+//     fixed places (mlp_decode.h), the next FU_BRECS of a lane's slot wait in LDS, asked for records ahead.
+//   wave 1, the OUTPUT wave: lane f of a chain takes PCM frame f of each unit the filter wave left in the OTHER tile one
+//     turn earlier -- six channels, bypassed LSBs, noise seed --, rematrixes it with the record of the frame's access
+//     unit (src/mlp.c:504-525: the parameters the unit's LAST block left), shifts, orders (src/mlp.c:416-438, 527-533)
+//     and stores: a unit leaves as 192 contiguous bytes (six channels, frame-major).  It loads NOTHING from global
+//     memory: the access-unit records reach LDS by the filter wave's direct loads, access units ahead of their use.
 //
-// One LDS-only barrier per unit (s_waitcnt lgkmcnt(0); s_barrier: the filter wave's loads in flight are not waited
-// for) hands a tile over; the two halves of a unit's work -- ~110 wave-instructions each, both latency-bound
-// dependency chains on a wave that has its SIMD to itself -- run side by side on two SIMDs instead of one after
-// the other on one (the first, single-wave version of this kernel: 10.9 ms against 6.5 for the two passes).
-// The output wave loads NOTHING from global memory: the access-unit records reach LDS by the filter wave's
-// global_load_lds (gfx950's direct-to-LDS load: no register, so no wait is ever inserted for it), issued two
-// access units ahead of their use; completion is implied by program order -- the filter wave has since waited for
-// plane loads it issued later, and loads return in order.
-// The filter wave's loop is FLAT: every turn every live chain does one unit, and what happens between two units --
-// a segment ends, the next one is set up, the unit pipeline is refilled -- happens between two barriers, so both
-// waves count the same turns whatever the chains of the group look like.
-constexpr int FU_DEPTH = 8;         // units of eight PCM frames a filter lane keeps in flight (a power of two)
-constexpr int FU_XS = 72;           // dwords of exchange tile per chain: 8 planes x 8 frames, + 8 so that the chains of a
-                                    // half-wave fall on different LDS banks
+// One LDS-only barrier per turn of FU_T units (s_waitcnt lgkmcnt(0); s_barrier: loads in flight are not waited for)
+// hands a tile over.  The filter wave's loop is FLAT: every turn every live chain does up to FU_T units, and what
+// happens between two units of a chain -- its segment ends, the next one is set up, the ring is refilled -- happens
+// between two barriers, so both waves count the same turns whatever the chains of the group look like.
+//
+// Why the direct-to-LDS loads are inline asm, and the one wait that is written out by hand: a load the compiler knows
+// of makes it wait -- vmcnt(0) -- in front of the first LDS access that might alias its target, or in front of the
+// first reuse of a register some load may still be writing; in a loop that keeps two dozen loads in flight that is a
+// full memory round trip per turn.  Loads return in order: "all but the N newest loads of this wave are done" (N = what
+// the wave has asked for since) is the exact condition for the unit in work, and whatever else the wave loads or stores
+// only makes that unit's loads older.  The compiler's own loads (a segment's set-up) are all used where they are
+// loaded (fu_use), so nothing is pending when a turn begins.
+//
+// Measured (MI355X, 4 096 chained titles x 512 access units, one chain per title): filter + rematrix 6.5 ms as two
+// passes -> 3.4-3.9 ms; what is left is the filter wave alone on its SIMD: 64 v_mad_i64_i32 per unit at ~12 cycles each
+// for a lone wave (their order does not matter: fir_unit8's two-chain schedule and the one-chain form take the same
+// 900 cycles), ~250 cycles per unit of segment set-up (dependent loads, each behind everything the ring has in flight),
+// and the chains of a batch being fewer than the chip's lanes (4 096 chains = 512 workgroups on 256 compute units).
+constexpr int FU_T = 4;             // units of eight PCM frames a chain does per turn (per barrier): what a turn costs beside the
+                                    // units themselves -- the hand-over, the bookkeeping of a lone wave -- is paid once per FU_T
+constexpr int FU_DT = 3;            // turns a unit is asked for ahead of its use
+constexpr int FU_RING = FU_T * FU_DT;       // units a filter lane has in flight
+constexpr int FU_XS = 72;           // dwords of exchange tile per chain and unit: 8 planes x 8 frames, + 8 so that the chains of
+                                    // a half-wave fall on different LDS banks
 constexpr int FU_THREADS = 128;
-constexpr int FU_RECS = 4;          // access-unit records per chain in LDS (ring by record number)
+constexpr int FU_RECS = 8;          // access-unit records per chain in LDS (ring by record number)
+constexpr int FU_BRECS = 8;         // block records per filter lane in LDS (ring by record number)
+constexpr int FU_WAIT = 2 * FU_T * (FU_DT - 1);     // loads a filter lane has asked for since the units of this turn
 constexpr uint32_t FU_DONE = 0xD0E5u;
 
 // 16 bytes per lane from `src` (per lane) straight into LDS at lds_base + lane * 16 (gfx950's global_load_lds; lds_base
@@ -636,27 +458,42 @@ __device__ __forceinline__ void fu_dma16(const void *src, uint32_t lds_base)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory", "m0");
 }
 
+#if defined(DVDA_EXP_STAMP)
+#define FU_STAMP(i)                                                      \
+    do {                                                                 \
+        const unsigned long long t_ = clock64();                         \
+        fu_acc[i] += t_ - fu_t;                                          \
+        fu_t = t_;                                                       \
+    } while (0)
+#else
+#define FU_STAMP(i) ((void)0)
+#endif
 __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chain_fused(ChainArgs a)
 {
-    __shared__ int32_t s_x[2][8 * FU_XS];
-    __shared__ uint4 s_hdr[2][8];                   // per tile and chain: valid | new record << 1, record ring slot, output row (64 bit)
+    __shared__ int32_t s_x[2][FU_T][8 * FU_XS];
+    __shared__ uint32_t s_cnt[2][8];                // per tile and chain: units the filter wave left in it | "first turn of a segment" << 8
+    __shared__ uint4 s_seg[8][2];                   // per chain, the segment its units belong to: first output row (64 bit), its
+                                                    // access units' records in memory (64 bit) | their first number in the record ring
     __shared__ uint32_t s_ctl[2];                   // per tile: FU_DONE when the filter wave is through
     __shared__ uint32_t s_rec[FU_RECS][64][4];      // access-unit records, words 0..31 (lane cl * 8 + j holds words 4j..4j+3)
-    __shared__ uint32_t s_rec2[FU_RECS][64][4];     // ... words 32..35 (lane cl * 8 holds them)
     __shared__ uint32_t s_b[8][8 * 6 * 3 / 4];      // packed WAV payload of a unit, per chain: 8 frames x 18 bytes at most
-    __shared__ int4 s_ring[FU_DEPTH][2][64];        // the filter wave's units in flight: ring place, line of the unit, lane
+    __shared__ int4 s_ring[FU_RING][2][64];         // the filter wave's units in flight: ring place, line of the unit, lane
+    __shared__ uint4 s_brl[FU_BRECS][64], s_brh[FU_BRECS][64];     // the next block records of each filter lane's slot (ring by
+                                                                   // record number): dwords 0..3 and 4..7 of the slot's eight
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t cl = lane >> 3, p = lane & 7u;   // chain of the group; plane (filter wave) / PCM frame of the unit (output wave)
-    const uint32_t ci = blockIdx.x * 8u + cl;
     const uint32_t n = chain_n_seg(a);
     const uint32_t n_chains = a.plan[n].z;
     if (blockIdx.x * 8u >= n_chains)
         return;                                     // (the whole workgroup: no barrier is left waiting)
+    // (chains are dealt longest first: a workgroup's eight are alike in length, and the long ones start first)
+    const uint32_t cpos = blockIdx.x * 8u + cl;
+    const uint32_t ci = cpos < n_chains ? DVDA_AT(a.chain_order, cpos, a.caps.max_seg, BT_C_HEAD) : n_chains;
     if (threadIdx.x < 2)
         s_ctl[threadIdx.x] = 0;
     if (threadIdx.x < 16)
-        (&s_hdr[0][0])[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        (&s_cnt[0][0])[threadIdx.x] = 0;
     __syncthreads();
 
     bool alive = ci < n_chains;
@@ -678,27 +515,51 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
         const bool direct6 = a.interleaved && !a.wav_bits && nch_out == 6u && (wavepk & 0xFFFFFFu) == 0x543210u &&
                              (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
         uint32_t fw0 = 0, f_outch = 0, f_qss = 0, f_oshift = 0, f_rec = 0;
+        const uint32_t *f_mem = nullptr;           // the record in memory (words 32.. are read from there: six matrices, rare)
         int32_t mc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};     // matrices 0 and 1: six channels + the two noise taps
+#if defined(DVDA_EXP_STAMP)
+        unsigned long long fu_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long fu_t = clock64();
+#endif
+        const uint32_t rpu = rpa >> 3;              // units per access unit
+        uint64_t row0 = 0;                          // the segment in work: its first output row, ...
+        const uint32_t *F0 = nullptr;               // ... its access units' records in memory, ...
+        uint32_t recno = 0;                         // ... and the first one's number in the record ring
+        uint32_t ou = 0, oau = 0, oleft = 0;        // units of it taken, access units opened, units until the next one opens
         for (uint32_t j = 0;; j++) {
+            FU_STAMP(3);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            FU_STAMP(0);
             const uint32_t t = j & 1u;
             if (s_ctl[t] == FU_DONE)
                 break;
-            const uint4 hd = s_hdr[t][cl];
-            if (!(hd.x & 1u))
+            const uint32_t cw = s_cnt[t][cl];
+            const uint32_t cnt = cw & 0xFFu;
+            if (cw & 0x100u) {
+                const uint4 g0 = s_seg[cl][0], g1 = s_seg[cl][1];
+                row0 = ((uint64_t)g0.y << 32) | g0.x;
+                F0 = reinterpret_cast<const uint32_t *>(((uint64_t)g0.w << 32) | g0.z);
+                recno = g1.x;
+                ou = oau = oleft = 0;
+            }
+            if (p == 0 && cw)
+                s_cnt[t][cl] = 0;                   // taken (a chain that pauses leaves nothing here next time)
+            for (uint32_t qu = 0; qu < (uint32_t)FU_T; qu++) {
+            if (qu >= cnt)
                 continue;
-            const int32_t *const X = s_x[t] + cl * FU_XS;
+            const int32_t *const X = s_x[t][qu] + cl * FU_XS;
             int32_t ch[6];
 #pragma unroll
             for (int q = 0; q < 6; q++)
                 ch[q] = X[q * 8 + p];
             const uint32_t bypass_bits = (uint32_t)X[6 * 8 + p];
             const uint32_t seed = (uint32_t)X[7 * 8 + p];
-            if (p == 0)
-                s_hdr[t][cl].x = 0;                 // taken (a chain that pauses leaves no unit here next time)
-            if (hd.x & 2u) {
-                // ---- the unit opens an access unit: its record from the ring slot the filter wave names
-                f_rec = hd.y & (FU_RECS - 1);
+            if (oleft == 0) {
+                // ---- the unit opens an access unit: its record from its place in the ring
+                f_rec = (recno + oau) & (FU_RECS - 1);
+                f_mem = F0 + (size_t)oau * FREC_WORDS;
+                oau++;
+                oleft = rpu;
                 const uint32_t *R0 = &s_rec[f_rec][cl * 8u][0];
                 fw0 = R0[0];
                 f_outch = R0[1];
@@ -720,6 +581,10 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 mc[1][6] = lo16(R0[13]);
                 mc[1][7] = hi16(R0[13]);
             }
+            oleft--;
+            const uint64_t urow = row0 + (uint64_t)ou * 8u;                 // the unit's first output row
+            ou++;
+            FU_STAMP(1);
             const uint32_t noise_shift = fw0 & 0xFFu, matrix_len = (fw0 >> 8) & 0xFFu, mmc = fw0 >> 16;
             const uint32_t shifted = (seed >> 7) & 0xFFFFu;
             const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
@@ -746,7 +611,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
 #pragma unroll
                 for (int q = 0; q < 5; q++) {
                     const uint32_t wd = 4u + m * 5u + (uint32_t)q;
-                    M[q] = wd < 32u ? s_rec[f_rec][cl * 8u + (wd >> 2)][wd & 3u] : s_rec2[f_rec][cl * 8u][wd & 3u];
+                    M[q] = wd < 32u ? s_rec[f_rec][cl * 8u + (wd >> 2)][wd & 3u] : f_mem[wd];
                 }
                 int64_t acc = (int64_t)n0 * (int64_t)lo16(M[4]) + (int64_t)n1 * (int64_t)hi16(M[4]);
 #pragma unroll
@@ -760,8 +625,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                     if ((uint32_t)q <= mmc)
                         ch[q] = (int32_t)((uint32_t)ch[q] << nib(f_oshift, q));
             }
+            FU_STAMP(2);
             // ---- RIFF order and the four PCM layouts
-            const uint64_t urow = ((uint64_t)hd.w << 32) | hd.z;            // the unit's first output row
             const uint64_t orow = urow + p;
             if (a.wav_bits) {
                 const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
@@ -802,7 +667,13 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                             out[a.interleaved ? orow * nch_out + nib(wavepk, q) : (uint64_t)nib(wavepk, q) * out_stride + orow] = ch[q];
                 }
             }
+            }
         }
+#if defined(DVDA_EXP_STAMP)
+        if (lane == 0 && a.dbg)
+            for (int i = 0; i < 8; i++)
+                atomicAdd(&a.dbg[24 + i], fu_acc[i]);
+#endif
         return;
     }
 
@@ -878,100 +749,115 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
     fu_use(prev_meta1);
     fu_use(out_stride);
     fu_use(seg);
+    uint32_t fbase_first = alive ? a.seg_fbase[sr.first_seg] : 0u;     // (output rows count from the stream's first segment)
+    fu_use(fbase_first);
+    uint32_t turn = 0;                      // turns of the flat loop below (wave-uniform: every lane takes every turn)
     // ---- the segment in work
     bool run = false;                       // units of it are left
     uint32_t u = 0, nu = 0;
     const int4 *Q = nullptr;                // line l, piece p: Q[l * 8]
     const uint32_t *F0 = nullptr;           // its access units' records
     uint32_t n_au = 0, recno = 0;           // record ring: number of the record of the segment's first access unit
+    uint32_t au_issue = 0, au_issue_at = 0; // the next access unit whose record is to be asked for, and at which unit of the segment
+    bool fresh = false;                     // no unit of the segment has been handed over yet
+    const uint32_t rpu = rpa >> 3;          // units per access unit
+    // records asked for this many access units ahead: there -- (FU_DT + 1) turns of units later at the least -- when the
+    // output wave opens that unit
+    const uint32_t rec_ahead = rpa ? (uint32_t)((FU_DT + 1) * FU_T * 8) / rpa + 1u : 2u;
+    uint32_t ring_phase = 0;                // turn % FU_DT (wave-uniform): the ring places of a turn are ring_phase * FU_T + 0 .. FU_T - 1
     uint64_t row0 = 0;
     uint32_t sub = 0, k = 0, meta0 = 0, meta1 = 0;
     bool filt = false, seg_iir = false, overrun = false;
-    const uint32_t *rp = nullptr, *rp_end = nullptr;
-    uint32_t left = 0xFFFFFFFFu, nw0 = 0, nw1 = 0, nw2 = 0, nw3 = 0, nw4 = 0, tgt = 0;
-    bool n_has = false;
-    uint32_t srow = 0, next_row = 0xFFFFFFFFu;      // IIR segments: frame by frame
+    const uint32_t *rbase = nullptr;        // this lane's slot in record 0 of its substream (records: BREC_STRIDE dwords apart)
+    const uint32_t *sbase = nullptr;        // the substream's first record (IIR words are addressed from it)
+    uint32_t rmax = 0;                      // records the substream can hold, terminator included
+    uint32_t rnext = 0;                     // the next record to take effect ...
+    uint32_t left = 0xFFFFFFFFu, tgt = 0;   // ... at PCM frame tgt of the segment, `left` frames from here
+    bool need_first = false;                // record 0's frame has not been looked at yet (it was still on its way)
+    unsigned long long rstamp = 0;          // turn (mod 256) each of the FU_BRECS ring places was asked for, a byte each
+    uint32_t srow = 0, next_row = 0xFFFFFFFFu, rcur = 0;    // IIR segments: frame by frame, records straight from memory
 
-    auto preload = [&](uint32_t row_now) __attribute__((always_inline)) {
-        overrun = overrun || rp >= rp_end;
-        const uint32_t nr = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
-        n_has = false;
-        tgt = nr;
-        left = nr - row_now;                                  // (terminator: 0xFFFFFFFF, never reached)
-        if (nr != 0xFFFFFFFFu) {
-            const uint32_t m = rp[1];
-            const uint32_t mask = m & 0xFFu, imask = (m >> 8) & 0xFFu;
-            const uint32_t below = (1u << k) - 1u;
-            const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) + BREC_IIR_WORDS * __popc(imask & below);
-            if ((mask >> k) & 1u) {
-                n_has = true;
-                nw0 = w[0];
-                nw1 = w[1];
-                nw2 = w[2];
-                nw3 = w[3];
-                nw4 = w[4];
+    // record r of this lane's slot: into ring place r % FU_BRECS, straight from memory (one instruction per place
+    // value: the LDS base of a load instruction is the wave's, the place is the lane's)
+    auto rec_dma = [&](uint32_t r, uint32_t stamp) __attribute__((always_inline)) {
+        const uint32_t b = r & (FU_BRECS - 1);
+        const uint32_t *src = rbase + (size_t)r * BREC_STRIDE;
+#pragma unroll
+        for (int q = 0; q < FU_BRECS; q++) {
+            if (r < rmax && b == (uint32_t)q) {
+                fu_dma16(src, fu_lds(&s_brl[q][0]));
+                fu_dma16(src + 4, fu_lds(&s_brh[q][0]));
             }
-            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
         }
-        // (the record waits in registers from here on: loaded now, not "some time before it is applied")
-        fu_use(nw0);
-        fu_use(nw1);
-        fu_use(nw2);
-        fu_use(nw3);
-        fu_use(nw4);
-        fu_use(left);
-        fu_use(tgt);
+        rstamp = (rstamp & ~(0xFFull << (8u * b))) | ((unsigned long long)(stamp & 0xFFu) << (8u * b));
     };
+    // the frame the next record takes effect at.  The record was asked for FU_BRECS - 1 records ago; blocks of a few
+    // frames (test streams) can bring that within the last turns, where "all but the newest loads are done" does not
+    // cover it yet: then, and only then, everything in flight is waited for
+    auto next_target = [&]() __attribute__((always_inline)) {
+        const uint32_t b = rnext & (FU_BRECS - 1);
+        const uint32_t age = (turn - (uint32_t)(rstamp >> (8u * b))) & 0xFFu;
+        if (age <= (uint32_t)FU_DT)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t row = s_brl[b][lane].x;
+        left = row - tgt;                                    // (terminator: 0xFFFFFFFF, never reached)
+        tgt = row;
+    };
+    // a block that sets filter parameters starts here (src/mlp.c:1033-1068, 1260-1270): its record, then the one behind it
     auto apply = [&]() __attribute__((always_inline)) {
-        if (n_has) {
-            shift = nw0 & 0xFu;
-            qmask = 0xFFFFFFFFu << ((nw0 >> 4) & 0xFu);
-            c[0] = lo16(nw1);
-            c[1] = hi16(nw1);
-            c[2] = lo16(nw2);
-            c[3] = hi16(nw2);
-            c[4] = lo16(nw3);
-            c[5] = hi16(nw3);
-            c[6] = lo16(nw4);
-            c[7] = hi16(nw4);
+        const uint32_t b = rnext & (FU_BRECS - 1);
+        const uint4 lo = s_brl[b][lane], hi = s_brh[b][lane];
+        if (lo.y & 1u) {
+            shift = lo.z & 0xFu;
+            qmask = 0xFFFFFFFFu << ((lo.z >> 4) & 0xFu);
+            c[0] = lo16(lo.w);
+            c[1] = hi16(lo.w);
+            c[2] = lo16(hi.x);
+            c[3] = hi16(hi.x);
+            c[4] = lo16(hi.y);
+            c[5] = hi16(hi.y);
+            c[6] = lo16(hi.z);
+            c[7] = hi16(hi.z);
         }
-        preload(tgt);
+        rec_dma(rnext + (uint32_t)FU_BRECS, turn);           // (into the place this record leaves)
+        rnext++;
+        next_target();
     };
-    // IIR segments: a block that sets filter parameters starts at `srow` (src/mlp.c:1033-1068, 1260-1270)
+    // IIR segments: a block that sets filter parameters starts at `srow`; records and IIR words straight from memory
     auto apply_records = [&]() __attribute__((always_inline)) {
         while (next_row == srow) {
-            if (rp >= rp_end) {
+            if (rcur >= rmax) {
                 overrun = true;
                 next_row = 0xFFFFFFFFu;
                 break;
             }
-            const uint32_t mask = rp[1] & 0xFFu, imask = (rp[1] >> 8) & 0xFFu;
-            if ((mask >> k) & 1u) {
-                const uint32_t below = (1u << k) - 1u;
-                const uint32_t *w = rp + 2 + BREC_SLOT_WORDS * __popc(mask & below) + BREC_IIR_WORDS * __popc(imask & below);
-                const uint32_t pk = w[0];
+            const uint32_t *w = rbase + (size_t)rcur * BREC_STRIDE;
+            if (w[1] & 1u) {
+                const uint32_t pk = w[2];
                 shift = pk & 0xFu;
                 qmask = 0xFFFFFFFFu << ((pk >> 4) & 0xFu);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    c[2 * j] = lo16(w[1 + j]);
-                    c[2 * j + 1] = hi16(w[1 + j]);
+                    c[2 * j] = lo16(w[3 + j]);
+                    c[2 * j + 1] = hi16(w[3 + j]);
                 }
                 if (pk & (1u << 16)) {
-                    iir = ((pk >> 12) & 0xFu) != 0;
+                    // the block (re)sets the IIR: taps and the history it starts from, or none
+                    iir = ((pk >> 12) & 0xFu) != 0 && w[7] != 0;
+                    const uint32_t *x = sbase + w[7];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        ic[2 * j] = iir ? lo16(w[5 + j]) : 0;
-                        ic[2 * j + 1] = iir ? hi16(w[5 + j]) : 0;
+                        ic[2 * j] = iir ? lo16(x[j]) : 0;
+                        ic[2 * j + 1] = iir ? hi16(x[j]) : 0;
                     }
 #pragma unroll
                     for (int j = 0; j < 8; j++)
-                        ih[j] = iir ? (int32_t)w[9 + j] : 0;
+                        ih[j] = iir ? (int32_t)x[4 + j] : 0;
                 }
             }
-            rp += 2 + BREC_SLOT_WORDS * __popc(mask) + BREC_IIR_WORDS * __popc(imask);
-            next_row = rp < rp_end ? rp[0] : 0xFFFFFFFFu;
-            overrun = overrun || rp >= rp_end;
+            rcur++;
+            next_row = rcur < rmax ? rbase[(size_t)rcur * BREC_STRIDE] : 0xFFFFFFFFu;
+            overrun = overrun || rcur >= rmax;
         }
     };
     auto slow_step = [&](int32_t residual) __attribute__((always_inline)) {
@@ -995,10 +881,17 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             y.w = slow_step(y.w);
             return;
         }
+        if (need_first) {
+            need_first = false;                 // (the set-up's loads are older than the unit just waited for)
+            tgt = 0;
+            const uint32_t row = s_brl[0][lane].x;
+            left = row;
+            tgt = row;
+        }
         if (left == 0)
             apply();
         if (left >= 8u) {
-            fir_step8(h, c, shift, qmask, x, y);
+            fir_unit8(h, c, shift, qmask, x, y);
             left -= 8u;
         } else {
             // a block starts inside the unit (test streams; encoders cut blocks at multiples of eight frames)
@@ -1025,11 +918,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
         const uint32_t *src = F0 + (size_t)au * FREC_WORDS + p * 4u;
 #pragma unroll
         for (int b = 0; b < FU_RECS; b++) {
-            if (au < n_au && slot == (uint32_t)b) {
+            if (au < n_au && slot == (uint32_t)b)
                 fu_dma16(src, fu_lds(&s_rec[b][0][0]));
-                if (p == 0)
-                    fu_dma16(src + 32, fu_lds(&s_rec2[b][0][0]));
-            }
         }
     };
     // unit w of the segment (the last one again past its end: the count of loads in flight stays what the wait
@@ -1040,37 +930,65 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
         fu_dma16(N + 8, fu_lds(&s_ring[place][1][0]));
     };
 
-    uint32_t turn = 0;                      // wave-uniform: every lane takes every turn
+#if defined(DVDA_EXP_STAMP)
+    unsigned long long fu_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long fu_t = clock64();
+#endif
     for (;;) {
         {
+            FU_STAMP(5);
             const uint32_t t = turn & 1u;
-            const uint32_t place = __builtin_amdgcn_readfirstlane(turn) & (uint32_t)(FU_DEPTH - 1);
+            const uint32_t pbase = __builtin_amdgcn_readfirstlane(ring_phase) * (uint32_t)FU_T;
+            const bool ran = run;
             if (run) {
-                // ---- one unit.  Its two lines were asked for FU_DEPTH turns ago (or by the segment's set-up) and every
-                //      turn since has asked for two more: all but the 2 (FU_DEPTH - 1) newest loads of this wave done
-                //      means they are there (loads return in order; whatever else the wave loaded or stored in between
-                //      only makes them older)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (FU_DEPTH - 1)) : "memory");
-                int4 xa = s_ring[place][0][lane], xb = s_ring[place][1][lane];
-                filter_unit(xa, xb);
-                int32_t *const X = s_x[t] + cl * FU_XS;
-                reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
-                reinterpret_cast<int4 *>(X + p * 8)[1] = xb;
-                const uint32_t row = u * 8u;
-                const uint32_t au = row / rpa;
-                const bool opens = au * rpa == row;
-                if (p == 0) {
-                    const uint64_t urow = row0 + row;
-                    s_hdr[t][cl] = make_uint4(1u | (opens ? 2u : 0u), (recno + au) & (FU_RECS - 1), (uint32_t)urow, (uint32_t)(urow >> 32));
+                // ---- up to FU_T units.  Their lines were asked for FU_DT turns ago (or by the segment's set-up) and every
+                //      turn since has asked for 2 FU_T more: all but the FU_WAIT newest loads of this wave done means they are
+                //      there (loads return in order; whatever else the wave loaded or stored in between only makes them older)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FU_WAIT) : "memory");
+                const uint32_t ubase = u;
+                const uint32_t cnt = nu - u < (uint32_t)FU_T ? nu - u : (uint32_t)FU_T;
+                int4 na = s_ring[pbase][0][lane], nb = s_ring[pbase][1][lane];
+                for (uint32_t qu = 0; qu < (uint32_t)FU_T; qu++) {
+                    int4 xa = na, xb = nb;
+                    // (the next unit's lines are on their way from LDS while this one is worked on)
+                    const uint32_t nq = qu + 1u < (uint32_t)FU_T ? qu + 1u : qu;
+                    na = s_ring[pbase + nq][0][lane];
+                    nb = s_ring[pbase + nq][1][lane];
+                    if (qu < cnt) {
+#if defined(DVDA_EXP_STAMP)
+                        FU_STAMP(0);
+#endif
+                        filter_unit(xa, xb);
+                        FU_STAMP(1);
+                        int32_t *const X = s_x[t][qu] + cl * FU_XS;
+                        reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
+                        reinterpret_cast<int4 *>(X + p * 8)[1] = xb;
+                    }
                 }
-                if (opens)
-                    dma_rec(au + 2u);       // two access units ahead: there when the output wave opens that unit
-                dma_unit(u + (uint32_t)FU_DEPTH, place);
-                u++;
+                u += cnt;
+                if (p == 0)
+                    s_cnt[t][cl] = cnt | (fresh ? 0x100u : 0u);
+                fresh = false;
+                FU_STAMP(6);
+                // the record of an access unit the output wave opens (FU_DT + 1) turns from now at the earliest
+                if (au_issue < n_au && u >= au_issue_at) {
+                    dma_rec(au_issue);
+                    au_issue++;
+                    au_issue_at += rpu;
+                }
+                FU_STAMP(7);
+                // the units of the turn FU_DT turns from now, into the ring places this turn has emptied (past the segment's
+                // end the last unit again: the count of loads per turn is what the wait above goes by)
+#pragma unroll
+                for (int qu = 0; qu < FU_T; qu++)
+                    dma_unit(ubase + (uint32_t)(FU_RING + qu), pbase + (uint32_t)qu);
             }
+            FU_STAMP(2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            FU_STAMP(3);
             turn++;
-            if (run && u == nu) {
+            ring_phase = ring_phase + 1u == (uint32_t)FU_DT ? 0u : ring_phase + 1u;
+            if (ran && u == nu) {
                 // ---- the segment is through: its history (what a later call, or the next chain, continues from), its status
                 run = false;
                 if (filt) {
@@ -1114,16 +1032,18 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                     fail = ST_ENVELOPE;                 // a substream's channel range changes under a running history
                 const uint32_t R = (r.nframes - r.ndrop) * rpa;
                 const uint4 pl = DVDA_AT(a.plan, seg, a.caps.max_seg + 1u, BT_C_PLAN);
+                const uint32_t fb = a.seg_fbase[seg];
                 if (!fail && (R == 0 ||
                               !DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES) ||
-                              !DVDA_RANGE_OK((size_t)(pl.x / 40u) * FREC_WORDS, (size_t)(r.nframes - r.ndrop) * FREC_WORDS, a.caps.frec, BT_C_FREC)))
+                              !DVDA_RANGE_OK((size_t)(pl.x / 40u) * FREC_WORDS, (size_t)(r.nframes - r.ndrop) * FREC_WORDS, a.caps.frec, BT_C_FREC) ||
+                              !DVDA_RANGE_OK(brec_offset(pl.x, pl.y, 0, R), (uint64_t)S * brec_capacity(R), a.caps.brec, BT_C_BREC)))
                     fail = ST_CAPACITY;
                 if (fail) {
                     stop_chain(fail);
                 } else {
                     filt = slot_of(meta0, meta1, sub, k);
                     seg_iir = ((meta0 | meta1) & 0x200u) != 0;       // (chain-uniform: every lane goes frame by frame then)
-                    row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
+                    row0 = (uint64_t)(fb - fbase_first) * rpa;
                     if (p == 0) {
                         a.seg_rows[seg] = R;
                         if (row0 + R > out_stride)
@@ -1132,37 +1052,60 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                     Q = reinterpret_cast<const int4 *>(a.res + (size_t)pl.x * 8u) + p;
                     F0 = a.frec + (size_t)(pl.x / 40u) * FREC_WORDS;
                     n_au = r.nframes - r.ndrop;
-                    rp = a.brec + 8ull * pl.x + 128ull * pl.y + (size_t)sub * brec_capacity(R);
-                    // (the parse pass ends a substream's records with a terminator inside its brec_capacity(R) words; a
-                    //  walk that gets there without meeting it stops, and the segment is reported)
-                    rp_end = (a.brec + a.caps.brec) - (rp + brec_capacity(R)) >= 0 ? rp + brec_capacity(R) - 1
-                                                                                  : a.brec + (a.caps.brec ? a.caps.brec - 1 : 0);
+                    sbase = a.brec + brec_offset(pl.x, pl.y, sub, R);
+                    rbase = sbase + BREC_SLOT * k;
+                    // (the parse pass ends a substream's records with a terminator; a walk that has taken as many
+                    //  records as the substream can hold without meeting it stops, and the segment is reported)
+                    rmax = (R >> 3) + 1u;
                     nu = R >> 3;                        // (a segment is a whole number of 40-frame access units)
                     u = 0;
                     overrun = false;
                     left = 0xFFFFFFFFu;
+                    tgt = 0;
+                    rnext = 0;
+                    rcur = 0;
                     srow = 0;
                     next_row = 0xFFFFFFFFu;
+                    need_first = false;
                     if (filt) {
-                        if (seg_iir)
-                            next_row = rp[0];
-                        else
-                            preload(0);
-                    }
-                    // the first two access units' records, then the unit pipeline: unit w of the segment is taken in
-                    // turn (turn + w), i.e. from ring place (turn + w) % FU_DEPTH -- the ring is indexed by the turn, so a
-                    // chain that starts a segment joins the ring at the phase the wave is in
-                    dma_rec(0);
-                    dma_rec(1);
-                    {
-                        const uint32_t t0 = __builtin_amdgcn_readfirstlane(turn);
+                        if (seg_iir) {
+                            next_row = rbase[0];
+                        } else {
+                            // the slot's first records (asked for before the units: there when the first unit is)
+                            need_first = true;
 #pragma unroll
-                        for (int w = 0; w < FU_DEPTH; w++)
-                            dma_unit((uint32_t)w, (t0 + (uint32_t)w) & (uint32_t)(FU_DEPTH - 1));
+                            for (int q = 0; q < FU_BRECS; q++)
+                                rec_dma((uint32_t)q, turn - 128u);      // ("long ago": the first unit's wait covers them)
+                        }
+                    }
+                    // the first access units' records, then the unit pipeline: unit w of the segment is taken in turn
+                    // (turn + w / FU_T), i.e. from ring place ((ring_phase + w / FU_T) % FU_DT) * FU_T + w % FU_T -- the ring is
+                    // indexed by the turn, so a chain that starts a segment joins the ring at the phase the wave is in
+                    for (uint32_t q = 0; q <= rec_ahead; q++)
+                        dma_rec(q);
+                    au_issue = rec_ahead + 1u;
+                    au_issue_at = rpu;
+                    fresh = true;
+                    if (p == 0) {
+                        // what the output wave needs to know of the segment (it looks when the first units arrive)
+                        const uint64_t fp = reinterpret_cast<uint64_t>(F0);
+                        s_seg[cl][0] = make_uint4((uint32_t)row0, (uint32_t)(row0 >> 32), (uint32_t)fp, (uint32_t)(fp >> 32));
+                        s_seg[cl][1] = make_uint4(recno, 0, 0, 0);
+                    }
+                    {
+                        uint32_t ph = __builtin_amdgcn_readfirstlane(ring_phase);
+#pragma unroll
+                        for (int w = 0; w < FU_RING; w++) {
+                            dma_unit((uint32_t)w, ph * (uint32_t)FU_T + (uint32_t)(w % FU_T));
+                            if (w % FU_T == FU_T - 1)
+                                ph = ph + 1u == (uint32_t)FU_DT ? 0u : ph + 1u;
+                        }
                     }
                     run = true;
                     // (everything the set-up loaded is in its registers when the turns go on)
                     fu_use(row0);
+                    fu_use(rmax);
+                    fu_use(next_row);
                     fu_use(nu);
                     fu_use(n_au);
                     fu_use(meta0);
@@ -1175,149 +1118,18 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 }
             }
         }
+        FU_STAMP(4);
         if (!__any(alive))
             break;
     }
+#if defined(DVDA_EXP_STAMP)
+    if (lane == 0 && a.dbg)
+        for (int i = 0; i < 8; i++)
+            atomicAdd(&a.dbg[16 + i], fu_acc[i]);
+#endif
     if (lane == 0)
         s_ctl[turn & 1u] = FU_DONE;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// ---------------------------------------------------------------------------------------------- rematrix
-// One lane per PCM frame of a deferred segment: noise, matrices, output shift (src/mlp.c:1308-1358, 515-525),
-// RIFF channel order (src/mlp.c:416-438, 527-533).  grid = (deferred segments, ceil(longest segment / 256)).
-__global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
-{
-    const uint32_t n = chain_n_seg(a);
-    // one workgroup per deferred segment (times remat_blocks for very long ones): what it has to look up about the
-    // segment -- five dependent loads -- is looked up once, not once per 256 PCM frames
-    const uint32_t j = blockIdx.x / a.remat_blocks, by0 = blockIdx.x % a.remat_blocks;
-    if (j >= a.plan[n].y)
-        return;
-    const uint32_t seg = DVDA_AT(a.def_list, j, a.caps.max_seg, BT_C_DEF);
-    const uint32_t ss = DVDA_AT(a.seg_status, seg, a.caps.max_seg, BT_C_STATUS);
-    if (!(ss & ST_GENERAL) || (ss & ~ST_INFO))
-        return;                                     // not filtered (its chain stopped before it)
-    const SegRec r = a.seg[seg];
-    const StreamRec sr = a.streams[r.stream];
-    const uint32_t rpa = rows_per_au((sr.sync >> 8) & 0xF);
-    const uint32_t R = (r.nframes - r.ndrop) * rpa;
-    const uint64_t row0 = (uint64_t)(a.seg_fbase[seg] - a.seg_fbase[sr.first_seg]) * rpa;
-    const uint64_t out_stride = a.out_stride[r.stream];
-    if (by0 == 0 && threadIdx.x == 0) {
-        a.seg_rows[seg] = R;
-        if (row0 + R > out_stride)
-            atomicOr(&a.seg_status[seg], ST_OVERFLOW);          // rows = the size needed
-    }
-    const uint32_t assignment = (sr.sync >> 16) & 0x1F;
-    const uint32_t nch_out = channel_count(assignment);
-    const uint32_t wavepk = wave_pack(assignment);
-    // packed WAV payload (a.wav_bits): the block's rows are assembled as bytes in LDS and leave as consecutive
-    // dwords -- a row is 18 (24-bit, 6-ch) bytes, not a whole number of dwords; a block starts dword-aligned
-    // (256 rows, and a segment's first row is a multiple of 40)
-    __shared__ uint8_t s_b[256 * 6 * 3];
-    const uint4 pl = a.plan[seg];
-    if (!DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES) ||
-        !DVDA_RANGE_OK((size_t)(pl.x / 40u) * FREC_WORDS, (size_t)(r.nframes - r.ndrop) * FREC_WORDS, a.caps.frec, BT_C_FREC))
-        return;
-    int32_t *out = a.pcm + a.out_off[r.stream];
-    for (uint32_t by = by0; by * 256u < R; by += a.remat_blocks) {
-    const uint32_t row = by * 256u + threadIdx.x;
-    int32_t ch[MAXCH];
-#pragma unroll
-    for (int c = 0; c < MAXCH; c++)
-        ch[c] = 0;
-    if (row < R) {
-        const int32_t *P = a.res + (size_t)pl.x * 8u + res_index(row, 0);
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-            ch[c] = P[c * 4];
-        const uint32_t bypass_bits = (uint32_t)P[6 * 4];
-        const uint32_t seed = (uint32_t)P[7 * 4];
-        const uint32_t *F = a.frec + ((size_t)(pl.x / 40u) + row / rpa) * FREC_WORDS;
-        const uint32_t w0 = F[0];
-        const uint32_t noise_shift = w0 & 0xFFu, matrix_len = (w0 >> 8) & 0xFFu, mmc = w0 >> 16;
-        const uint32_t outch_pack = F[1], qss_pack = F[2], oshift_pack = F[3];
-        const uint32_t shifted = (seed >> 7) & 0xFFFFu;
-        const int32_t n0 = (int32_t)((uint32_t)(int32_t)(int8_t)(seed >> 15) << noise_shift);
-        const int32_t n1 = (int32_t)((uint32_t)(int32_t)(int8_t)shifted << noise_shift);
-        for (uint32_t m = 0; m < matrix_len; m++) {
-            const uint32_t *M = F + 4 + m * 5;
-            const uint32_t nz = M[4];
-            int64_t acc = (int64_t)n0 * (int64_t)lo16(nz) + (int64_t)n1 * (int64_t)hi16(nz);
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const uint32_t w = M[c >> 1];
-                acc += (int64_t)ch[c] * (int64_t)((c & 1) ? hi16(w) : lo16(w));
-            }
-            const uint32_t oc = nib(outch_pack, m);
-            const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_pack, oc)) + ((bypass_bits >> m) & 1u));
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                ch[c] = (uint32_t)c == oc ? nv : ch[c];
-        }
-        if (oshift_pack) {
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                if ((uint32_t)c <= mmc)
-                    ch[c] = (int32_t)((uint32_t)ch[c] << nib(oshift_pack, c));
-        }
-    }
-    const uint64_t orow = row0 + row;
-    if (a.wav_bits) {
-        const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
-        const uint64_t blk_row0 = row0 + (uint64_t)by * 256u;            // first output row of the block
-        uint32_t nvalid = R - by * 256u < 256u ? R - by * 256u : 256u;
-        if (blk_row0 >= out_stride)
-            nvalid = 0;
-        else if (blk_row0 + nvalid > out_stride)
-            nvalid = (uint32_t)(out_stride - blk_row0);
-        if (threadIdx.x < nvalid) {
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                if ((uint32_t)c < nch_out) {
-                    const uint32_t u = wav_signed(ch[c], a.wav_bits);
-                    uint8_t *e = s_b + threadIdx.x * spf + nib(wavepk, c) * nb;
-                    e[0] = (uint8_t)u;
-                    e[1] = (uint8_t)(u >> 8);
-                    if (nb == 3u)
-                        e[2] = (uint8_t)(u >> 16);
-                }
-        }
-        __syncthreads();
-        const uint32_t nbytes = nvalid * spf;
-        uint8_t *ob = reinterpret_cast<uint8_t *>(out) + blk_row0 * spf;
-        const uint32_t *sd = reinterpret_cast<const uint32_t *>(s_b);
-        for (uint32_t d = threadIdx.x; d < (nbytes >> 2); d += 256u)
-            reinterpret_cast<uint32_t *>(ob)[d] = sd[d];
-        for (uint32_t b = (nbytes & ~3u) + threadIdx.x; b < nbytes; b += 256u)
-            ob[b] = s_b[b];
-        __syncthreads();                            // (the next block of frames assembles in the same LDS)
-        continue;
-    }
-    if (row >= R || orow >= out_stride)
-        continue;
-    if (a.interleaved && nch_out == 6u && ((reinterpret_cast<uintptr_t>(out) | (orow * 24u)) & 7u) == 0) {
-        // six channels, frame-major, the frame 8-byte aligned: three 8-byte stores instead of six scattered dwords
-        int32_t o[6];
-#pragma unroll
-        for (int w = 0; w < 6; w++) {
-            o[w] = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                o[w] = nib(wavepk, c) == (uint32_t)w ? ch[c] : o[w];
-        }
-        int2 *dst = reinterpret_cast<int2 *>(out + orow * 6u);
-        dst[0] = make_int2(o[0], o[1]);
-        dst[1] = make_int2(o[2], o[3]);
-        dst[2] = make_int2(o[4], o[5]);
-        continue;
-    }
-#pragma unroll
-    for (int c = 0; c < 6; c++)
-        if ((uint32_t)c < nch_out)
-            out[a.interleaved ? orow * nch_out + nib(wavepk, c) : (uint64_t)nib(wavepk, c) * out_stride + orow] = ch[c];
-    }
 }
 
 } // namespace mlp

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     const uint32_t chk = a.seg_check[(size_t)segi * 2u + sub];
     bool stop = false;
     // ---- parse pass: where this segment's planes and records go (ChainPlan, mlp_chain.h)
-    uint32_t *brec = nullptr, *brec_end = nullptr, *frec = nullptr;
+    uint32_t *brec = nullptr, *brec_end = nullptr, *brec_base = nullptr, *frec = nullptr;
     int32_t *planes = nullptr;
     bool seg_iir = false;
     if (PARSE) {
@@ -254,14 +254,15 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         const uint32_t seg_R = (sr.nframes - sr.ndrop) * rpa;
         const uint32_t cap = brec_capacity(seg_R);
         planes = a.res + (uint64_t)pl.x * 8u;
-        brec = a.brec + 8ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap;
-        brec_end = brec + cap - 2u;                 // room for the terminator
+        brec = a.brec + brec_offset(pl.x, pl.y, sub, seg_R);
+        brec_base = brec;
+        brec_end = brec + cap;                      // (IIR words are dealt from here downwards)
         frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
         if (lane == 0)
             atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
         // (range-checked build: the segment's planes, block records and per-unit records lie inside the workspaces)
         if (!DVDA_RANGE_OK((uint64_t)pl.x * 8u, 8ull * seg_R, a.caps.res, BT_RES) ||
-            !DVDA_RANGE_OK(8ull * pl.x + 128ull * pl.y, (uint64_t)S * cap, a.caps.brec, BT_BREC) ||
+            !DVDA_RANGE_OK(brec_offset(pl.x, pl.y, 0, seg_R), (uint64_t)S * cap, a.caps.brec, BT_BREC) ||
             !DVDA_RANGE_OK((uint64_t)(pl.x / 40u) * FREC_WORDS, (uint64_t)(sr.nframes - sr.ndrop) * FREC_WORDS, a.caps.frec, BT_FREC)) {
             if (lane == 0)
                 atomicOr(&a.seg_status[segi], ST_CAPACITY);
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     bool ok = true;
                     uint32_t e1 = ST_PARAMS;
                     uint32_t new_iir_mask = 0;
-                    uint32_t chg_mask = 0, iir_mask = 0, rec_words = 0;     // parse pass: this block's record
+                    uint32_t chg_mask = 0;                  // parse pass: slots this block's record sets
                     bool seq_needed = false, hdr_restart = false;
                     if (rd.read(1)) {
                         const bool restart = rd.read(1) != 0;
@@ -614,27 +615,26 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                                             //      the history it starts from
                                             const bool nw_iir = ((new_iir_mask >> k) & 1u) != 0;
                                             const bool with_iir = nw_iir && iir_order != 0;
-                                            uint32_t *w = brec + 2 + rec_words;
-                                            if (w + BREC_SLOT_WORDS + (with_iir ? BREC_IIR_WORDS : 0) > brec_end) {
+                                            // (room for this record, the terminator behind it and the slot's IIR words)
+                                            if (brec + 2 * BREC_STRIDE + (with_iir ? BREC_IIR_WORDS : 0) > brec_end) {
                                                 seq_needed = true;      // more parameter changes than the records hold
                                             } else {
+                                                uint32_t *w = brec + BREC_SLOT * k;
+                                                if (with_iir)
+                                                    brec_end -= BREC_IIR_WORDS;
                                                 if (lane == 0) {
-                                                    w[0] = shift | (q << 4) | (fir_order << 8) | (iir_order << 12) | (nw_iir ? 1u << 16 : 0u);
+                                                    w[2] = shift | (q << 4) | (fir_order << 8) | (iir_order << 12) | (nw_iir ? 1u << 16 : 0u);
                                                     for (uint32_t j = 0; j < 4; j++)
-                                                        w[1 + j] = P.cf[k][j];
+                                                        w[3 + j] = P.cf[k][j];
+                                                    w[7] = with_iir ? (uint32_t)(brec_end - brec_base) : 0u;
                                                     if (with_iir) {
                                                         for (uint32_t j = 0; j < 4; j++)
-                                                            w[5 + j] = P.icf[k][j];
+                                                            brec_end[j] = P.icf[k][j];
                                                         for (uint32_t j = 0; j < 8; j++)
-                                                            w[9 + j] = (uint32_t)P.ihist[k][j];
+                                                            brec_end[4 + j] = (uint32_t)P.ihist[k][j];
                                                     }
                                                 }
                                                 chg_mask |= 1u << k;
-                                                rec_words += BREC_SLOT_WORDS;
-                                                if (with_iir) {
-                                                    iir_mask |= 1u << k;
-                                                    rec_words += BREC_IIR_WORDS;
-                                                }
                                             }
                                         }
                                     }
@@ -660,11 +660,11 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         break;
                     }
                     if (PARSE && chg_mask) {
-                        if (lane == 0) {
-                            brec[0] = frames_out * rpa + frame_rows;    // first PCM frame (of the segment) the record applies to
-                            brec[1] = chg_mask | (iir_mask << 8);
+                        if (lane < 6u) {
+                            brec[BREC_SLOT * lane] = frames_out * rpa + frame_rows;     // first PCM frame (of the segment) the record applies to
+                            brec[BREC_SLOT * lane + 1] = (chg_mask >> lane) & 1u;
                         }
-                        brec += 2 + rec_words;
+                        brec += BREC_STRIDE;
                     }
                     if (PARSE && (seq_needed || (hdr_restart && blocks_in_frame))) {
                         err = ST_SEQ;               // a restart header inside a unit, or records overflowed: the whole
@@ -1040,7 +1040,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         //      runs IIR taps, for the filter pass
         if (lane == 0) {
             if (!stop) {
-                brec[0] = brec[1] = 0xFFFFFFFFu;
+                for (uint32_t kk = 0; kk < 6u; kk++)
+                    brec[BREC_SLOT * kk] = 0xFFFFFFFFu;
                 a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8) | (seg_iir ? 1u << 9 : 0u);
             }
             if (status)

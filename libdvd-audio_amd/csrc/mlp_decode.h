@@ -155,13 +155,24 @@ constexpr uint32_t HDR_RESIDENT = 16;       // dwords the header parser tops the
                                             // chunk: the most ensure() may ask of a two-chunk ring)
 constexpr uint32_t SUMMARY_PARTS = 64;      // the fast pass adds into summary[1 + block % 64]; k_finalize folds them into summary[0]
 constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
-constexpr int BREC_SLOT_WORDS = 5; // per changed channel slot: packed parameters + 4 coefficient pairs ...
-constexpr int BREC_IIR_WORDS = 12; // ... + when the block (re)sets the slot's IIR: 4 coefficient pairs + 8 history values
-// block-record dwords one (segment, substream) may use: four per PCM frame -- a block that sets the FIR of all
-// six slots needs 32, one that also loads six IIRs 104, and a block has at least 8 frames; the BASELINE recipe
-// uses 1 % of that.  A segment that changes parameters more densely still is decoded by the sequential pass
-// instead (ST_SEQ)
-__host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return 4u * rows + 64u; }
+// Block records (round 4: fixed places, so that the pass that reads them can ask for a record before it knows
+// what the record before it holds).  Record r of a (segment, substream) -- its r-th block that sets filter
+// parameters -- is six slots of eight dwords at r * BREC_STRIDE; slot k:
+//   [0] first PCM frame (of the segment) the block applies to; 0xFFFFFFFF: no further record
+//   [1] bit 0: the block sets this slot's parameters
+//   [2] shift | quant step << 4 | FIR order << 8 | IIR order << 12 | "the block (re)sets the slot's IIR" << 16
+//   [3..6] the eight FIR taps, int16 pairs
+//   [7] != 0: where the slot's IIR words are (dwords from the substream's first record): 4 tap pairs + 8 history values
+// A block has at least 8 PCM frames, so rows / 8 records and the terminator behind them are 6 * rows + 48 dwords at
+// most; the IIR words are dealt from the END of the capacity downwards, and a segment that needs more of them than
+// fit is decoded by the sequential pass instead (ST_SEQ).
+constexpr int BREC_SLOT = 8, BREC_STRIDE = 6 * BREC_SLOT, BREC_IIR_WORDS = 12;
+__host__ __device__ inline uint32_t brec_capacity(uint32_t rows) { return 8u * rows + 128u; }
+// where the records of (segment, substream) start: plan entry (.x rows, .y segments deferred before it)
+__host__ __device__ inline uint64_t brec_offset(uint32_t rows_before, uint32_t segs_before, uint32_t sub, uint32_t rows)
+{
+    return 16ull * rows_before + 256ull * segs_before + (uint64_t)sub * brec_capacity(rows);
+}
 // write_signed(bits, v) of the reference's little-endian writer (src/bitstream.c:2846-2857): the low bits - 1
 // bits of v, then a sign bit taken from v < 0 -- NOT plain truncation for values outside the nominal width
 __device__ __forceinline__ uint32_t wav_signed(int32_t v, uint32_t bits)
@@ -192,7 +203,7 @@ __host__ __device__ inline size_t res_index(uint32_t row, uint32_t plane)
 }
 // where the chain workspaces of a deferred segment start, from its ChainPlan entry (rows / deferred
 // segments before it): planes at res + 8 * rows_before; block records (two substreams) at
-// brec + 8 * rows_before + 128 * segs_before; per-access-unit records at frec[rows_before / 40 + unit]
+// brec + brec_offset(); per-access-unit records at frec[rows_before / 40 + unit]
 // (40 = the shortest access unit: a segment's rows / 40 is at least its number of units)
 
 struct DecodeArgs {
@@ -673,7 +684,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // chain parse pass: the segment's planes [8][R] of residuals (+ bypassed LSBs, noise seeds) take the
     // place of the PCM buffer
     uint32_t seg_R = 0;                      // PCM frames of this segment at standard timing
-    uint32_t *brec = nullptr, *brec_end = nullptr;
+    uint32_t *brec = nullptr, *brec_end = nullptr, *brec_base = nullptr;
     uint32_t *frec = nullptr;
     if (PARSE && active) {
         const uint4 pl = DVDA_AT(a.plan, segi, a.caps.max_seg + 1u, BT_PLAN);
@@ -684,14 +695,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         row0 = 0;
         row_limit = seg_R;
         const uint32_t cap = brec_capacity(seg_R);
-        brec = a.brec + 8ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap;
-        brec_end = brec + cap - 2u;                 // room for the terminator
+        brec = a.brec + brec_offset(pl.x, pl.y, sub, seg_R);
+        brec_base = brec;
+        brec_end = brec + cap;                      // (IIR words are dealt from here downwards)
         frec = a.frec + (uint64_t)(pl.x / 40u) * FREC_WORDS;
         (void)st_j;
         atomicAnd(&a.seg_status[segi], ST_DEFERRED | ST_FATAL_INDEX | ST_TRUNCATED | ST_SYNC_CHANGE);
         // (range-checked build: the segment's planes, block records and per-unit records lie inside the workspaces)
         if (!DVDA_RANGE_OK(out_base, 8ull * seg_R, a.caps.res, BT_RES) ||
-            !DVDA_RANGE_OK(8ull * pl.x + 128ull * pl.y + (uint64_t)sub * cap, cap, a.caps.brec, BT_BREC) ||
+            !DVDA_RANGE_OK(brec_offset(pl.x, pl.y, sub, seg_R), cap, a.caps.brec, BT_BREC) ||
             !DVDA_RANGE_OK((uint64_t)(pl.x / 40u) * FREC_WORDS, (uint64_t)(sr.nframes - sr.ndrop) * FREC_WORDS, a.caps.frec, BT_FREC)) {
             status |= ST_CAPACITY;
             active = false;
@@ -902,8 +914,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                     if (GENERAL || PARSE)
                         a.seg_meta[seg_lane] = min_ch | (max_ch << 4) | (1u << 8) | (seg_iir ? 1u << 9 : 0u);
-                    if (PARSE && brec)
-                        brec[0] = brec[1] = 0xFFFFFFFFu;         // end of this (segment, substream)'s records
+                    if (PARSE && brec) {
+#pragma unroll
+                        for (int kk = 0; kk < 6; kk++)
+                            brec[BREC_SLOT * kk] = 0xFFFFFFFFu;  // end of this (segment, substream)'s records
+                    }
                     bool go_on = false;
                     if (GENERAL) {
                         atomicOr(&a.seg_status[segi], status | ((status & ~ST_INFO) ? 0u : ST_GENERAL));
@@ -1014,7 +1029,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 bool matrix_class_change = false;
                 bool hdr_restart = false;
                 bool too_wide = false;
-                uint32_t chg_mask = 0, iir_mask = 0, rec_words = 0;   // chain parse pass: slots whose filter parameters this block sets
+                uint32_t chg_mask = 0;                     // chain parse pass: slots whose filter parameters this block sets
                 bool seq_needed = false;                   // ... and what only the sequential pass decodes
                 // two-wave layout, the lane that rematrixes with the OTHER substream's parameters: its own
                 // header sets the same variables (the parse below needs them: matrix count, bypass flags); they
@@ -1360,26 +1375,28 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                         //      (re)sets the slot's IIR -- its taps and the history it starts from
                                         //      (most recent first, as the header parse left them in the workspace)
                                         const bool with_iir = new_iir && iir_order != 0;
-                                        uint32_t *w = brec + 2 + rec_words;
-                                        if (w + BREC_SLOT_WORDS + (with_iir ? BREC_IIR_WORDS : 0) > brec_end) {
+                                        // (room for this record, the terminator behind it and the slot's IIR words)
+                                        if (brec + 2 * BREC_STRIDE + (with_iir ? BREC_IIR_WORDS : 0) > brec_end) {
                                             seq_needed = true;      // more parameter changes than the records hold
                                         } else {
-                                            w[0] = shift | (q << 4) | (fir_order << 8) | (iir_order << 12) |
+                                            uint32_t *w = brec + BREC_SLOT * k;
+                                            w[2] = shift | (q << 4) | (fir_order << 8) | (iir_order << 12) |
                                                    (new_iir ? 1u << 16 : 0u);
 #pragma unroll
                                             for (int j = 0; j < 4; j++)
-                                                w[1 + j] = new_fir ? ncf[j] : cf_old[j];
+                                                w[3 + j] = new_fir ? ncf[j] : cf_old[j];
+                                            w[7] = 0;
                                             chg_mask |= 1u << k;
-                                            rec_words += BREC_SLOT_WORDS;
                                             if (with_iir) {
                                                 const int32_t *ws = a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl;
+                                                brec_end -= BREC_IIR_WORDS;
+                                                uint32_t *x = brec_end;
                                                 for (uint32_t j = 0; j < 4; j++)
-                                                    w[5 + j] = ((uint32_t)ws[(size_t)(2 * j) * a.total_lanes] & 0xFFFFu) |
-                                                               ((uint32_t)ws[(size_t)(2 * j + 1) * a.total_lanes] << 16);
+                                                    x[j] = ((uint32_t)ws[(size_t)(2 * j) * a.total_lanes] & 0xFFFFu) |
+                                                           ((uint32_t)ws[(size_t)(2 * j + 1) * a.total_lanes] << 16);
                                                 for (uint32_t j = 0; j < 8; j++)
-                                                    w[9 + j] = (uint32_t)ws[(size_t)(8 + j) * a.total_lanes];
-                                                iir_mask |= 1u << k;
-                                                rec_words += BREC_IIR_WORDS;
+                                                    x[4 + j] = (uint32_t)ws[(size_t)(8 + j) * a.total_lanes];
+                                                w[7] = (uint32_t)(x - brec_base);
                                             }
                                         }
                                     }
@@ -1396,9 +1413,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 if (PARSE && iir_any)
                     seg_iir = true;
                 if (PARSE && ok && chg_mask) {
-                    brec[0] = rows_done;                // first PCM frame (of the segment) the record applies to
-                    brec[1] = chg_mask | (iir_mask << 8);
-                    brec += 2 + rec_words;
+#pragma unroll
+                    for (int kk = 0; kk < 6; kk++) {
+                        brec[BREC_SLOT * kk] = rows_done;       // first PCM frame (of the segment) the record applies to
+                        brec[BREC_SLOT * kk + 1] = (chg_mask >> kk) & 1u;
+                    }
+                    brec += BREC_STRIDE;
                 }
                 if (PARSE && ok && (seq_needed || (hdr_restart && blocks_in_frame))) {
                     // a restart header inside a frame (the noise seed of the frame's earlier rows changes under

@@ -95,6 +95,8 @@ struct dvda_mlp_hip_ctx {
     uint4 *d_scan4_tmp;        // [max_segments / 1024 + 2]
     uint32_t *d_def_list;      // [max_segments]
     uint32_t *d_head_list;     // [max_segments]
+    uint32_t *d_chain_order;   // [max_segments]: the chains, longest first
+    uint32_t *d_chain_hist;    // [2 * CHAIN_BUCKETS]
     // grown on first use (a batch that needs them):
     int32_t *d_fb;             // sequential pass: one frame buffer per lane pair of a round
     uint32_t fb_slots;
@@ -201,6 +203,8 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_scan4_tmp);
     (void)hipFree(c->d_def_list);
     (void)hipFree(c->d_head_list);
+    (void)hipFree(c->d_chain_order);
+    (void)hipFree(c->d_chain_hist);
     (void)hipFree(c->d_fb);
     (void)hipFree(c->d_res);
     (void)hipFree(c->d_brec);
@@ -262,7 +266,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->iir_lanes = (uint32_t)(((2 * ns + DEC_THREADS - 1) / DEC_THREADS) * DEC_THREADS);
     alloc((void **)&c->d_iir, (size_t)c->iir_lanes * MAXCH * 16 * sizeof(int32_t));
     alloc((void **)&c->d_mat, (size_t)c->iir_lanes * MAXMAT * 5 * sizeof(uint32_t));
-    alloc((void **)&c->d_dbg, 16 * sizeof(unsigned long long));
+    alloc((void **)&c->d_dbg, 32 * sizeof(unsigned long long));
     alloc((void **)&c->d_fir, (size_t)c->iir_lanes * 6 * 8 * sizeof(int32_t));
     alloc((void **)&c->d_seg_meta, (size_t)c->iir_lanes * sizeof(uint32_t));
     alloc((void **)&c->d_yield, ns * sizeof(uint32_t));
@@ -281,10 +285,12 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_scan4_tmp, (ns / 1024 + 4) * sizeof(uint4));
     alloc((void **)&c->d_def_list, ns * sizeof(uint32_t));
     alloc((void **)&c->d_head_list, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_chain_order, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_chain_hist, 2 * CHAIN_BUCKETS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->h_summary, sizeof(DecodeSummary), hipHostMallocDefault);
     if (e == hipSuccess)
-        e = hipMemset(c->d_dbg, 0, 16 * sizeof(unsigned long long));
+        e = hipMemset(c->d_dbg, 0, 32 * sizeof(unsigned long long));
     if (e == hipSuccess)
         e = hipMemset(c->d_seg_meta, 0, (size_t)c->iir_lanes * sizeof(uint32_t));
     // the event ring is made here: the decode calls create nothing
@@ -663,7 +669,7 @@ __global__ void k_chain_guard(uint4 *plan, const uint32_t *n_seg_ptr, uint32_t m
         n = max_seg;
     const uint4 t = plan[n];
     const unsigned long long rows = t.x, segs = t.y;
-    if (segs > seg_cap || rows * 8 + 64 > caps.res || 8 * rows + 128ull * segs + 64 > caps.brec ||
+    if (segs > seg_cap || rows * 8 + 64 > caps.res || 16 * rows + 256ull * segs + 64 > caps.brec ||
         (rows / 40 + segs + 1) * FREC_WORDS > caps.frec)
         plan[n] = make_uint4(t.x, 0, 0, 0);
 }
@@ -679,7 +685,7 @@ extern "C" int dvda_mlp_hip_reserve(dvda_mlp_hip_ctx *c, uint64_t chain_pcm_fram
     int rc;
     if (chain_segments || chain_pcm_frames) {
         if ((rc = grow(&c->d_res, &c->res_cap, chain_pcm_frames * 8 + 64)) != 0 ||
-            (rc = grow(&c->d_brec, &c->brec_cap, 8 * chain_pcm_frames + 128ull * chain_segments + 64)) != 0 ||
+            (rc = grow(&c->d_brec, &c->brec_cap, 16 * chain_pcm_frames + 256ull * chain_segments + 64)) != 0 ||
             (rc = grow(&c->d_frec, &c->frec_cap, (chain_pcm_frames / 40 + chain_segments + 1) * FREC_WORDS)) != 0)
             return rc;
         if (chain_segments > c->rsv_segs)
@@ -814,11 +820,10 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     if (blocking ? c->h_summary->chain_segs != 0 : c->rsv_segs != 0) {
         const uint64_t rows = blocking ? c->h_summary->chain_rows : 0;
         const uint32_t segs = blocking ? c->h_summary->chain_segs : c->rsv_segs;
-        const uint32_t max_rows = blocking ? c->h_summary->chain_max_rows : 0;
         if (rows >> 32)
             return DVDA_HIP_ECAPACITY;          // plan entries are 32-bit (137 GB of planes)
         if (blocking && ((rc = grow(&c->d_res, &c->res_cap, rows * 8 + 64)) != 0 ||
-                         (rc = grow(&c->d_brec, &c->brec_cap, 8 * rows + 128ull * segs + 64)) != 0 ||
+                         (rc = grow(&c->d_brec, &c->brec_cap, 16 * rows + 256ull * segs + 64)) != 0 ||
                          (rc = grow(&c->d_frec, &c->frec_cap, (rows / 40 + segs + 1) * FREC_WORDS)) != 0))
             return rc;
         a.caps = ws_caps(c);
@@ -836,6 +841,8 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         ca.plan = c->d_plan;
         ca.def_list = c->d_def_list;
         ca.head_list = c->d_head_list;
+        ca.chain_order = c->d_chain_order;
+        ca.chain_hist = c->d_chain_hist;
         ca.res = c->d_res;
         ca.brec = c->d_brec;
         ca.frec = c->d_frec;
@@ -847,6 +854,7 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         ca.out_stride = d_out_stride;
         ca.interleaved = a.interleaved;
         ca.wav_bits = a.wav_bits;
+        ca.dbg = c->d_dbg;
         const unsigned sblocks = (unsigned)((ms + 1023) / 1024);
         hipLaunchKernelGGL(k_chain_plan, dim3((unsigned)((ms + 255) / 256)), dim3(256), 0, st, ca);
         hipLaunchKernelGGL(k_scan4_blocks, dim3(sblocks), dim3(1024), 0, st, c->d_plan, c->d_scan4_tmp, c->d_n_cand,
@@ -883,19 +891,13 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
                                    dim3(DEC_THREADS), 0, st, a);
             }
         }
-        static const bool split = getenv("DVDA_CHAIN_SPLIT") && atoi(getenv("DVDA_CHAIN_SPLIT")) != 0;
-        if (!split) {
-            // filter + rematrix in one walk over the planes: two waves per eight chains (at most one chain per deferred segment)
-            hipLaunchKernelGGL(k_chain_fused, dim3((unsigned)(((uint64_t)segs + 7) / 8)), dim3(FU_THREADS), 0, st, ca);
-        } else {
-        // filter: 16 lanes per chain (at most one chain per deferred segment)
-        hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);
-        // rematrix: one lane per PCM frame
-        // (a workgroup walks its segment 256 PCM frames at a time; segments of more than 16 such blocks share
-        //  the walk between several workgroups)
-        ca.remat_blocks = (max_rows + 4095) / 4096 ? (max_rows + 4095) / 4096 : 1;
-        hipLaunchKernelGGL(k_chain_rematrix, dim3(segs * ca.remat_blocks), dim3(256), 0, st, ca);
-        }
+        // the chains longest first (k_chain_fused's workgroups take eight neighbours of that order)
+        HIP_TRY(hipMemsetAsync(c->d_chain_hist, 0, CHAIN_BUCKETS * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_chain_hist, dim3((segs + 255) / 256), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(k_chain_scan, dim3(1), dim3(CHAIN_BUCKETS), 0, st, ca);
+        hipLaunchKernelGGL(k_chain_scatter, dim3((segs + 255) / 256), dim3(256), 0, st, ca);
+        // filter + rematrix in one walk over the planes: two waves per eight chains (at most one chain per deferred segment)
+        hipLaunchKernelGGL(k_chain_fused, dim3((unsigned)(((uint64_t)segs + 7) / 8)), dim3(FU_THREADS), 0, st, ca);
         HIP_TRY(hipMemsetAsync(&c->d_summary->seq_streams, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
@@ -1055,6 +1057,18 @@ extern "C" int dvda_mlp_hip_debug_counters(dvda_mlp_hip_ctx *c, unsigned long lo
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out16, c->d_dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(c->d_dbg, 0, 16 * sizeof(unsigned long long)));
+    return DVDA_HIP_OK;
+}
+
+// ... and the second half of them: k_chain_fused's two waves (tools/probe/fused_stamp.py)
+extern "C" int dvda_mlp_hip_debug_counters2(dvda_mlp_hip_ctx *c, unsigned long long *out16)
+{
+    if (!c || !out16)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, c->d_dbg + 16, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->d_dbg + 16, 0, 16 * sizeof(unsigned long long)));
     return DVDA_HIP_OK;
 }
 
