@@ -824,7 +824,7 @@ def plumbing_rank(args, rank, world):
         mine = np.arange(len(sizes))
     rows = int(frames[mine].sum())
     summ = pkg.shard.reduce_summary(dist if world > 1 else None, torch.device("cpu"), rows, rows * 6,
-                                    int(sizes[mine].sum()), 0, len(mine), 0.001 * (rank + 1))
+                                    int(sizes[mine].sum()), 0, len(mine), 0.001 * (rank + 1), checked=False)
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "Msamples/s", "n_gpus": world, "plumbing_only": True,
                           "scaling": "strong" if args.workload == "c4" else "weak",
@@ -988,7 +988,7 @@ def main():
     checksum = int(b.d_pcm.to(torch.int64).sum().item())
     summ = pkg.shard.reduce_summary(dist if world > 1 else None, dev if backend == "nccl" else torch.device("cpu"),
                                     b.rows_total, b.samples, b.comp_bytes, 0, checksum, elapsed,
-                                    verified=bool(bit_exact) or checked == 0)
+                                    verified=bool(bit_exact), checked=checked != 0)
     elapsed_max = summ["seconds"]
     job_samples = float(summ["samples"])
 
@@ -1054,7 +1054,7 @@ def main():
                             "load_imbalance": round(summ["bytes_max"] / mean_bytes, 4) if mean_bytes else None,
                             "bit_exact_on_every_rank": summ["all_verified"],
                             "titles_checked_per_rank": checked}
-            out["config"]["bit_exact"] = bool(bit_exact) and summ["all_verified"]
+            out["config"]["bit_exact"] = (bool(bit_exact) and bool(summ["all_verified"])) if checked else None
         if serial:
             out["serial_step"] = serial
         if latency:

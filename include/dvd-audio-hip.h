@@ -77,8 +77,16 @@ void dvda_hip_set_device(int device);
 /* on != 0: MLP track readers opened afterwards are decoded straight into the WAV payload dvda2wav would write
  * (the output stage -- dvda_read's interleave + write_signed at the stream's bit depth -- runs inside the decode
  * kernels, DVDA_PCM_WAV24 / DVDA_PCM_WAV16): no int32 PCM buffer, no packing pass.  Such a reader serves
- * dvda_hip_reader_wav_payload() only; dvda_read() on it returns 0.  Default off (the reference API's int samples). */
+ * dvda_hip_reader_wav_payload() only; dvda_read() on it returns 0 (dvda_hip_reader_wav_only() tells that case from an
+ * empty track).  Default off (the reference API's int samples). */
 void dvda_hip_set_wav_output(int on);
+/* Both options are per calling THREAD (a host that fans tracks out over several devices sets them in each worker).
+ * The per-reader form: opens the track on HIP device `device`, as a WAV-payload-only reader if wav_output != 0,
+ * whatever the thread's defaults are, and leaves those alone. */
+DVDA_Track_Reader *dvda_hip_open_track_reader_on(const DVDA_Track *track, int device, int wav_output);
+/* != 0: the reader holds the WAV payload only (opened with wav_output): dvda_read() on it returns 0 frames -- NOT
+ * because the track is empty; take the payload with dvda_hip_reader_wav_payload() */
+int dvda_hip_reader_wav_only(const DVDA_Track_Reader *reader);
 /* status word of the decode behind a reader: DVDA_ST_* bits of dvda_mlp_hip.h (0 = clean) */
 unsigned dvda_hip_reader_status(const DVDA_Track_Reader *reader);
 /* PCM frames the reader holds in total */

@@ -207,6 +207,39 @@ int dvda_mlp_hip_kernel_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *la
  * dvda_mlp_hip_kernel_time. */
 int dvda_mlp_hip_decode_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *calls);
 
+/* ------------------------------------------------------------------ several GPUs from one C host
+ * titles are independent -- the reference decodes one track at a time through one decoder,
+ * src/dvd-audio.c:597-657, and two decoders share nothing -- so a host with a list of streams gives every GPU its
+ * own sub-list: greedy longest-processing-time on the compressed size (dvda_mlp_hip_shard, the same deterministic
+ * partition as libdvd-audio_amd/shard.py), one host thread + decode context + HIP stream per device entry, no
+ * exchange between devices, a small summary added up on the host (csrc/mlp_multi.cpp).  The streams and the PCM are
+ * HOST buffers here (each device gets its own copies); a device may be named more than once. */
+typedef struct dvda_mlp_hip_multi dvda_mlp_hip_multi;
+typedef struct dvda_mlp_multi_summary {
+    uint64_t pcm_frames;                  /* sum over the streams                                         */
+    uint64_t samples;                     /* sum of pcm_frames x channels                                 */
+    uint64_t compressed_bytes;            /* sum of the stream lengths                                    */
+    uint64_t compressed_bytes_max_device; /* the largest share one device entry got (load balance)        */
+    uint32_t streams_with_errors;         /* streams whose status has a bit outside DVDA_ST_BENIGN        */
+    uint32_t devices;                     /* device entries the list was dealt to                         */
+} dvda_mlp_multi_summary;
+
+/* part_of[i] = which of `parts` parts stream i (sizes[i] bytes) goes to */
+int dvda_mlp_hip_shard(const uint64_t *sizes, uint32_t n, uint32_t parts, uint32_t *part_of);
+/* one decode context per entry of devices[]; every one sized for max_streams / max_segments */
+int dvda_mlp_hip_create_multi(dvda_mlp_hip_multi **multi, const int *devices, uint32_t n_devices,
+                              uint32_t max_streams, uint32_t max_segments);
+void dvda_mlp_hip_destroy_multi(dvda_mlp_hip_multi *multi);
+uint32_t dvda_mlp_hip_multi_devices(const dvda_mlp_hip_multi *multi);
+/* Decodes n_streams host streams (streams[i], lengths[i] bytes) and returns when all of them are done.  pcm[i]
+ * receives stream i in `layout` (DVDA_PCM_*): planar = [channel][capacity_frames[i]] int32, interleaved =
+ * [frame][channel] int32, WAV24 / WAV16 = the packed payload; capacity_frames[i] = PCM frames per channel pcm[i]
+ * has room for (a stream that needs more is reported DVDA_ST_OVERFLOW, infos[i].pcm_frames = the size needed).
+ * infos[i] as dvda_mlp_hip_stream_info would give it; summary may be NULL.  Blocks; no CPU fallback. */
+int dvda_mlp_hip_decode_multi(dvda_mlp_hip_multi *multi, const uint8_t *const *streams, const uint64_t *lengths,
+                              uint32_t n_streams, uint32_t layout, void *const *pcm, const uint64_t *capacity_frames,
+                              dvda_mlp_stream_info *infos, dvda_mlp_multi_summary *summary);
+
 /* Range-checked diagnostic build (-DDVDA_BOUNDS, tests/test_gpu_soak.py): every index a kernel forms into a
  * workspace of the library is compared with the workspace's size; out4 = {violations so far, and of the first
  * one: array tag, index, capacity}.  Returns 1 from a checked build, 0 from the shipped library (which does not

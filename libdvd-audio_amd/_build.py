@@ -21,7 +21,8 @@ DISC_SRCS = [os.path.join(HERE, "csrc", "dvda_disc.c"),
 
 # [0] the HIP translation unit, [1] the streaming tier; behind them EVERY header under csrc/ (the staleness
 # test looks at all of them: an edit to any header mlp_hip.hip includes rebuilds the library)
-HIP_SRCS = [os.path.join(HERE, "csrc", "mlp_hip.hip"), os.path.join(HERE, "csrc", "mlp_stream.c")]
+HIP_SRCS = [os.path.join(HERE, "csrc", "mlp_hip.hip"), os.path.join(HERE, "csrc", "mlp_stream.c"),
+            os.path.join(HERE, "csrc", "mlp_multi.cpp")]
 HIP_SRCS += sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))
 HIP_SRCS.append(os.path.join(os.path.dirname(HERE), "include", "dvda_mlp_hip.h"))
 SYNTH_SRCS = [os.path.join(HERE, "synth", f) for f in ("mlp_synth.c", "mlp_synth.h")]
@@ -58,8 +59,12 @@ def build_hip(force=False, verbose=False, defines=(), out=None):
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
-    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, obj_hip, obj_c],
-                   check=True)
+    # the multi-device dispatcher: host-only C++ on top of the entry points above
+    obj_multi = os.path.join(HERE, "csrc", "mlp_multi_%s.o" % tag)
+    subprocess.run(["g++", "-O2", "-fPIC", "-Wall", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-c", "-o", obj_multi, HIP_SRCS[2]], check=True)
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target, obj_hip, obj_c, obj_multi,
+                    "-lpthread"], check=True)
     return target
 
 
@@ -94,7 +99,7 @@ def build_tool(force=False):
         return TOOL
     os.makedirs(os.path.dirname(TOOL), exist_ok=True)
     subprocess.run(["gcc", "-O2", "-Wall", "-o", TOOL, TOOL_SRC, "-I" + os.path.join(os.path.dirname(HERE), "include"),
-                    "-L" + HERE, "-ldvd_audio_hip", "-ldvda_mlp_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-L" + HERE, "-ldvd_audio_hip", "-ldvda_mlp_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
                     "-Wl,-rpath,$ORIGIN/../libdvd-audio_amd", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return TOOL
 
@@ -108,4 +113,6 @@ def build_synth(force=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_disc(force), build_tool(force), build_synth(force), build_bounds(force)
+    # (the range-checked diagnostic library is built by its own test, tests/test_gpu_soak.py -> build_bounds(): a second
+    #  compile of the heaviest translation unit is not every user's business)
+    return build_hip(force, verbose), build_disc(force), build_tool(force), build_synth(force)

@@ -40,9 +40,11 @@
 #define CODEC_PCM 0xA0u
 #define CODEC_MLP 0xA1u
 
-static int g_device = 0;
+/* per THREAD: a host that fans tracks out over several devices (tools/dvda2wav_hip.c --devices) sets them in each
+ * of its worker threads; dvda_hip_open_track_reader_on() names both for one reader and touches neither */
+static _Thread_local int g_device = 0;
 
-static int g_wav_output = 0;
+static _Thread_local int g_wav_output = 0;
 void dvda_hip_set_device(int device) { g_device = device; }
 void dvda_hip_set_wav_output(int on) { g_wav_output = on != 0; }
 
@@ -807,6 +809,20 @@ done:
 }
 
 /* ------------------------------------------------------------------ track reader */
+DVDA_Track_Reader *dvda_hip_open_track_reader_on(const DVDA_Track *k, int device, int wav_output)
+{
+    /* the options of THIS reader: the calling thread's defaults are put back whatever happens */
+    const int keep_device = g_device, keep_wav = g_wav_output;
+    g_device = device;
+    g_wav_output = wav_output != 0;
+    DVDA_Track_Reader *r = dvda_open_track_reader(k);
+    g_device = keep_device;
+    g_wav_output = keep_wav;
+    return r;
+}
+
+int dvda_hip_reader_wav_only(const DVDA_Track_Reader *r) { return r && r->d_wav != NULL; }
+
 DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *k)
 {
     struct aob_set aobs;

@@ -718,8 +718,24 @@ extern "C" int dvda_mlp_hip_decode_async(dvda_mlp_hip_ctx *c, int32_t *d_pcm, co
     return decode_impl(c, d_pcm, d_out_off, d_out_stride, stream_, false);
 }
 
+static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off, const uint64_t *d_out_stride,
+                       void *stream_, bool blocking, bool *counted, uint32_t *slot_out);
+
 static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off, const uint64_t *d_out_stride,
                        void *stream_, bool blocking)
+{
+    // (a call that was counted in the event ring has its end event recorded whichever way it leaves: the timing call
+    //  measures start -> end of every counted call)
+    bool counted = false;
+    uint32_t slot = 0;
+    const int rc = decode_body(c, d_pcm, d_out_off, d_out_stride, stream_, blocking, &counted, &slot);
+    if (counted && rc != DVDA_HIP_OK)
+        (void)hipEventRecord(c->ev_end[slot], (hipStream_t)stream_);
+    return rc;
+}
+
+static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_out_off, const uint64_t *d_out_stride,
+                       void *stream_, bool blocking, bool *counted, uint32_t *slot_out)
 {
     if (!c || !d_pcm || !d_out_off || !d_out_stride)
         return DVDA_HIP_EINVAL;
@@ -803,6 +819,8 @@ static int decode_impl(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     }
     HIP_TRY(hipEventRecord(c->ev[2 * slot + 1], st));
     c->ev_count++;
+    *counted = true;
+    *slot_out = slot;
     const dim3 fgrid((unsigned)(((uint64_t)c->n_streams * FIN_GROUP + 255) / 256));
     hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                        c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);

@@ -1,0 +1,262 @@
+// mlp_multi.cpp -- the title list of ONE host process dealt to several GPUs (include/dvda_mlp_hip.h, "multi" calls).
+//
+// the path shards with no exchange step -- titles are independent (the reference decodes one track
+// at a time through one decoder, src/dvd-audio.c:597-657; nothing is shared between two of them) -- so a host that
+// holds a list of streams gives every GPU its own sub-list and adds up a small summary.  This is the C restatement
+// of libdvd-audio_amd/shard.py (what `bench.py --gpus N` does with one PROCESS per GPU and one RCCL all-reduce):
+// here it is one host THREAD per device entry, each with its own decode context, device buffers and HIP stream,
+// and the summary is reduced on the host.  Plain C ABI on top of the batch tier's own entry points: a device list
+// may name a device more than once (two contexts and two host threads on one GPU -- how the tests run it on a
+// one-GPU box, and a way to overlap one batch's copies with another's decode).
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/dvda_mlp_hip.h"
+
+struct dvda_mlp_hip_multi {
+    std::vector<int> devices;
+    std::vector<dvda_mlp_hip_ctx *> ctx;
+    uint32_t max_streams, max_segments;
+};
+
+// shard.shard_titles: greedy longest-processing-time on the compressed size -- streams by size descending (ties:
+// lower index first), each to the part with the least bytes so far (ties: lower part) -- deterministic, so that any
+// two callers (this one, the Python launcher) compute the same partition
+extern "C" int dvda_mlp_hip_shard(const uint64_t *sizes, uint32_t n, uint32_t parts, uint32_t *part_of)
+{
+    if (!sizes || !part_of || parts == 0)
+        return DVDA_HIP_EINVAL;
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++)
+        order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sizes[a] > sizes[b]; });
+    std::vector<uint64_t> load(parts, 0);
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t best = 0;
+        for (uint32_t p = 1; p < parts; p++)
+            if (load[p] < load[best])
+                best = p;
+        part_of[order[k]] = best;
+        load[best] += sizes[order[k]];
+    }
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_create_multi(dvda_mlp_hip_multi **out, const int *devices, uint32_t n_devices,
+                                         uint32_t max_streams, uint32_t max_segments)
+{
+    if (!out || !devices || n_devices == 0 || max_streams == 0 || max_segments == 0)
+        return DVDA_HIP_EINVAL;
+    dvda_mlp_hip_multi *m = new (std::nothrow) dvda_mlp_hip_multi();
+    if (!m)
+        return DVDA_HIP_ENOMEM;
+    m->max_streams = max_streams;
+    m->max_segments = max_segments;
+    for (uint32_t d = 0; d < n_devices; d++) {
+        dvda_mlp_hip_ctx *c = nullptr;
+        const int rc = dvda_mlp_hip_create(&c, devices[d], max_streams, max_segments);
+        if (rc != DVDA_HIP_OK) {
+            for (dvda_mlp_hip_ctx *x : m->ctx)
+                dvda_mlp_hip_destroy(x);
+            delete m;
+            return rc;                      // (no device, no decode: there is no CPU path behind this)
+        }
+        m->devices.push_back(devices[d]);
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return DVDA_HIP_OK;
+}
+
+extern "C" void dvda_mlp_hip_destroy_multi(dvda_mlp_hip_multi *m)
+{
+    if (!m)
+        return;
+    for (dvda_mlp_hip_ctx *x : m->ctx)
+        dvda_mlp_hip_destroy(x);
+    delete m;
+}
+
+extern "C" uint32_t dvda_mlp_hip_multi_devices(const dvda_mlp_hip_multi *m) { return m ? (uint32_t)m->ctx.size() : 0u; }
+
+namespace {
+
+struct Job {
+    dvda_mlp_hip_multi *m;
+    uint32_t part;
+    const uint8_t *const *streams;
+    const uint64_t *lengths;
+    const uint32_t *part_of;
+    uint32_t n_streams;
+    uint32_t layout;
+    void *const *pcm;
+    const uint64_t *capacity;
+    dvda_mlp_stream_info *infos;
+    int rc;
+    uint64_t bytes;             // compressed bytes this part decoded
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)) == hipSuccess; }
+};
+
+// bytes one PCM frame of a stream takes in the caller's buffer / one value in the device buffer, per layout
+inline size_t value_bytes(uint32_t layout) { return layout == DVDA_PCM_WAV24 ? 3 : layout == DVDA_PCM_WAV16 ? 2 : 4; }
+
+void *worker(void *arg)
+{
+    Job &j = *static_cast<Job *>(arg);
+    dvda_mlp_hip_ctx *ctx = j.m->ctx[j.part];
+    j.rc = DVDA_HIP_OK;
+    j.bytes = 0;
+    std::vector<uint32_t> mine;
+    for (uint32_t i = 0; i < j.n_streams; i++)
+        if (j.part_of[i] == j.part)
+            mine.push_back(i);
+    if (mine.empty())
+        return nullptr;
+    if (hipSetDevice(j.m->devices[j.part]) != hipSuccess) {
+        j.rc = DVDA_HIP_ENODEV;
+        return nullptr;
+    }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        j.rc = DVDA_HIP_ENODEV;
+        return nullptr;
+    }
+    const uint32_t n = (uint32_t)mine.size();
+    // the part's streams back to back, each 16-byte aligned, 64 readable bytes behind the last one; its PCM the same
+    // way, every stream at the capacity (PCM frames per channel) the caller gave it and 6 channels wide -- the widest
+    // a DVD-Audio assignment is (src/dvd-audio.c:1459-1496); what the stream really has is known after the index
+    std::vector<uint64_t> off(n), len(n), ooff(n), ostr(n);
+    uint64_t total = 0, words = 0;
+    const size_t vb = value_bytes(j.layout);
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t i = mine[k];
+        off[k] = total;
+        len[k] = j.lengths[i];
+        total += (j.lengths[i] + 15) & ~15ull;
+        ooff[k] = words;
+        ostr[k] = j.capacity[i];
+        words += (j.capacity[i] * 6 * vb + 3) / 4 + 4;
+        j.bytes += j.lengths[i];
+    }
+    DevBuf<uint8_t> d_bytes;
+    DevBuf<uint64_t> d_meta;
+    DevBuf<int32_t> d_pcm;
+    std::vector<dvda_mlp_stream_info> info(n);
+    uint8_t *h_stage = nullptr;
+    do {
+        if (!d_bytes.alloc(total + 64) || !d_meta.alloc(4 * (size_t)n) || !d_pcm.alloc(words) ||
+            hipHostMalloc((void **)&h_stage, total + 64, hipHostMallocDefault) != hipSuccess) {
+            j.rc = DVDA_HIP_ENOMEM;
+            break;
+        }
+        memset(h_stage, 0, total + 64);
+        for (uint32_t k = 0; k < n; k++)
+            memcpy(h_stage + off[k], j.streams[mine[k]], len[k]);
+        std::vector<uint64_t> meta(4 * (size_t)n);
+        for (uint32_t k = 0; k < n; k++) {
+            meta[k] = off[k];
+            meta[n + k] = len[k];
+            meta[2 * (size_t)n + k] = ooff[k];
+            meta[3 * (size_t)n + k] = ostr[k];
+        }
+        if (hipMemcpyAsync(d_bytes.p, h_stage, total + 64, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_meta.p, meta.data(), meta.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+            j.rc = DVDA_HIP_ENODEV;
+            break;
+        }
+        if ((j.rc = dvda_mlp_hip_set_pcm_layout(ctx, j.layout)) != DVDA_HIP_OK ||
+            (j.rc = dvda_mlp_hip_index(ctx, d_bytes.p, total, d_meta.p, d_meta.p + n, n, st)) != DVDA_HIP_OK ||
+            (j.rc = dvda_mlp_hip_decode(ctx, d_pcm.p, d_meta.p + 2 * (size_t)n, d_meta.p + 3 * (size_t)n, st)) != DVDA_HIP_OK ||
+            (j.rc = dvda_mlp_hip_stream_info(ctx, info.data(), n, st)) != DVDA_HIP_OK)
+            break;
+        // PCM back: planar [channel][capacity] int32, or frame-major / packed payload in one run per stream
+        for (uint32_t k = 0; k < n && j.rc == DVDA_HIP_OK; k++) {
+            const uint32_t i = mine[k];
+            j.infos[i] = info[k];
+            const uint64_t frames = info[k].pcm_frames < ostr[k] ? info[k].pcm_frames : ostr[k];
+            const uint32_t ch = info[k].channels;
+            if (!j.pcm[i] || !frames || !ch)
+                continue;
+            hipError_t e;
+            if (j.layout == DVDA_PCM_PLANAR) {
+                e = hipMemcpy2DAsync(j.pcm[i], ostr[k] * 4, d_pcm.p + ooff[k], ostr[k] * 4, frames * 4, ch,
+                                     hipMemcpyDeviceToHost, st);
+            } else {
+                e = hipMemcpyAsync(j.pcm[i], d_pcm.p + ooff[k], frames * ch * vb, hipMemcpyDeviceToHost, st);
+            }
+            if (e != hipSuccess)
+                j.rc = DVDA_HIP_ENODEV;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess)
+            j.rc = DVDA_HIP_ENODEV;
+    } while (0);
+    if (h_stage)
+        (void)hipHostFree(h_stage);
+    (void)hipStreamDestroy(st);
+    return nullptr;
+}
+
+} // namespace
+
+extern "C" int dvda_mlp_hip_decode_multi(dvda_mlp_hip_multi *m, const uint8_t *const *streams, const uint64_t *lengths,
+                                         uint32_t n_streams, uint32_t layout, void *const *pcm,
+                                         const uint64_t *capacity_frames, dvda_mlp_stream_info *infos,
+                                         dvda_mlp_multi_summary *summary)
+{
+    if (!m || !streams || !lengths || !pcm || !capacity_frames || !infos || n_streams == 0 || layout > DVDA_PCM_WAV16)
+        return DVDA_HIP_EINVAL;
+    if (n_streams > m->max_streams)
+        return DVDA_HIP_ECAPACITY;
+    const uint32_t parts = (uint32_t)m->ctx.size();
+    std::vector<uint32_t> part_of(n_streams);
+    int rc = dvda_mlp_hip_shard(lengths, n_streams, parts, part_of.data());
+    if (rc != DVDA_HIP_OK)
+        return rc;
+    memset(infos, 0, sizeof(dvda_mlp_stream_info) * n_streams);
+    std::vector<Job> jobs(parts);
+    std::vector<pthread_t> th(parts);
+    std::vector<char> started(parts, 0);
+    for (uint32_t p = 0; p < parts; p++) {
+        jobs[p] = Job{m, p, streams, lengths, part_of.data(), n_streams, layout, pcm, capacity_frames, infos, 0, 0};
+        started[p] = pthread_create(&th[p], nullptr, worker, &jobs[p]) == 0;
+        if (!started[p])
+            worker(&jobs[p]);               // (no thread to be had: the part is decoded here, in turn)
+    }
+    for (uint32_t p = 0; p < parts; p++)
+        if (started[p])
+            pthread_join(th[p], nullptr);
+    for (uint32_t p = 0; p < parts; p++)
+        if (jobs[p].rc != DVDA_HIP_OK)
+            rc = jobs[p].rc;
+    if (summary) {
+        // the path's one reduction (bench.py does the same with one all-reduce over RCCL): sums, and the balance
+        memset(summary, 0, sizeof(*summary));
+        summary->devices = parts;
+        uint64_t bmax = 0, bsum = 0;
+        for (uint32_t p = 0; p < parts; p++) {
+            bsum += jobs[p].bytes;
+            bmax = jobs[p].bytes > bmax ? jobs[p].bytes : bmax;
+        }
+        for (uint32_t i = 0; i < n_streams; i++) {
+            summary->pcm_frames += infos[i].pcm_frames;
+            summary->samples += infos[i].pcm_frames * infos[i].channels;
+            summary->streams_with_errors += (infos[i].status & ~(uint32_t)DVDA_ST_BENIGN) ? 1u : 0u;
+        }
+        summary->compressed_bytes = bsum;
+        summary->compressed_bytes_max_device = bmax;
+    }
+    return rc;
+}

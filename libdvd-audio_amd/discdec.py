@@ -22,7 +22,7 @@ EXPORTS = [
     "dvda_open_track_reader", "dvda_close_track_reader", "dvda_codec", "dvda_bits_per_sample",
     "dvda_sample_rate", "dvda_channel_count", "dvda_riff_wave_channel_mask", "dvda_read",
     "dvda_hip_set_device", "dvda_hip_set_wav_output", "dvda_hip_reader_status", "dvda_hip_reader_total_frames",
-    "dvda_hip_reader_wav_payload",
+    "dvda_hip_reader_wav_payload", "dvda_hip_open_track_reader_on", "dvda_hip_reader_wav_only",
 ]
 
 _lib = None
@@ -63,6 +63,10 @@ def lib():
         L.dvda_hip_set_device.argtypes = [ctypes.c_int]
         L.dvda_hip_set_wav_output.restype = None
         L.dvda_hip_set_wav_output.argtypes = [ctypes.c_int]
+        L.dvda_hip_open_track_reader_on.restype = ctypes.c_void_p
+        L.dvda_hip_open_track_reader_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.dvda_hip_reader_wav_only.restype = ctypes.c_int
+        L.dvda_hip_reader_wav_only.argtypes = [ctypes.c_void_p]
         L.dvda_hip_reader_total_frames.restype = ctypes.c_ulonglong
         L.dvda_hip_reader_total_frames.argtypes = [vp]
         L.dvda_hip_reader_wav_payload.restype = ctypes.c_ulonglong
@@ -101,11 +105,10 @@ def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0
     """Decodes one track on the GPU.  Returns a dict: codec ("PCM"/"MLP"), bits, rate, channels,
     mask, status, and pcm = int32 [frames, channels] (interleaved, RIFF-WAVE order) read with
     dvda_read() in `chunk`-frame calls -- or, with wav=True, payload = the WAV data bytes packed
-    on the GPU; fused=True (with wav=True) opens the reader under dvda_hip_set_wav_output(1): MLP tracks are decoded
-    straight into that payload, no int32 PCM and no packing pass."""
+    on the GPU; fused=True (with wav=True) opens the reader as a WAV-payload-only one (dvda_hip_open_track_reader_on):
+    MLP tracks are decoded straight into that payload, no int32 PCM and no packing pass.  Device and output form are
+    the READER's: no process-wide switch is left behind."""
     L = lib()
-    L.dvda_hip_set_device(device)
-    L.dvda_hip_set_wav_output(1 if (fused and wav) else 0)
     d = L.dvda_open(audio_ts.encode(), None)
     if not d:
         raise IOError("not an AUDIO_TS directory: %s" % audio_ts)
@@ -114,13 +117,14 @@ def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0
         ts = L.dvda_open_titleset(d, titleset)
         t = L.dvda_open_title(ts, title) if ts else None
         k = L.dvda_open_track(t, track) if t else None
-        r = L.dvda_open_track_reader(k) if k else None
+        r = L.dvda_hip_open_track_reader_on(k, device, 1 if (fused and wav) else 0) if k else None
         if not r:
             raise RuntimeError("track %d/%d/%d cannot be opened for reading" % (titleset, title, track))
         ch = L.dvda_channel_count(r)
         info = {"codec": "MLP" if L.dvda_codec(r) == 1 else "PCM", "bits": L.dvda_bits_per_sample(r),
                 "rate": L.dvda_sample_rate(r), "channels": ch, "mask": L.dvda_riff_wave_channel_mask(r),
-                "status": L.dvda_hip_reader_status(r), "frames": int(L.dvda_hip_reader_total_frames(r))}
+                "status": L.dvda_hip_reader_status(r), "frames": int(L.dvda_hip_reader_total_frames(r)),
+                "wav_only": bool(L.dvda_hip_reader_wav_only(r))}
         if wav:
             p = ctypes.POINTER(ctypes.c_ubyte)()
             n = L.dvda_hip_reader_wav_payload(r, ctypes.byref(p))

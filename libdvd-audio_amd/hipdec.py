@@ -31,6 +31,13 @@ class StreamInfo(ctypes.Structure):
                 ("reserved", ctypes.c_uint32)]
 
 
+class MultiSummary(ctypes.Structure):
+    """dvda_mlp_multi_summary of include/dvda_mlp_hip.h"""
+    _fields_ = [("pcm_frames", ctypes.c_uint64), ("samples", ctypes.c_uint64), ("compressed_bytes", ctypes.c_uint64),
+                ("compressed_bytes_max_device", ctypes.c_uint64), ("streams_with_errors", ctypes.c_uint32),
+                ("devices", ctypes.c_uint32)]
+
+
 class HipError(RuntimeError):
     pass
 
@@ -48,7 +55,9 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
            "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",
            "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result",
-           "dvda_mlp_hip_demux_sectors", "dvda_mlp_hip_pack_wav")
+           "dvda_mlp_hip_demux_sectors", "dvda_mlp_hip_pack_wav",
+           "dvda_mlp_hip_shard", "dvda_mlp_hip_create_multi", "dvda_mlp_hip_destroy_multi",
+           "dvda_mlp_hip_multi_devices", "dvda_mlp_hip_decode_multi")
 
 
 def lib():
@@ -98,6 +107,14 @@ def lib():
         L.dvda_pcm_hip_result.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u32), vp]
         L.dvda_mlp_hip_demux_sectors.argtypes = [vp, u32, vp, u64, vp, vp]
         L.dvda_mlp_hip_pack_wav.argtypes = [vp, u64, ctypes.c_uint, u64, ctypes.c_uint, vp, vp]
+        L.dvda_mlp_hip_shard.argtypes = [vp, u32, u32, vp]
+        L.dvda_mlp_hip_create_multi.argtypes = [ctypes.POINTER(vp), vp, u32, u32, u32]
+        L.dvda_mlp_hip_destroy_multi.argtypes = [vp]
+        L.dvda_mlp_hip_destroy_multi.restype = None
+        L.dvda_mlp_hip_multi_devices.argtypes = [vp]
+        L.dvda_mlp_hip_multi_devices.restype = u32
+        L.dvda_mlp_hip_decode_multi.argtypes = [vp, vp, vp, u32, u32, vp, vp, ctypes.POINTER(StreamInfo),
+                                                ctypes.POINTER(MultiSummary)]
         _lib = L
     return _lib
 
@@ -279,6 +296,53 @@ def decode_streams(streams, device=0, max_segments=None, lanes_per_segment=0, la
     finally:
         if own:
             ctx.close()
+
+
+def shard_c(sizes, parts):
+    """dvda_mlp_hip_shard: the C restatement of shard.shard_titles -> owner[i]"""
+    import numpy as np
+    sz = np.ascontiguousarray(sizes, np.uint64)
+    out = np.zeros(len(sz), np.uint32)
+    _check(lib().dvda_mlp_hip_shard(sz.ctypes.data, len(sz), parts, out.ctypes.data), "dvda_mlp_hip_shard")
+    return out
+
+
+def decode_streams_multi(streams, devices, layout=PCM_PLANAR, max_segments=None):
+    """dvda_mlp_hip_decode_multi: host streams dealt to the device entries of `devices` (a device may be named more
+    than once), host PCM back.  -> (pcm list as decode_streams gives it, infos, MultiSummary)"""
+    import numpy as np
+    n = len(streams)
+    bufs = [np.ascontiguousarray(s, np.uint8) for s in streams]
+    lens = np.array([len(b) for b in bufs], np.uint64)
+    if max_segments is None:
+        max_segments = int(sum(len(b) // 2048 + 8 for b in bufs))
+    devs = np.array(devices, np.int32)
+    h = ctypes.c_void_p()
+    _check(lib().dvda_mlp_hip_create_multi(ctypes.byref(h), devs.ctypes.data, len(devs), n, max_segments),
+           "dvda_mlp_hip_create_multi")
+    try:
+        vb = 3 if layout == PCM_WAV24 else 2 if layout == PCM_WAV16 else 4
+        caps = np.array([len(b) + 4096 for b in bufs], np.uint64)      # PCM frames: a frame takes more than a byte
+        outs = [np.zeros(int(c) * 6 * vb + 16, np.uint8) for c in caps]
+        sp = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        infos = (StreamInfo * n)()
+        summ = MultiSummary()
+        _check(lib().dvda_mlp_hip_decode_multi(h, sp, lens.ctypes.data, n, layout, op, caps.ctypes.data, infos,
+                                               ctypes.byref(summ)), "dvda_mlp_hip_decode_multi")
+        pcm = []
+        for i in range(n):
+            f, ch, cap = int(infos[i].pcm_frames), int(infos[i].channels), int(caps[i])
+            f = min(f, cap)
+            if layout == PCM_PLANAR:
+                pcm.append(outs[i][:cap * ch * 4].view(np.int32).reshape(ch, cap)[:, :f].copy() if ch else np.zeros((0, 0), np.int32))
+            elif layout == PCM_INTERLEAVED:
+                pcm.append(outs[i][:f * ch * 4].view(np.int32).reshape(f, ch).T.copy() if ch else np.zeros((0, 0), np.int32))
+            else:
+                pcm.append(outs[i][:f * ch * vb].copy())
+        return pcm, list(infos), summ
+    finally:
+        lib().dvda_mlp_hip_destroy_multi(h)
 
 
 def decode_streams_wav(streams, bits, device=0, lanes_per_segment=0):

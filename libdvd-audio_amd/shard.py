@@ -19,7 +19,7 @@ def shard_titles(sizes, world, rank):
     return np.flatnonzero(owner == rank)
 
 
-def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checksum, seconds, verified=True):
+def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checksum, seconds, verified=True, checked=True):
     """The path's one collective: all ranks learn {sum frames, sum samples, sum bytes, sum errors,
     xor-free additive checksum}, the slowest and the fastest rank's time, the largest and the smallest rank's share
     of the compressed bytes (the load balance of the shard) and whether EVERY rank's bit-exact check passed.  `dist` is torch.distributed (already
@@ -30,7 +30,9 @@ def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checks
     chk = torch.tensor([int(checksum) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
     tmax = torch.tensor([float(seconds), float(comp_bytes)], dtype=torch.float64, device=device)
     # (the fastest rank's time, the smallest share, and "every rank's sample check passed" travel as minima)
-    tmin = torch.tensor([float(seconds), float(comp_bytes), 1.0 if verified else 0.0], dtype=torch.float64, device=device)
+    # ("checked": a rank that compared nothing -- profiling runs -- must not pass as verified)
+    tmin = torch.tensor([float(seconds), float(comp_bytes), 1.0 if verified else 0.0, 1.0 if checked else 0.0],
+                        dtype=torch.float64, device=device)
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)
@@ -40,4 +42,5 @@ def reduce_summary(dist, device, pcm_frames, samples, comp_bytes, errors, checks
             "compressed_bytes": int(tot[2].item()), "errors": int(tot[3].item()),
             "checksum": int(chk[0].item()), "seconds": float(tmax[0].item()),
             "seconds_min": float(tmin[0].item()), "bytes_max": int(tmax[1].item()), "bytes_min": int(tmin[1].item()),
-            "all_verified": bool(tmin[2].item() > 0.5)}
+            "all_verified": bool(tmin[2].item() > 0.5) if tmin[3].item() > 0.5 else None,
+            "all_checked": bool(tmin[3].item() > 0.5)}

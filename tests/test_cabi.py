@@ -74,3 +74,16 @@ def test_inline_asm_selects_keep_the_sgpr_hazard_distance():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "hazard violations: 0" in r.stdout
+
+
+def test_c_shard_is_the_python_shard():
+    """dvda_mlp_hip_shard (csrc/mlp_multi.cpp, what a C host deals its title list to the GPUs with) computes the
+    partition libdvd-audio_amd/shard.py computes -- greedy longest-processing-time, ties included."""
+    import numpy as np
+    import libdvd_audio_amd as pkg
+    rng = np.random.default_rng(5)
+    for n, parts in ((1, 1), (7, 2), (64, 8), (1000, 3), (33, 5)):
+        sizes = rng.integers(1, 50, n).astype(np.int64) * 1000        # (many ties)
+        owner = pkg.hipdec.shard_c(sizes, parts)
+        for r in range(parts):
+            assert np.array_equal(np.flatnonzero(owner == r), pkg.shard.shard_titles(sizes, parts, r))

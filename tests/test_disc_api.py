@@ -117,7 +117,7 @@ def test_pcm_tracks_and_gpu_wav_payload(pkg, oracle):
 
 @pytest.mark.gpu
 def test_mlp_tracks_decoded_straight_into_the_wav_payload(pkg, oracle):
-    """dvda_hip_set_wav_output(1): an MLP track reader holds the WAV payload the decode kernels wrote themselves
+    """dvda_hip_open_track_reader_on(track, device, 1): an MLP track reader holds the WAV payload the decode kernels wrote themselves
     (DVDA_PCM_WAV24) -- no int32 PCM, no packing pass.  Byte for byte what the int32 decode + GPU packer give, and what
     the oracle's packing of the oracle's PCM gives; dvda_read() on such a reader returns nothing."""
     syn, disc = pkg.synth, pkg.disc
@@ -131,9 +131,15 @@ def test_mlp_tracks_decoded_straight_into_the_wav_payload(pkg, oracle):
                 packed = pkg.discdec.read_track(ats, 1, ti, ki, wav=True)
                 fused = pkg.discdec.read_track(ats, 1, ti, ki, wav=True, fused=True)
                 assert fused["status"] & ~pkg.hipdec.ST_BENIGN == 0 and fused["frames"] == plain["frames"]
+                assert fused["wav_only"] and not packed["wav_only"] and not plain["wav_only"]
                 assert fused["payload"] == packed["payload"] == oracle.wav_pack(plain["pcm"].T, plain["bits"])
                 assert len(fused["payload"]) == plain["frames"] * nch * plain["bits"] // 8
-    pkg.discdec.lib().dvda_hip_set_wav_output(0)
+    # (the output form is the reader's: a reader opened the reference's way right after is an ordinary one)
+    with tempfile.TemporaryDirectory() as tmp:
+        titles, streams = _titles(pkg, seeds=(33, 34))
+        ats = disc.write_disc_titles(tmp, titles)
+        again = pkg.discdec.read_track(ats, 1, 1, 1)
+        assert not again["wav_only"] and again["pcm"].shape[0] == again["frames"] > 0
 
 
 REF_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_ref")

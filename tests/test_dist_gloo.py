@@ -46,6 +46,12 @@ def _worker(rank, world, port, q):
         checksum += int(pcm.astype(np.int64).sum()) & 0xFFFFFFFF
     out = pkg.shard.reduce_summary(dist, torch.device("cpu"), frames, samples, nbytes, errors, checksum,
                                    0.1 * (rank + 1))
+    # "bit-exact on every rank": one rank that failed its check makes it false, one rank that checked nothing makes it
+    # unknown (None) -- never true by default
+    one_bad = pkg.shard.reduce_summary(dist, torch.device("cpu"), 0, 0, 1, 0, 0, 0.1, verified=rank != 1)
+    one_blind = pkg.shard.reduce_summary(dist, torch.device("cpu"), 0, 0, 1, 0, 0, 0.1, checked=rank != 1)
+    out["_one_bad"] = one_bad["all_verified"]
+    out["_one_blind"] = one_blind["all_verified"]
     q.put((rank, [int(i) for i in mine], out))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,6 +87,7 @@ def test_two_rank_shard_and_summary(pkg, oracle):
         nbytes += len(b)
         checksum += int(pcm.astype(np.int64).sum()) & 0xFFFFFFFF
     s = res[0][2]
+    assert s["all_verified"] is True and s["_one_bad"] is False and s["_one_blind"] is None
     assert (s["pcm_frames"], s["samples"], s["compressed_bytes"], s["errors"]) == (frames, samples, nbytes, 0)
     assert s["checksum"] == checksum
     assert abs(s["seconds"] - 0.2) < 1e-9               # max over ranks
@@ -121,7 +128,8 @@ def test_bench_launcher_starts_two_ranks_over_gloo():
     assert rec["config"]["samples_all_ranks"] == 24 * 8 * 80 * 6
     assert abs(rec["seconds_max_over_ranks"] - 0.002) < 1e-9     # max over ranks, not rank 0's
     # ... and what the N > 1 line says about the shard itself: fastest rank, balance, every rank's own check
-    assert abs(rec["ranks"]["seconds_min"] - 0.001) < 1e-9 and rec["ranks"]["bit_exact_on_every_rank"] is True
+    # (plumbing mode decodes nothing, so nothing was compared: "not checked" is null, never true)
+    assert abs(rec["ranks"]["seconds_min"] - 0.001) < 1e-9 and rec["ranks"]["bit_exact_on_every_rank"] is None
     assert rec["ranks"]["compressed_bytes_max"] >= rec["ranks"]["compressed_bytes_min"] > 0
     assert 1.0 <= rec["ranks"]["load_imbalance"] < 1.2
 

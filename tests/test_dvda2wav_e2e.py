@@ -164,3 +164,22 @@ def test_gpu_extractor_writes_the_reference_files(pkg):
         assert [os.path.basename(p) for p in got] == [os.path.basename(p) for p in ref] and len(ref) == 8
         for a, b in zip(ref, got):
             assert open(a, "rb").read() == open(b, "rb").read(), os.path.basename(a)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_TOOL), reason="reference tools not built (dev container only)")
+def test_gpu_extractor_fans_tracks_out_over_device_entries(pkg):
+    """dvda2wav_hip --devices 0,0,0: three worker threads, each with its own device entry (all the one GPU of a test
+    box), take the disc's tracks in turn -- the same eight files as the reference's tool, whichever worker wrote which."""
+    tool = pkg._build.build_tool()
+    with tempfile.TemporaryDirectory() as tmp:
+        ats = _mixed_disc(pkg, tmp)
+        ref = _run(REF_TOOL, ats, os.path.join(tmp, "ref"))
+        out = os.path.join(tmp, "gpu")
+        os.makedirs(out)
+        r = subprocess.run([tool, "-A", ats, "-d", out, "--devices", "0,0,0"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr
+        got = sorted(os.path.join(out, f) for f in os.listdir(out))
+        assert [os.path.basename(p) for p in got] == [os.path.basename(p) for p in ref] and len(ref) == 8
+        for a, b in zip(ref, got):
+            assert open(a, "rb").read() == open(b, "rb").read(), os.path.basename(a)

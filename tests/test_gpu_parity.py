@@ -930,3 +930,36 @@ def test_workspaces_full_of_garbage_change_nothing(fill):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p",
                         "no:cacheprovider", "-k", pick], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("layout", ["planar", "interleaved", "wav24"])
+def test_title_list_dealt_to_several_devices_from_c(pkg, oracle, layout):
+    """dvda_mlp_hip_decode_multi (SURVEY 8(e) from a C host): a list of host streams dealt to the entries of a device
+    list -- here {0, 0, 0}: three contexts and three host threads on the one GPU a test box has -- every stream's PCM
+    against the oracle, the summary against the sums, the partition against shard.py."""
+    syn, hip = pkg.synth, pkg.hipdec
+    streams, frames, nchs = [], [], []
+    kinds = [dict(assignment=12, n_substreams=1, n_aus=40), dict(assignment=1, n_substreams=1, n_aus=72),
+             dict(assignment=12, n_substreams=2, n_aus=24),
+             dict(assignment=12, n_substreams=1, n_aus=32, profile=1, features=syn.SF["CHAINED"])]
+    for i in range(14):
+        cfg = syn.make_cfg(rate_code=1, **kinds[i % len(kinds)])
+        b, f = syn.stream(cfg, 300 + i)
+        streams.append(b)
+        frames.append(f)
+        nchs.append(syn.channels(cfg.assignment))
+    lay = {"planar": hip.PCM_PLANAR, "interleaved": hip.PCM_INTERLEAVED, "wav24": hip.PCM_WAV24}[layout]
+    pcm, infos, summ = hip.decode_streams_multi(streams, [0, 0, 0], layout=lay)
+    assert summ.devices == 3 and summ.streams_with_errors == 0
+    assert summ.pcm_frames == sum(frames) and summ.samples == sum(f * c for f, c in zip(frames, nchs))
+    assert summ.compressed_bytes == sum(len(b) for b in streams)
+    owner = hip.shard_c([len(b) for b in streams], 3)
+    assert summ.compressed_bytes_max_device == max(sum(len(b) for b, o in zip(streams, owner) if o == r) for r in range(3))
+    for i, (b, f, nch) in enumerate(zip(streams, frames, nchs)):
+        want, r, st = oracle.decode(b, nch, f)
+        assert st == 0 and infos[i].pcm_frames == f and infos[i].channels == nch
+        assert not (infos[i].status & ~hip.ST_BENIGN)
+        if layout == "wav24":
+            assert pcm[i].tobytes() == oracle.wav_pack(want, 24), "stream %d" % i
+        else:
+            assert np.array_equal(pcm[i], want), "stream %d" % i

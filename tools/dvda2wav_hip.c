@@ -10,6 +10,8 @@
  *      -ldvda_mlp_hip -Wl,-rpath,'$ORIGIN/../libdvd-audio_amd'
  */
 #include <getopt.h>
+#include <pthread.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,14 +47,15 @@ static void wave_header(uint8_t h[68], unsigned rate, unsigned channels, unsigne
     put32(h + 64, data);
 }
 
-static int extract(DVDA_Title *title, unsigned track_num, const char *dir)
+static int extract(DVDA_Title *title, unsigned track_num, const char *dir, int device, int fused_wav)
 {
     DVDA_Track *track = dvda_open_track(title, track_num);
     if (!track) {
         fprintf(stderr, "*** Error: unable to open track %u\n", track_num);
         return 0;
     }
-    DVDA_Track_Reader *r = dvda_open_track_reader(track);
+    /* this tool only ever writes WAV files: MLP tracks are decoded straight into the payload */
+    DVDA_Track_Reader *r = dvda_hip_open_track_reader_on(track, device, fused_wav);
     if (!r) {
         fprintf(stderr, "*** Error: unable to open track %u for reading\n", track_num);
         dvda_close_track(track);
@@ -87,6 +90,40 @@ static int extract(DVDA_Title *title, unsigned track_num, const char *dir)
     return ok;
 }
 
+/* ---- tracks fanned out over device entries (SURVEY 8(e) from the C host: tracks are independent -- the reference
+ *      extracts them one after the other through one decoder, utils/dvda2wav.c:287-350, src/dvd-audio.c:597-657):
+ *      one worker thread per entry of --devices, each takes the next track of the job list, opens it on ITS device,
+ *      fetches the payload and writes the file.  A device named more than once is that many workers on it: one
+ *      worker's file read and WAV write overlap another's decode. */
+struct job {
+    DVDA_Title *title;
+    unsigned track;
+};
+struct pool {
+    struct job *jobs;
+    unsigned n_jobs;
+    atomic_uint next, failed;
+    const char *dir;
+    int fused_wav;
+};
+struct worker {
+    struct pool *pool;
+    int device;
+};
+
+static void *work(void *arg)
+{
+    struct worker *w = arg;
+    for (;;) {
+        const unsigned i = atomic_fetch_add(&w->pool->next, 1);
+        if (i >= w->pool->n_jobs)
+            break;
+        if (!extract(w->pool->jobs[i].title, w->pool->jobs[i].track, w->pool->dir, w->device, w->pool->fused_wav))
+            atomic_fetch_add(&w->pool->failed, 1);
+    }
+    return NULL;
+}
+
 static void usage(const char *prog)
 {
     printf("*** Usage : %s -A [AUDIO_TS] [OPTIONS]\n"
@@ -97,7 +134,9 @@ static void usage(const char *prog)
            "  -T TITLE, --title=TITLE   title number to extract (default: all)\n"
            "  -t TRACK, --track=TRACK   track number to extract (default: all)\n"
            "  -d DIR, --dir=DIR         output directory (default: the working directory)\n"
-           "  -g N, --gpu=N             HIP device (default 0)\n", prog);
+           "  -g N, --gpu=N             HIP device (default 0)\n"
+           "  -D LIST, --devices=LIST   comma-separated HIP devices: one worker thread per entry takes tracks in turn\n"
+           "                            (a device may be named more than once)\n", prog);
 }
 
 int main(int argc, char *argv[])
@@ -106,11 +145,13 @@ int main(int argc, char *argv[])
                                        {"titleset", required_argument, 0, 'S'}, {"title", required_argument, 0, 'T'},
                                        {"track", required_argument, 0, 't'},    {"dir", required_argument, 0, 'd'},
                                        {"gpu", required_argument, 0, 'g'},      {"help", no_argument, 0, 'h'},
+                                       {"devices", required_argument, 0, 'D'},
                                        {0, 0, 0, 0}};
     const char *audio_ts = NULL, *dir = ".", *cdrom = NULL;
     unsigned titleset_num = 1, title_num = 0, track_num = 0;
+    int devices[64], n_devices = 0, one_device = 0;
     int c;
-    while ((c = getopt_long(argc, argv, "A:c:S:T:t:d:g:h", longopts, NULL)) != -1) {
+    while ((c = getopt_long(argc, argv, "A:c:S:T:t:d:g:D:h", longopts, NULL)) != -1) {
         switch (c) {
         case 'A': audio_ts = optarg; break;
         case 'c': cdrom = optarg; break;
@@ -118,7 +159,11 @@ int main(int argc, char *argv[])
         case 'T': title_num = (unsigned)strtoul(optarg, NULL, 10); break;
         case 't': track_num = (unsigned)strtoul(optarg, NULL, 10); break;
         case 'd': dir = optarg; break;
-        case 'g': dvda_hip_set_device(atoi(optarg)); break;
+        case 'g': one_device = atoi(optarg); break;
+        case 'D':
+            for (char *tok = strtok(optarg, ","); tok && n_devices < 64; tok = strtok(NULL, ","))
+                devices[n_devices++] = atoi(tok);
+            break;
         case 'h': usage(argv[0]); return 0;
         default: return 1;
         }
@@ -127,9 +172,10 @@ int main(int argc, char *argv[])
         usage(argv[0]);
         return 0;
     }
-    /* this tool only ever writes WAV files: MLP tracks are decoded straight into the payload (DVDA_NO_FUSED_WAV=1
-       in the environment brings the int32 decode + packing pass back, for comparison) */
-    dvda_hip_set_wav_output(getenv("DVDA_NO_FUSED_WAV") == NULL);
+    /* (DVDA_NO_FUSED_WAV=1 in the environment brings the int32 decode + packing pass back, for comparison) */
+    const int fused_wav = getenv("DVDA_NO_FUSED_WAV") == NULL;
+    if (n_devices == 0)
+        devices[n_devices++] = one_device;
     DVDA *dvda = dvda_open(audio_ts, cdrom);
     DVDA_Titleset *ts = dvda ? dvda_open_titleset(dvda, titleset_num) : NULL;
     if (!ts) {
@@ -140,18 +186,47 @@ int main(int argc, char *argv[])
     }
     int rc = 0;
     const unsigned t_lo = title_num ? title_num : 1, t_hi = title_num ? title_num : dvda_title_count(ts);
-    for (unsigned t = t_lo; t <= t_hi && !rc; t++) {
+    /* the job list: every (title, track) asked for, in the reference tool's order */
+    DVDA_Title *titles[256];
+    unsigned n_titles = 0, n_jobs = 0, cap_jobs = 0;
+    struct job *jobs = NULL;
+    for (unsigned t = t_lo; t <= t_hi && !rc && n_titles < 256; t++) {
         DVDA_Title *title = dvda_open_title(ts, t);
         if (!title) {
             fprintf(stderr, "*** Error: unable to open title %u\n", t);
             rc = 1;
             break;
         }
+        titles[n_titles++] = title;
         const unsigned k_lo = track_num ? track_num : 1, k_hi = track_num ? track_num : dvda_track_count(title);
-        for (unsigned k = k_lo; k <= k_hi; k++)
-            extract(title, k, dir);
-        dvda_close_title(title);
+        for (unsigned k = k_lo; k <= k_hi; k++) {
+            if (n_jobs == cap_jobs) {
+                cap_jobs = cap_jobs ? 2 * cap_jobs : 64;
+                jobs = realloc(jobs, cap_jobs * sizeof(*jobs));
+                if (!jobs)
+                    return 1;
+            }
+            jobs[n_jobs].title = title;
+            jobs[n_jobs++].track = k;
+        }
     }
+    struct pool pool = {jobs, n_jobs, 0, 0, dir, fused_wav};
+    struct worker workers[64];
+    pthread_t th[64];
+    int started[64];
+    for (int i = 0; i < n_devices; i++) {
+        workers[i].pool = &pool;
+        workers[i].device = devices[i];
+        started[i] = n_devices > 1 && pthread_create(&th[i], NULL, work, &workers[i]) == 0;
+        if (!started[i])
+            work(&workers[i]);              /* one entry (or no thread to be had): here, in turn */
+    }
+    for (int i = 0; i < n_devices; i++)
+        if (started[i])
+            pthread_join(th[i], NULL);
+    for (unsigned i = 0; i < n_titles; i++)
+        dvda_close_title(titles[i]);
+    free(jobs);
     dvda_close_titleset(ts);
     dvda_close(dvda);
     return rc;
