@@ -501,7 +501,7 @@ static void put_decoding_params(gen_t *g, bw_t *w, ss_t *s, int restart, int fir
         else if (recipe2)
             send = 1;
         else
-            send = rnd_chance(&g->rng, 60);
+            send = rnd_chance(&g->rng, (f & MLP_SF_DISC) ? 85 : 60);
         /* a channel whose current lsbs would fall below a freshly drawn qss must
            be re-sent */
         if (!send && !restart && ch->lsbs < s->qss[c])
@@ -521,7 +521,7 @@ static void put_decoding_params(gen_t *g, bw_t *w, ss_t *s, int restart, int fir
         }
         /* FIR */
         if (s->flags[3]) {
-            int sf = recipe2 ? 1 : (fuzz ? rnd_chance(&g->rng, restart ? 60 : 50) : 0);
+            int sf = recipe2 ? 1 : (fuzz ? rnd_chance(&g->rng, restart ? 60 : ((f & MLP_SF_DISC) ? 80 : 50)) : 0);
             if (!filters_ok && !restart && ch->fir.order)
                 sf = 1; /* cannot happen: lead-in is always a restart block */
             bw_put(w, 1, (uint32_t)sf);
@@ -710,6 +710,8 @@ static size_t build_substream(gen_t *g, ss_t *s, unsigned au, int restart_au, in
             g->leadin = 1; /* mid-frame restarts also start with a raw block */
         params = restart || recipe2 || blk[b] != s->block_size ||
                  (fuzz && (f & MLP_SF_PARAMBLOCKS) && rnd_chance(&g->rng, 35));
+        if (fuzz && (f & MLP_SF_DISC))
+            params = 1;
         /* after a lead-in block the filters have to be (re)enabled at some point;
            in fuzz mode do it on the next block */
         if (fuzz && !restart && b > 0 && s->ch[s->min_ch].codebook == 0 && s->ch[s->min_ch].lsbs == 24 &&
@@ -901,7 +903,9 @@ size_t mlp_synth_stream(const mlp_synth_cfg *cfg, uint64_t seed, uint8_t *out, s
                 end += sslen[s];
                 bw_put(&hw, 1, extraword[s]);
                 bw_put(&hw, 1, !restart_au);         /* nonrestart_substream (ignored) */
-                bw_put(&hw, 1, (uint32_t)check);
+                /* (the reference reads substream 1's check bytes when SUBSTREAM 0's flag is set, src/mlp.c:545: what
+                   substream 1's own flag says does not matter) */
+                bw_put(&hw, 1, (uint32_t)((s == 1 && (f & MLP_SF_CHECKQUIRK)) ? !check : check));
                 bw_put(&hw, 1, 0);
                 bw_put(&hw, 12, (uint32_t)(end / 2));
                 if (extraword[s])

@@ -37,6 +37,11 @@ extern "C" {
 #define MLP_SF_TERMINATOR  (1u << 15) /* 0xD234D234 marker after the last block           */
 #define MLP_SF_FIRRAND     (1u << 16) /* random FIR order/shift/coefficients              */
 #define MLP_SF_NOISE       (1u << 17) /* larger noise coefficients and noise_shift        */
+/* (bits 18 and up are not part of the "all features" fuzz set: existing streams stay what they were) */
+#define MLP_SF_CHECKQUIRK  (1u << 18) /* substream 1's checkdata_present flag says the OPPOSITE of substream 0's: the
+                                         reference goes by substream 0's flag for both (src/mlp.c:545)               */
+#define MLP_SF_DISC        (1u << 19) /* what an encoder writes: EVERY block carries parameters, most channels are
+                                         sent and most of those re-send their FIR taps; fixed block positions       */
 
 typedef struct mlp_synth_cfg {
     uint32_t profile;          /* 0 = BASELINE.md recipe, 1 = fuzz (uses .features) */

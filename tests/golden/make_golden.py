@@ -39,6 +39,13 @@ FIXTURES = [
     ("fuzz_midframe", 12, 1, 1, 16, 1, SF["MIDMATRIX"] | SF["PARAMBLOCKS"] | SF["MATRIXRAND"] |
      SF["QSS"] | SF["OUTSHIFT"] | SF["VARBLOCK"], 17, 4),
     ("fuzz_varrows", 6, 0, 1, 24, 1, SF["VARROWS"] | SF["VARBLOCK"], 18, 8),
+    # round 4: the other rate / bit-depth codes (88.2 kHz 20-bit, 176.4 kHz 16-bit); two substreams whose
+    # checkdata_present flags disagree (src/mlp.c:545: substream 0's counts for both), with and without check bytes;
+    # a chained two-substream title with parameters on every block (what an encoder writes)
+    ("recipe_6ch_88k_20bit", 12, 9, 1, 16, 0, 0, 23, 8, dict(bps_code=1)),
+    ("fuzz_2ch_176k_16bit", 1, 10, 1, 12, 1, syn.SF_FAST, 24, 4, dict(bps_code=0)),
+    ("check_flags_disagree_2ss", 12, 1, 2, 24, 1, SF["CHECKQUIRK"] | SF["NOCHECK"] | SF["FIRRAND"] | SF["PARAMBLOCKS"], 25, 4),
+    ("disc_profile_2ss", 12, 1, 2, 24, 1, SF["DISC"] | SF["CHAINED"] | SF["FIRRAND"] | SF["MIXBOOKS"], 26, 8),
 ]
 
 
@@ -62,11 +69,11 @@ def main():
     ref = oracle_lib.Reference()
     here = os.path.dirname(os.path.abspath(__file__))
     only_missing = "--all" not in sys.argv
-    for name, asg, rate, S, naus, prof, feat, seed, ri in FIXTURES:
+    for name, asg, rate, S, naus, prof, feat, seed, ri, *more in FIXTURES:
         if only_missing and os.path.exists(os.path.join(here, name + ".npz")):
             continue
         cfg = syn.make_cfg(assignment=asg, rate_code=rate, n_substreams=S, n_aus=naus, profile=prof,
-                           features=feat, restart_interval=ri)
+                           features=feat, restart_interval=ri, **(more[0] if more else {}))
         data, frames = syn.stream(cfg, seed)
         if name in SYNC_CHANGES:
             which, bps, new_asg = SYNC_CHANGES[name]

@@ -62,16 +62,37 @@ def test_recipe_two_substreams(pkg, oracle):
     _check(pkg, oracle, [(cfg, s) for s in range(1, 5)], lanes=2)
 
 
-@pytest.mark.parametrize("rate", [0, 1, 2])
+@pytest.mark.parametrize("rate", [0, 1, 2, 8, 9, 10])          # 48 / 96 / 192 / 44.1 / 88.2 / 176.4 kHz
 @pytest.mark.parametrize("assignment,S", [(12, 1), (12, 2), (1, 1), (0, 1), (0x14, 2), (0x12, 1), (6, 2)])
 def test_fuzz_fast_features(pkg, oracle, assignment, S, rate):
     syn = pkg.synth
     cases = []
     for seed in range(4):
+        # (the bit-depth codes 16 / 20 / 24 bit ride along: the major sync carries them, the decode does not clamp)
         cfg = syn.make_cfg(assignment=assignment, rate_code=rate, n_substreams=S, n_aus=24, profile=1,
-                           features=syn.SF_FAST, restart_interval=[8, 3, 16, 5][seed])
+                           features=syn.SF_FAST, restart_interval=[8, 3, 16, 5][seed], bps_code=(rate + seed) % 3)
         cases.append((cfg, 100 + seed))
     _check(pkg, oracle, cases, lanes=2)
+
+
+@pytest.mark.parametrize("lanes", [0, 2, 64])
+@pytest.mark.parametrize("S", [1, 2])
+def test_disc_profile_streams(pkg, oracle, S, lanes):
+    """What an encoder writes (generator feature DISC): chained titles -- no raw lead-in at restart points --, every
+    block carries parameters, most channels re-send their FIR taps, mixed code books, fixed block positions; also with
+    the two substreams' checkdata_present flags disagreeing (src/mlp.c:545: substream 0's goes for both).  Through the
+    library's own kernel choice, the lane kernels and the cooperative kernel."""
+    syn = pkg.synth
+    SF = syn.SF
+    cases = []
+    for seed in range(6):
+        feats = SF["DISC"] | SF["CHAINED"] | SF["FIRRAND"] | SF["MIXBOOKS"] | (SF["HUFFOFF"] if seed & 1 else 0) | \
+            (SF["CHECKQUIRK"] | SF["NOCHECK"] if S == 2 and seed >= 3 else 0)
+        cfg = syn.make_cfg(assignment=12 if seed % 3 else 0x14, rate_code=[1, 0, 2, 9, 1, 8][seed], n_substreams=S,
+                           n_aus=40, profile=1, features=feats, restart_interval=[8, 4, 16, 8, 5, 8][seed],
+                           blocks_per_au=[2, 1, 4, 2, 5, 2][seed])
+        cases.append((cfg, 700 + seed))
+    _check(pkg, oracle, cases, lanes=lanes)
 
 
 def test_golden_vectors_on_gpu(pkg):

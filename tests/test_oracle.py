@@ -159,6 +159,35 @@ def test_oracle_vs_reference_on_changed_major_syncs(oracle, pkg, S):
     assert st == 2 and r2 == want_frames and np.array_equal(got, want)
 
 
+@pytest.mark.skipif(not oracle_lib.Reference.available(), reason="compiled reference not present")
+def test_oracle_vs_reference_on_a_long_run_of_changed_major_syncs(oracle, pkg):
+    """src/mlp.c:449-460 drops ANY number of consecutive access units whose major sync announces other parameters.
+    The HIP index walks through at most 64 in a row (csrc/mlp_index.h MAX_DROP) and reports a longer run
+    (tests/test_gpu_parity.py); the restatement has no such bound: 66 in a row against the compiled reference."""
+    import subprocess
+    import sys
+    import tempfile
+    from tests import stream_tools
+    syn = pkg.synth
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=72, restart_interval=1)
+    data, frames = syn.stream(cfg, 4100)
+    which = tuple(range(2, 68))
+    changed, _ = stream_tools.change_sync_params(data, which, g1_bps=0, assignment=None)
+    want_frames = frames - len(which) * 80
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "in.npy"), changed)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from tests import oracle_lib; "
+                "d = np.load(%r); pcm, r = oracle_lib.Reference().decode(d, 12, 1, 2, %d, chunk=1999); "
+                "np.save(%r, pcm)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                      os.path.join(tmp, "in.npy"), frames, os.path.join(tmp, "out.npy")))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        want = np.load(os.path.join(tmp, "out.npy"))
+    assert want.shape == (6, want_frames)
+    got, r2, st = oracle.decode(changed, 6, frames)
+    assert st == 2 and r2 == want_frames and np.array_equal(got, want)
+
+
 def test_oracle_reports_substreams_of_different_access_unit_length():
     """src/mlp.c:1308-1320, 598-603: with substreams that disagree on an access unit's length the reference reads one
     substream's channels past their arrays and appends channels of different lengths.  The restatement reports the
