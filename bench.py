@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the full-size check")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (other shapes of the path)")
+    ap.add_argument("--only-sub", default="", help="comma-separated sub-record names: run only those (profiling)")
     ap.add_argument("--verify", type=int, default=8, help="titles checked against the oracle when the full check is off")
     ap.add_argument("--substreams", type=int, default=1, choices=(1, 2),
                     help="1 = the BASELINE metric; 2 = the recipe's 2-substream variant (ch 0-1 | ch 2-5)")
@@ -365,6 +366,19 @@ def committed_profile(samples, comp_bytes, layout):
     return None
 
 
+def sub_traffic(name, samples, comp_bytes):
+    """counter traffic (FETCH_SIZE x 2 + WRITE_SIZE over the decode call's kernels) of a sub-record from the committed
+    PMC passes, tools/pmc_sub.py -> profiles/sub_traffic.json; None when that file has no entry of this size"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "sub_traffic.json"))).get(name)
+        if tj and tj.get("samples_per_step") == samples and tj.get("compressed_bytes") == comp_bytes:
+            return {"hbm_bytes_per_step": tj["hbm_bytes_per_step"], "per_kernel": tj.get("per_kernel"),
+                    "source": tj.get("source")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def gen_mixed(syn, specs, seed0):
     """Concatenates syn.batch() outputs of several configurations into one flat buffer.
     specs: list of (cfg, n).  -> flat, offs, sizes, frames, nchs, n_segments"""
@@ -413,8 +427,12 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         torch.cuda.empty_cache()
         return r
 
+    only = set(x for x in args.only_sub.split(",") if x)
+
     def run(name, flat, offs, sizes, frames, nchs, nseg, replicas, layout, lanes, benign=0, note=None, flight=0,
             chained=False):
+        if only and name not in only:
+            return
         t_run = time.perf_counter()
         b = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, replicas, layout, lanes, nseg)
         dt, kms, launches = b.timed(steps, warmup)
@@ -425,11 +443,21 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
             raise SystemExit("sub-record %s: HIP decode differs from the oracle" % name)
         # kernel_ms: device time of the whole decode call (fast pass + chain passes + sequential pass + what lies
         # between them); fast_pass_ms: the fast-pass kernels alone
+        algo = b.comp_bytes + b.out_bytes * b.samples
+        kall = b.last_decode_ms
         rec = {"value": round(b.samples * steps / dt / 1e6, 1), "unit": "Msamples/s",
-               "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(b.last_decode_ms, 4),
+               "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(kall, 4),
                "fast_pass_ms": round(kms, 4), "titles": b.n_streams,
                "samples_per_step": b.samples, "compressed_bytes": b.comp_bytes,
-               "algorithmic_bytes_per_launch": b.comp_bytes + b.out_bytes * b.samples,
+               "algorithmic_bytes_per_launch": algo,
+               # the decode call's kernels against the HBM roofline: algorithmic bytes / device time of the whole
+               # call (HIP events, first kernel to last); `traffic` = counter bytes of the same sub-record from the
+               # committed PMC passes (profiles/sub_traffic.json), null when none was taken at this size
+               "roofline": {"bound": "hbm", "kernels": "decode call (all passes)",
+                            "achieved": round(algo / (kall * 1e-3) / 1e9, 2) if kall > 0 else 0.0,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(algo / (kall * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kall > 0 else 0.0,
+                            "traffic": sub_traffic(name, b.samples, b.comp_bytes)},
                "bit_exact_sample": ok}
         if note:
             rec["note"] = note
@@ -455,14 +483,15 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
              "algorithmic bytes = compressed in + 3 B per sample out")
     # ---- batch-size sweep on the headline layout (non-multiples of the 2 048 resident waves included)
     sweep = []
-    for n in (64, 512, 1000, 1536, 2500, 4096):
+    for n in (() if only and "batch_sweep" not in only else (64, 512, 1000, 1536, 2500, 4096)):
         n = min(n, main_batch.n_streams)
         dt, kms, launches = main_batch.timed(max(5, steps // 4), 2, n_streams=n)
         smp = int((main_batch.all_frames[:n] * main_batch.all_nch[:n]).sum())
         k = max(5, steps // 4)
         sweep.append({"titles": n, "segments": n * ((args.aus + 7) // 8), "value": round(smp * k / dt / 1e6, 1),
                       "ms_per_step": round(dt / k * 1e3, 3), "kernel_ms": round(kms, 4)})
-    out["batch_sweep"] = {"unit": "Msamples/s", "points": sweep}
+    if sweep:
+        out["batch_sweep"] = {"unit": "Msamples/s", "points": sweep}
     # ---- two substreams (ch 0-1 | ch 2-5, matrices in substream 1)
     cfg2 = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=2, n_aus=args.aus)
     flat, offs, sizes, frames = syn.batch(cfg2, 1, args.streams)
@@ -543,6 +572,16 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         args.replicas, args.layout, 0, benign=hip.ST_BENIGN,
         note="the bench batch as a disc would hold it: every segment continues the FIR history of the one before it, "
              "two substreams per title; decoded by the chain passes (parse in lane pairs, filter, rematrix)")
+    # ---- the shape a disc really has: chained, two substreams, EVERY block carries parameters (most channels re-send
+    #      their FIR taps), mixed code books, blocks at fixed positions
+    SFd = syn.SF
+    cfgp = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=2, n_aus=args.aus, profile=1,
+                        features=SFd["DISC"] | SFd["CHAINED"] | SFd["FIRRAND"] | SFd["MIXBOOKS"])
+    flat, offs, sizes, frames = syn.batch(cfgp, 1, args.streams)
+    run("disc_profile", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg + args.streams * args.replicas * 2,
+        args.replicas, args.layout, 0, benign=hip.ST_BENIGN,
+        note="what an encoder writes: chained titles, two substreams (ch 0-1 | ch 2-5), parameters on every block -- most "
+             "channels re-send their FIR taps --, per-channel code books, two blocks of 40 PCM frames per access unit")
     one = syn.make_cfg(assignment=12, rate_code=rate, n_substreams=1, n_aus=512, profile=1, features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(one, 7, 1)
     run("chained_single_title", flat, offs, sizes, frames, np.full(1, 6), 512 // 8 + 2, 1, args.layout, 0,
@@ -554,7 +593,12 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     run("chained_single_long_title", flat, offs, sizes, frames, np.full(1, 6), 8192 // 8 + 2, 1, args.layout, 0,
         benign=hip.ST_BENIGN, note="ONE chained 6-ch title of 8 192 access units (68 s of 96 kHz audio): the filter "
                                    "pass's serial recurrence is what bounds it", flight=4, chained=True)
-    out["mixed_corpus_c5"] = mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup)
+    if only and "c4" not in only and "mixed_corpus_c5" not in only:
+        return out
+    if not only or "mixed_corpus_c5" in only:
+        out["mixed_corpus_c5"] = mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup)
+    if only and "c4" not in only:
+        return out
     # ---- BASELINE configs[3] on this GPU: 1 024 independent single-access-unit streams in ONE batch -- the low-
     #      parallelism regime, decoded by the wave-cooperative kernel (csrc/mlp_coop.h); throughput back to back and
     #      the latency of one batch (index + decode enqueued and waited for, host clock); all 1 024 vs the oracle

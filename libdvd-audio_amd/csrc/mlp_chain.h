@@ -253,72 +253,9 @@ __device__ __forceinline__ int32_t iir_step_one(int32_t (&h)[8], const int32_t (
     return v;
 }
 
-// Eight steps of the recursion for a lone wave.  fir_step_rot's sum is ONE chain of eight dependent 64-bit multiply-adds,
-// and a wave that has its SIMD to itself issues in order and waits out every one of them: ~900 cycles per unit of eight
-// PCM frames (measured, round 4: half of what the filter wave of k_chain_fused did with its time).  Only the tap on
-// the newest value depends on the step before.  So a step is cut in two: its TAIL -- the newest tap onto partial sum A,
-// plus partial sum B, shift, plus residual, mask: five dependent instructions -- and the two partial sums of the NEXT
-// step (taps 1, 3, 5, 7 and 2, 4, 6: nothing of them depends on the value the tail is producing), and the two are
-// dealt out alternately, so that no instruction needs the result of the one right before it.  The order is pinned by
-// empty volatile asm statements every value passes through (left to itself the optimizer sorts the sum back into one
-// chain, and the scheduler keeps each chain together).
-#define FU_PIN(v) asm volatile("" : "+v"(v))
-__device__ __forceinline__ void fir_unit8(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask, int4 &p,
-                                          int4 &q)
-{
-    int32_t x[16];                      // x[8 + t] = value of step t; x[7 - j] = h[j] (x[7]: the newest before the unit)
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        x[7 - j] = h[j];
-    const int32_t r[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
-    // partial sums of step 0: tap j multiplies x[7 - j]
-    int64_t a = (int64_t)c[7] * (int64_t)x[0];
-    a += (int64_t)c[5] * (int64_t)x[2];
-    a += (int64_t)c[3] * (int64_t)x[4];
-    a += (int64_t)c[1] * (int64_t)x[6];
-    int64_t b = (int64_t)c[6] * (int64_t)x[1];
-    b += (int64_t)c[4] * (int64_t)x[3];
-    b += (int64_t)c[2] * (int64_t)x[5];
-    FU_PIN(a);
-    FU_PIN(b);
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int n = 8 + t;            // this step: tap j multiplies x[n - 1 - j]; the next one: x[n - j]
-        int64_t sum = a + (int64_t)c[0] * (int64_t)x[n - 1];
-        FU_PIN(sum);
-        int64_t an = (int64_t)c[7] * (int64_t)x[n - 7];
-        FU_PIN(an);
-        sum += b;
-        FU_PIN(sum);
-        int64_t bn = (int64_t)c[6] * (int64_t)x[n - 6];
-        FU_PIN(bn);
-        int32_t ss = (int32_t)(sum >> shift);
-        FU_PIN(ss);
-        an += (int64_t)c[5] * (int64_t)x[n - 5];
-        FU_PIN(an);
-        uint32_t v = (uint32_t)ss + (uint32_t)r[t];
-        FU_PIN(v);
-        bn += (int64_t)c[4] * (int64_t)x[n - 4];
-        FU_PIN(bn);
-        v &= qmask;
-        FU_PIN(v);
-        x[n] = (int32_t)v;
-        an += (int64_t)c[3] * (int64_t)x[n - 3];
-        FU_PIN(an);
-        bn += (int64_t)c[2] * (int64_t)x[n - 2];
-        FU_PIN(bn);
-        an += (int64_t)c[1] * (int64_t)x[n - 1];
-        FU_PIN(an);
-        a = an;
-        b = bn;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        h[j] = x[15 - j];
-    p = make_int4(x[8], x[9], x[10], x[11]);
-    q = make_int4(x[12], x[13], x[14], x[15]);
-}
-
+// (Round 4 tried the eight steps with the sum cut into two shorter chains dealt out alternately with the previous step's
+//  tail, the order pinned by empty asm statements: the same speed on a full chip and 6 % slower on a lone chain --
+//  what a lone wave pays for is the NUMBER of instructions, four cycles each, not their dependencies.)
 __device__ __forceinline__ void fir_step8(int32_t (&h)[8], const int32_t (&c)[8], uint32_t shift, uint32_t qmask, int4 &p,
                                           int4 &q)
 {
@@ -351,13 +288,23 @@ __device__ __forceinline__ uint32_t chain_bucket(const ChainArgs &a, uint32_t ci
     return CHAIN_BUCKETS - 1u - (cls < CHAIN_BUCKETS ? cls : CHAIN_BUCKETS - 1u);   // longest first
 }
 
+// (chains of a batch are mostly ALIKE in length -- one class: counted per workgroup in LDS first, one atomic per
+//  workgroup and class on the global counters; 10^5 lanes adding to one address took 2 ms a kernel)
 __global__ __launch_bounds__(256) void k_chain_hist(ChainArgs a)
 {
+    __shared__ uint32_t s_h[CHAIN_BUCKETS];
+    for (uint32_t i = threadIdx.x; i < CHAIN_BUCKETS; i += 256u)
+        s_h[i] = 0;
+    __syncthreads();
     const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = chain_n_seg(a);
     const uint32_t n_chains = a.plan[n].z;
     if (ci < n_chains)
-        atomicAdd(&a.chain_hist[chain_bucket(a, ci, n_chains, n)], 1u);
+        atomicAdd(&s_h[chain_bucket(a, ci, n_chains, n)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CHAIN_BUCKETS; i += 256u)
+        if (s_h[i])
+            atomicAdd(&a.chain_hist[i], s_h[i]);
 }
 
 // one workgroup: class counts -> class starts (exclusive scan), the counts' place becomes the fill cursors
@@ -379,14 +326,25 @@ __global__ __launch_bounds__(CHAIN_BUCKETS) void k_chain_scan(ChainArgs a)
 
 __global__ __launch_bounds__(256) void k_chain_scatter(ChainArgs a)
 {
+    __shared__ uint32_t s_h[CHAIN_BUCKETS];         // chains of this workgroup per class, then where the workgroup's run starts
+    for (uint32_t i = threadIdx.x; i < CHAIN_BUCKETS; i += 256u)
+        s_h[i] = 0;
+    __syncthreads();
     const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = chain_n_seg(a);
     const uint32_t n_chains = a.plan[n].z;
-    if (ci >= n_chains)
-        return;
-    const uint32_t b = chain_bucket(a, ci, n_chains, n);
-    const uint32_t at = a.chain_hist[CHAIN_BUCKETS + b] + atomicAdd(&a.chain_hist[b], 1u);
-    DVDA_AT(a.chain_order, at, a.caps.max_seg, BT_C_HEAD) = ci;
+    uint32_t b = 0, mine = 0;
+    if (ci < n_chains) {
+        b = chain_bucket(a, ci, n_chains, n);
+        mine = atomicAdd(&s_h[b], 1u);              // place among the workgroup's chains of the class
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CHAIN_BUCKETS; i += 256u)
+        if (s_h[i])
+            s_h[i] = a.chain_hist[CHAIN_BUCKETS + i] + atomicAdd(&a.chain_hist[i], s_h[i]);
+    __syncthreads();
+    if (ci < n_chains)
+        DVDA_AT(a.chain_order, s_h[b] + mine, a.caps.max_seg, BT_C_HEAD) = ci;
 }
 
 // ---------------------------------------------------------------------------------- filter + rematrix, fused
@@ -478,6 +436,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
     __shared__ uint32_t s_rec[FU_RECS][64][4];      // access-unit records, words 0..31 (lane cl * 8 + j holds words 4j..4j+3)
     __shared__ uint32_t s_b[8][8 * 6 * 3 / 4];      // packed WAV payload of a unit, per chain: 8 frames x 18 bytes at most
     __shared__ int4 s_ring[FU_RING][2][64];         // the filter wave's units in flight: ring place, line of the unit, lane
+    __shared__ uint4 s_nx[64];                      // what the index and the parse pass left about the segment BEHIND the one in
+                                                    // work, asked for when that one was set up: lane j of a chain holds piece j
     __shared__ uint4 s_brl[FU_BRECS][64], s_brh[FU_BRECS][64];     // the next block records of each filter lane's slot (ring by
                                                                    // record number): dwords 0..3 and 4..7 of the slot's eight
     const uint32_t wv = threadIdx.x >> 6;
@@ -547,6 +507,10 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             for (uint32_t qu = 0; qu < (uint32_t)FU_T; qu++) {
             if (qu >= cnt)
                 continue;
+#if defined(DVDA_FU_X_NOOUT)        // (timing experiments only: the output wave takes the units and does nothing with them)
+            ou++;
+            continue;
+#endif
             const int32_t *const X = s_x[t][qu] + cl * FU_XS;
             int32_t ch[6];
 #pragma unroll
@@ -751,6 +715,9 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
     fu_use(seg);
     uint32_t fbase_first = alive ? a.seg_fbase[sr.first_seg] : 0u;     // (output rows count from the stream's first segment)
     fu_use(fbase_first);
+    bool have_nx = false;                   // the end of a segment found the next one's pieces in LDS: its set-up takes them
+    uint32_t nx_stream = 0, nx_nframes = 0, nx_flags = 0, nx_ndrop = 0, nx_ss = 0, nx_m0 = 0, nx_m1 = 0, nx_fb = 0;
+    uint4 nx_pl = make_uint4(0, 0, 0, 0), nx_pl1 = nx_pl;
     uint32_t turn = 0;                      // turns of the flat loop below (wave-uniform: every lane takes every turn)
     // ---- the segment in work
     bool run = false;                       // units of it are left
@@ -776,6 +743,33 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
     bool need_first = false;                // record 0's frame has not been looked at yet (it was still on its way)
     unsigned long long rstamp = 0;          // turn (mod 256) each of the FU_BRECS ring places was asked for, a byte each
     uint32_t srow = 0, next_row = 0xFFFFFFFFu, rcur = 0;    // IIR segments: frame by frame, records straight from memory
+
+    // ---- the segment behind the one in work, ahead of time.  Setting a segment up is a handful of small loads in a row
+    //      (its index entry, status, channel ranges, plan entries, first access unit), and every wait for one of them
+    //      also stands in front of everything the ring has in flight: ~20 k cycles per segment when the chip is busy, a
+    //      sixth of the filter wave's time.  So when a segment is set up, the eight lanes of the chain ask for those pieces of
+    //      segment + 1 -- straight into LDS, like everything else here -- and eighty units later its set-up finds them there.
+    //      (A dead segment in between, or a chain's first segment: the loads as before.)
+    uint32_t nx_seg = 0xFFFFFFFFu, nx_turn = 0;
+    auto ask_next = [&](uint32_t nx) __attribute__((always_inline)) {
+        nx_seg = 0xFFFFFFFFu;
+        if (nx >= n)
+            return;
+        const char *src;
+        switch (p) {
+        case 0: src = reinterpret_cast<const char *>(a.seg + nx); break;                    // off, end
+        case 1: src = reinterpret_cast<const char *>(a.seg + nx) + 16; break;               // stream, nframes, flags, sync
+        case 2: src = reinterpret_cast<const char *>(a.seg + nx) + 24; break;               // flags, sync, ndrop, prev
+        case 3: src = reinterpret_cast<const char *>(a.seg_status + nx); break;             // (the arrays behind these
+        case 4: src = reinterpret_cast<const char *>(a.seg_meta + (size_t)nx * 2); break;   //  four are four entries longer
+        case 5: src = reinterpret_cast<const char *>(a.plan + nx); break;                   //  than their last index: the
+        case 6: src = reinterpret_cast<const char *>(a.plan + nx + 1); break;               //  16 bytes are always there)
+        default: src = reinterpret_cast<const char *>(a.seg_fbase + nx); break;
+        }
+        fu_dma16(src, fu_lds(&s_nx[0]));
+        nx_seg = nx;
+        nx_turn = turn;
+    };
 
     // record r of this lane's slot: into ring place r % FU_BRECS, straight from memory (one instruction per place
     // value: the LDS base of a load instruction is the wave's, the place is the lane's)
@@ -891,7 +885,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
         if (left == 0)
             apply();
         if (left >= 8u) {
-            fir_unit8(h, c, shift, qmask, x, y);
+            fir_step8(h, c, shift, qmask, x, y);
             left -= 8u;
         } else {
             // a block starts inside the unit (test streams; encoders cut blocks at multiples of eight frames)
@@ -947,6 +941,12 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FU_WAIT) : "memory");
                 const uint32_t ubase = u;
                 const uint32_t cnt = nu - u < (uint32_t)FU_T ? nu - u : (uint32_t)FU_T;
+                // A lone wave pays four cycles for every instruction it issues, scalar ones included, and the general form of
+                // a unit -- is the chain running, has the segment this unit, does a block start here or inside it, IIR
+                // taps, the first record not looked at yet: a per-lane branch each -- is ~60 of them around the recursion's
+                // 100.  So the wave asks ONCE per unit whether every running chain has a whole plain unit in front of it
+                // (nearly always): then the unit is the recursion under one mask and two stores.
+                const bool plain_turn = cnt == (uint32_t)FU_T && !seg_iir && !need_first;
                 int4 na = s_ring[pbase][0][lane], nb = s_ring[pbase][1][lane];
                 for (uint32_t qu = 0; qu < (uint32_t)FU_T; qu++) {
                     int4 xa = na, xb = nb;
@@ -954,13 +954,16 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                     const uint32_t nq = qu + 1u < (uint32_t)FU_T ? qu + 1u : qu;
                     na = s_ring[pbase + nq][0][lane];
                     nb = s_ring[pbase + nq][1][lane];
-                    if (qu < cnt) {
-#if defined(DVDA_EXP_STAMP)
-                        FU_STAMP(0);
-#endif
+                    int32_t *const X = s_x[t][qu] + cl * FU_XS;
+                    if (__all(plain_turn && (!filt || left >= 8u))) {
+                        if (filt) {
+                            fir_step8(h, c, shift, qmask, xa, xb);
+                            left -= 8u;
+                        }
+                        reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
+                        reinterpret_cast<int4 *>(X + p * 8)[1] = xb;
+                    } else if (qu < cnt) {
                         filter_unit(xa, xb);
-                        FU_STAMP(1);
-                        int32_t *const X = s_x[t][qu] + cl * FU_XS;
                         reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
                         reinterpret_cast<int4 *>(X + p * 8)[1] = xb;
                     }
@@ -1004,12 +1007,34 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 recno += n_au;
                 // ---- on to the next segment of the stream while it continues this history
                 uint32_t nxt = seg + 1;
-                while (nxt < n && a.seg[nxt].stream == r0.stream && (a.seg[nxt].flags & SEG_DEAD))
-                    nxt++;
-                if (any_over || nxt >= n || a.seg[nxt].stream != r0.stream) {
+                have_nx = false;
+                if (nx_seg == nxt) {
+                    // (asked for when this segment was set up; a segment of a few units can end before "all but the newest
+                    //  loads are done" covers it: then, and only then, everything in flight is waited for)
+                    if (turn - nx_turn <= (uint32_t)FU_DT + 1u)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const uint32_t g0 = (lane & 56u);
+                    const uint4 e1 = s_nx[g0 + 1], e2 = s_nx[g0 + 2], e3 = s_nx[g0 + 3], e4 = s_nx[g0 + 4];
+                    nx_pl = s_nx[g0 + 5];
+                    nx_pl1 = s_nx[g0 + 6];
+                    nx_fb = s_nx[g0 + 7].x;
+                    nx_stream = e1.x;
+                    nx_nframes = e1.y;
+                    nx_flags = e1.z;
+                    nx_ndrop = e2.z;
+                    nx_ss = e3.x;
+                    nx_m0 = e4.x;
+                    nx_m1 = e4.y;
+                    have_nx = nx_stream == r0.stream && !(nx_flags & SEG_DEAD);
+                }
+                if (!have_nx) {
+                    while (nxt < n && a.seg[nxt].stream == r0.stream && (a.seg[nxt].flags & SEG_DEAD))
+                        nxt++;
+                }
+                if (any_over || nxt >= n || (have_nx ? nx_stream : a.seg[nxt].stream) != r0.stream) {
                     alive = false;
                 } else {
-                    const uint4 pn = a.plan[nxt], qn = a.plan[nxt + 1];
+                    const uint4 pn = have_nx ? nx_pl : a.plan[nxt], qn = have_nx ? nx_pl1 : a.plan[nxt + 1];
                     if (qn.y == pn.y || qn.z != pn.z)
                         alive = false;                  // not deferred, or the head of the next chain
                     else
@@ -1018,10 +1043,35 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             }
             if (alive && !run) {
                 // ---- set the segment up (between two barriers: the output wave sees no unit of this chain meanwhile)
-                const SegRec r = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
-                const uint32_t ss = a.seg_status[seg];
-                meta0 = DVDA_AT(a.seg_meta, (size_t)seg * 2, a.caps.lanes, BT_C_META);
-                meta1 = S == 2u ? DVDA_AT(a.seg_meta, (size_t)seg * 2 + 1, a.caps.lanes, BT_C_META) : 0u;
+                SegRec r;
+                uint32_t ss;
+                uint4 pl;
+                uint32_t fb;
+                if (have_nx) {
+                    r.stream = nx_stream;
+                    r.nframes = nx_nframes;
+                    r.flags = nx_flags;
+                    r.ndrop = nx_ndrop;
+                    ss = nx_ss;
+                    meta0 = nx_m0;
+                    meta1 = S == 2u ? nx_m1 : 0u;
+                    pl = nx_pl;
+                    fb = nx_fb;
+                } else {
+                    r = DVDA_AT(a.seg, seg, a.caps.max_seg, BT_C_SEG);
+                    ss = a.seg_status[seg];
+                    meta0 = DVDA_AT(a.seg_meta, (size_t)seg * 2, a.caps.lanes, BT_C_META);
+                    meta1 = S == 2u ? DVDA_AT(a.seg_meta, (size_t)seg * 2 + 1, a.caps.lanes, BT_C_META) : 0u;
+                    pl = DVDA_AT(a.plan, seg, a.caps.max_seg + 1u, BT_C_PLAN);
+                    fb = a.seg_fbase[seg];
+                    fu_use(r.nframes);
+                    fu_use(r.ndrop);
+                    fu_use(ss);
+                    fu_use(pl.x);
+                    fu_use(pl.y);
+                    fu_use(fb);
+                }
+                have_nx = false;
                 uint32_t fail = 0;
                 if (ss & ~ST_INFO)
                     fail = ss & ~ST_INFO;               // the parse pass stopped on an error here
@@ -1031,8 +1081,6 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                                                (S == 2u && prev_meta1 && ((prev_meta1 ^ meta1) & 0xFFu))))
                     fail = ST_ENVELOPE;                 // a substream's channel range changes under a running history
                 const uint32_t R = (r.nframes - r.ndrop) * rpa;
-                const uint4 pl = DVDA_AT(a.plan, seg, a.caps.max_seg + 1u, BT_C_PLAN);
-                const uint32_t fb = a.seg_fbase[seg];
                 if (!fail && (R == 0 ||
                               !DVDA_RANGE_OK((size_t)pl.x * 8u, 8ull * R, a.caps.res, BT_C_RES) ||
                               !DVDA_RANGE_OK((size_t)(pl.x / 40u) * FREC_WORDS, (size_t)(r.nframes - r.ndrop) * FREC_WORDS, a.caps.frec, BT_C_FREC) ||
@@ -1102,6 +1150,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                         }
                     }
                     run = true;
+                    ask_next(seg + 1u);
                     // (everything the set-up loaded is in its registers when the turns go on)
                     fu_use(row0);
                     fu_use(rmax);

@@ -69,7 +69,16 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_HDR_GATE
 #define DVDA_HDR_GATE 1
 #endif
-constexpr uint32_t HDR_GATE_TURNS = 4, HDR_GATE_LANES = 16;
+// (round 4, tools/probe/sub_ab.sh: 4 turns / 16 lanes -> 32 / 32: fuzz_fast_features 26.0 -> 33.2 Gsamples/s,
+//  fuzz_all_features 10.3 -> 12.5, the header phase's share of a wave's time 62 -> 38 %; the headline -- lanes in
+//  lockstep, the phase runs when all of them wait -- and the heterogeneous batches do not move)
+#ifndef DVDA_HDR_GATE_TURNS
+#define DVDA_HDR_GATE_TURNS 32
+#endif
+#ifndef DVDA_HDR_GATE_LANES
+#define DVDA_HDR_GATE_LANES 32
+#endif
+constexpr uint32_t HDR_GATE_TURNS = DVDA_HDR_GATE_TURNS, HDR_GATE_LANES = DVDA_HDR_GATE_LANES;
 // The row-loop experiments of rounds 1 and 2 that lost (ring holding byte-swapped dwords, slot tests on a scalar
 // count, the second window step without its branch, split FIR accumulators, uniform slots, line-aware prefetch,
 // store cache policies, alternating wave roles) are no longer in this file: DESIGN.md section 4 keeps what each
@@ -888,8 +897,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // every loop turn has some lane at a header, and the whole wave pays the parser every turn: the header
         // parse becomes the row loop (sub.fuzz_fast_features: 9 x below the headline in round 2).  So headers are
         // parsed in company: the phase runs when every active lane waits for it (lanes in lockstep: at once), when
-        // HDR_GATE_LANES of them do, or on every HDR_GATE_TURNS-th turn -- a lane waits a few turns, rowless, and
-        // the wave pays the parser a quarter as often.  (Not in the two-wave layout -- its waves exchange rows by
+        // HDR_GATE_LANES of them do, or on every HDR_GATE_TURNS-th turn -- a lane waits some turns, rowless, and
+        // the wave pays the parser that much less often.  (Not in the two-wave layout -- its waves exchange rows by
         // turn count -- nor in the sequential pass, whose lane pairs end access units together.)
         bool hdr_now = active && rows_left == 0;
         if (HDR_GATE && __builtin_expect(__any(hdr_now), 0)) {

@@ -256,10 +256,11 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
             e = ws_malloc(p, bytes ? bytes : 16);
     };
     alloc((void **)&c->d_cand_off, ns * sizeof(uint64_t));
-    alloc((void **)&c->d_seg, ns * sizeof(SegRec));
+    // (+ 4 entries on the arrays k_chain_fused prefetches 16 bytes at a time from: the read behind the last index stays inside)
+    alloc((void **)&c->d_seg, (ns + 4) * sizeof(SegRec));
     alloc((void **)&c->d_seg_frames, (ns + 1) * sizeof(uint32_t));
-    alloc((void **)&c->d_seg_fbase, (ns + 1) * sizeof(uint32_t));
-    alloc((void **)&c->d_seg_status, ns * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_fbase, (ns + 5) * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_status, (ns + 4) * sizeof(uint32_t));
     alloc((void **)&c->d_seg_rows, ns * sizeof(uint32_t));
     alloc((void **)&c->d_streams, (size_t)max_streams * sizeof(StreamRec));
     // two lanes per segment at most, rounded up to whole workgroups
@@ -268,7 +269,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_mat, (size_t)c->iir_lanes * MAXMAT * 5 * sizeof(uint32_t));
     alloc((void **)&c->d_dbg, 32 * sizeof(unsigned long long));
     alloc((void **)&c->d_fir, (size_t)c->iir_lanes * 6 * 8 * sizeof(int32_t));
-    alloc((void **)&c->d_seg_meta, (size_t)c->iir_lanes * sizeof(uint32_t));
+    alloc((void **)&c->d_seg_meta, ((size_t)c->iir_lanes + 4) * sizeof(uint32_t));
     alloc((void **)&c->d_yield, ns * sizeof(uint32_t));
     alloc((void **)&c->d_seg_check, 2 * ns * sizeof(uint32_t));
     alloc((void **)&c->d_cls, 4 * sizeof(uint32_t));
@@ -281,7 +282,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_lane_seg, ns * sizeof(uint32_t));
     alloc((void **)&c->d_summary, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary));        // the total + the fast pass's partial sums
     alloc((void **)&c->d_seq_list, (size_t)max_streams * sizeof(uint32_t));
-    alloc((void **)&c->d_plan, (ns + 1) * sizeof(uint4));
+    alloc((void **)&c->d_plan, (ns + 5) * sizeof(uint4));
     alloc((void **)&c->d_scan4_tmp, (ns / 1024 + 4) * sizeof(uint4));
     alloc((void **)&c->d_def_list, ns * sizeof(uint32_t));
     alloc((void **)&c->d_head_list, ns * sizeof(uint32_t));

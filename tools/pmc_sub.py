@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""tools/pmc_sub.py DIR SUB[,SUB...] -- what tools/pmc_sub.sh collected, per sub-record: every kernel of the decode call
+with its mean duration (kernel trace), launches per step, and its HBM counter bytes per step -- FETCH_SIZE (KiB,
+doubled: gfx950 tallies a 128-byte read request as 64 bytes, MI355X_MICROARCH.md; calibrated on k_sync_mask, which
+reads the input once) and WRITE_SIZE (KiB) -- beside the sub-record's algorithmic bytes.  Writes DIR/sub_traffic.json
+(entries for profiles/sub_traffic.json, which bench.py carries into the sub-records' `roofline.traffic`)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out_dir, subs = sys.argv[1], sys.argv[2].split(",")
+STEPS = 4          # --steps 3 --warmup 1 of the traced runs: launches per kernel / STEPS = launches per step
+
+
+def short(n):
+    n = n.replace("void ", "").replace("mlp::", "")
+    return n.split("(")[0][:44]
+
+
+res = {}
+for sub in subs:
+    d = os.path.join(out_dir, sub)
+    bench = None
+    try:
+        for line in open(os.path.join(d, "bench.json")):
+            if line.startswith("{"):
+                bench = json.loads(line)
+    except OSError:
+        pass
+    rec = (bench or {}).get("sub", {}).get(sub)
+    dur = {}
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[short(r["Name"])] = (float(r["AverageNs"]) / 1e6, int(r["Calls"]))
+    ctr = defaultdict(lambda: defaultdict(list))
+    for which in ("fetch", "write"):
+        for f in glob.glob(os.path.join(d, which, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                ctr[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # the headline batch runs in the same process (main record): its kernels are in the trace too; the sub-record's
+    # own decode call is told apart by the kernels only it launches being present -- all are listed, by name
+    print("== %s" % sub)
+    if rec:
+        print("   %s Msamples/s, %.3f ms/step, decode call %.3f ms on the device; algorithmic bytes per step %.3f GB" % (
+            rec["value"], rec["ms_per_step"], rec["kernel_ms"], rec["algorithmic_bytes_per_launch"] / 1e9))
+    per_kernel = {}
+    tot = 0.0
+    for k in sorted(dur, key=lambda k: -dur[k][0] * dur[k][1]):
+        ms, calls = dur[k]
+        if ms * calls < 0.05 or k.startswith("__amd") or k.startswith("at::"):
+            continue
+        fe = ctr[k].get("FETCH_SIZE")
+        wr = ctr[k].get("WRITE_SIZE")
+        fb = 2.0 * 1024 * sum(fe) / len(fe) if fe else None
+        wb = 1024 * sum(wr) / len(wr) if wr else None
+        print("   %-46s %8.3f ms x %5.1f per step   read %8s  written %8s  (GB per launch)" % (
+            k, ms, calls / STEPS, "%.3f" % (fb / 1e9) if fb is not None else "-", "%.3f" % (wb / 1e9) if wb is not None else "-"))
+        per_kernel[k] = {"ms": round(ms, 4), "launches_per_step": round(calls / STEPS, 2),
+                         "fetch_bytes": int(fb) if fb is not None else None, "write_bytes": int(wb) if wb is not None else None}
+    if rec:
+        # bytes of the sub-record's own step: kernels weighted by how often a step launches them.  (The headline batch's
+        # kernels of the same process are in these means too where the names coincide: k_sync_mask, k_decode<6,..,true,false>
+        # of an unchained batch -- stated, not hidden: the chain-pass kernels and the parse pass are the sub-record's alone.)
+        own = [k for k in per_kernel if any(t in k for t in ("k_chain", "false, true>", "k_coop<true>"))]
+        tb = sum((per_kernel[k]["fetch_bytes"] or 0) + (per_kernel[k]["write_bytes"] or 0) for k in own)
+        res[sub] = {"samples_per_step": rec["samples_per_step"], "compressed_bytes": rec["compressed_bytes"],
+                    "hbm_bytes_per_step": int(tb), "kernels_counted": own, "per_kernel": per_kernel,
+                    "algorithmic_bytes": rec["algorithmic_bytes_per_launch"], "source": os.path.basename(out_dir.rstrip("/"))}
+        print("   passes behind the fast pass (%s): %.2f GB of counter traffic per step = %.2f x the step's algorithmic bytes" % (
+            ", ".join(own), tb / 1e9, tb / max(rec["algorithmic_bytes_per_launch"], 1)))
+json.dump(res, open(os.path.join(out_dir, "sub_traffic.json"), "w"), indent=1)
