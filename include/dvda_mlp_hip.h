@@ -261,6 +261,12 @@ int dvda_mlp_hip_bounds_violations(unsigned long long *out4);
  * and soaks that want the lane kernels on small batches). */
 int dvda_mlp_hip_set_lanes_per_segment(dvda_mlp_hip_ctx *ctx, uint32_t lanes);
 
+/* Which form the chain passes behind the parse pass take (segments that continue the FIR history of the one before
+ * them, src/mlp.c:297-304, 1302; csrc/mlp_chain.h).  0 (default): chosen per batch -- few deferred segments (one title,
+ * a small batch): the recursion in place on the planes and a parallel rematrix pass behind it; many: ONE walk over
+ * the planes by two-wave workgroups (k_chain_fused).  1 / 2 force the fused / the two-pass form (tests).  Same PCM. */
+int dvda_mlp_hip_set_chain_form(dvda_mlp_hip_ctx *ctx, uint32_t form);
+
 /* Per-segment results of the last decode (blocks on `stream`). */
 typedef struct dvda_mlp_segment_info {
     uint64_t offset, end;     /* byte range of the segment in the input buffer */

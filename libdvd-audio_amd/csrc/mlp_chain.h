@@ -53,6 +53,7 @@ struct ChainArgs {
     const uint64_t *out_stride;
     uint32_t interleaved;
     uint32_t wav_bits;             // 0, or 16 / 24: packed WAV payload instead of int32 values
+    uint32_t remat_blocks;         // k_chain_rematrix (mlp_chain_small.h): workgroups per segment (1 unless segments are very long)
     WsCaps caps;                   // what the workspaces hold (block-record walks stop there; the range-checked build)
     unsigned long long *dbg;       // diagnostic builds only (DVDA_EXP_STAMP): per-phase cycle sums of k_chain_fused
 };
@@ -389,7 +390,12 @@ constexpr int FU_DT = 3;            // turns a unit is asked for ahead of its us
 constexpr int FU_RING = FU_T * FU_DT;       // units a filter lane has in flight
 constexpr int FU_XS = 72;           // dwords of exchange tile per chain and unit: 8 planes x 8 frames, + 8 so that the chains of
                                     // a half-wave fall on different LDS banks
-constexpr int FU_THREADS = 128;
+constexpr int FU_OUT = 1;           // output waves of a workgroup: a turn's units go to them in turn (unit q to wave 1 + q % FU_OUT).
+                                    // (Two were measured, round 4: a lone chain 4 % faster, the bench-size batch 36 % SLOWER --
+                                    //  4 096 chains are 512 workgroups = two per compute unit: with two waves each every wave has
+                                    //  a SIMD to itself, with three some SIMDs carry two, and a workgroup runs at the pace of its
+                                    //  slowest wave.)
+constexpr int FU_THREADS = 64 * (1 + FU_OUT);
 constexpr int FU_RECS = 8;          // access-unit records per chain in LDS (ring by record number)
 constexpr int FU_BRECS = 8;         // block records per filter lane in LDS (ring by record number)
 constexpr int FU_WAIT = 2 * FU_T * (FU_DT - 1);     // loads a filter lane has asked for since the units of this turn
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                                                     // access units' records in memory (64 bit) | their first number in the record ring
     __shared__ uint32_t s_ctl[2];                   // per tile: FU_DONE when the filter wave is through
     __shared__ uint32_t s_rec[FU_RECS][64][4];      // access-unit records, words 0..31 (lane cl * 8 + j holds words 4j..4j+3)
-    __shared__ uint32_t s_b[8][8 * 6 * 3 / 4];      // packed WAV payload of a unit, per chain: 8 frames x 18 bytes at most
+    __shared__ uint32_t s_b[FU_OUT][8][8 * 6 * 3 / 4];     // packed WAV payload of a unit, per output wave and chain: 8 frames x 18 bytes at most
     __shared__ int4 s_ring[FU_RING][2][64];         // the filter wave's units in flight: ring place, line of the unit, lane
     __shared__ uint4 s_nx[64];                      // what the index and the parse pass left about the segment BEHIND the one in
                                                     // work, asked for when that one was set up: lane j of a chain holds piece j
@@ -467,8 +473,11 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
     if (S == 0 || S > 2 || rpa == 0 || nch_out == 0)
         alive = false;
 
-    if (wv == 1) {
-        // ================================================================================ the output wave
+    if (wv != 0) {
+        // ================================================================================ an output wave
+        // (FU_OUT of them: the filter wave's turn is FU_T recursions in a row, an output wave's share of it FU_T / FU_OUT
+        //  units -- the chain's pace is the filter wave's, not the sum of both kinds of work)
+        const uint32_t my_q = wv - 1u;
         const uint32_t wavepk = wave_pack(assignment);
         const uint64_t out_stride = a.out_stride[r0.stream];
         int32_t *const out = a.pcm + a.out_off[r0.stream];
@@ -485,7 +494,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
         uint64_t row0 = 0;                          // the segment in work: its first output row, ...
         const uint32_t *F0 = nullptr;               // ... its access units' records in memory, ...
         uint32_t recno = 0;                         // ... and the first one's number in the record ring
-        uint32_t ou = 0, oau = 0, oleft = 0;        // units of it taken, access units opened, units until the next one opens
+        uint32_t ou = 0, oau = 0, oleft = 0;        // units of it seen, access units opened, units until the next one opens
+        uint32_t have_au = 0xFFFFFFFFu;             // the access unit whose record these registers hold
         for (uint32_t j = 0;; j++) {
             FU_STAMP(3);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -501,16 +511,21 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 F0 = reinterpret_cast<const uint32_t *>(((uint64_t)g0.w << 32) | g0.z);
                 recno = g1.x;
                 ou = oau = oleft = 0;
+                have_au = 0xFFFFFFFFu;
             }
-            if (p == 0 && cw)
-                s_cnt[t][cl] = 0;                   // taken (a chain that pauses leaves nothing here next time)
             for (uint32_t qu = 0; qu < (uint32_t)FU_T; qu++) {
             if (qu >= cnt)
                 continue;
-#if defined(DVDA_FU_X_NOOUT)        // (timing experiments only: the output wave takes the units and does nothing with them)
+            // (every output wave counts every unit: which access unit it belongs to, where it goes)
+            if (oleft == 0) {
+                oau++;
+                oleft = rpu;
+            }
+            oleft--;
+            const uint64_t urow = row0 + (uint64_t)ou * 8u;                 // the unit's first output row
             ou++;
-            continue;
-#endif
+            if ((qu % (uint32_t)FU_OUT) != my_q)
+                continue;                           // the other output wave's
             const int32_t *const X = s_x[t][qu] + cl * FU_XS;
             int32_t ch[6];
 #pragma unroll
@@ -518,12 +533,11 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 ch[q] = X[q * 8 + p];
             const uint32_t bypass_bits = (uint32_t)X[6 * 8 + p];
             const uint32_t seed = (uint32_t)X[7 * 8 + p];
-            if (oleft == 0) {
-                // ---- the unit opens an access unit: its record from its place in the ring
-                f_rec = (recno + oau) & (FU_RECS - 1);
-                f_mem = F0 + (size_t)oau * FREC_WORDS;
-                oau++;
-                oleft = rpu;
+            if (have_au != oau - 1u) {
+                // ---- the first unit this wave takes of an access unit: its record from its place in the ring
+                have_au = oau - 1u;
+                f_rec = (recno + have_au) & (FU_RECS - 1);
+                f_mem = F0 + (size_t)have_au * FREC_WORDS;
                 const uint32_t *R0 = &s_rec[f_rec][cl * 8u][0];
                 fw0 = R0[0];
                 f_outch = R0[1];
@@ -545,9 +559,6 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 mc[1][6] = lo16(R0[13]);
                 mc[1][7] = hi16(R0[13]);
             }
-            oleft--;
-            const uint64_t urow = row0 + (uint64_t)ou * 8u;                 // the unit's first output row
-            ou++;
             FU_STAMP(1);
             const uint32_t noise_shift = fw0 & 0xFFu, matrix_len = (fw0 >> 8) & 0xFFu, mmc = fw0 >> 16;
             const uint32_t shifted = (seed >> 7) & 0xFFFFu;
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             const uint64_t orow = urow + p;
             if (a.wav_bits) {
                 const uint32_t nb = a.wav_bits >> 3, spf = nch_out * nb;
-                uint8_t *const sb = reinterpret_cast<uint8_t *>(s_b[cl]);
+                uint8_t *const sb = reinterpret_cast<uint8_t *>(s_b[my_q][cl]);
 #pragma unroll
                 for (int q = 0; q < 6; q++)
                     if ((uint32_t)q < nch_out) {
@@ -612,7 +623,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 const uint32_t ndw = nvalid * spf >> 2;                     // (8 frames are a whole number of dwords)
                 uint32_t *const od = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(out) + urow * spf);
                 for (uint32_t d = p; d < ndw; d += 8u)
-                    od[d] = s_b[cl][d];
+                    od[d] = s_b[my_q][cl][d];
                 for (uint32_t bb = (ndw << 2) + p; bb < nvalid * spf; bb += 8u)   // (the capacity ends inside the unit)
                     reinterpret_cast<uint8_t *>(od)[bb] = sb[bb];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             }
         }
 #if defined(DVDA_EXP_STAMP)
-        if (lane == 0 && a.dbg)
+        if (lane == 0 && a.dbg && wv == 1)
             for (int i = 0; i < 8; i++)
                 atomicAdd(&a.dbg[24 + i], fu_acc[i]);
 #endif
@@ -986,6 +997,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                 for (int qu = 0; qu < FU_T; qu++)
                     dma_unit(ubase + (uint32_t)(FU_RING + qu), pbase + (uint32_t)qu);
             }
+            if (!ran && p == 0)
+                s_cnt[t][cl] = 0;                   // (a chain that pauses, or is through, leaves no units in this turn's tile)
             FU_STAMP(2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             FU_STAMP(3);

@@ -22,6 +22,7 @@
 #include "../../include/dvda_mlp_hip.h"
 #include "mlp_decode.h"
 #include "mlp_chain.h"
+#include "mlp_chain_small.h"
 #include "mlp_check.h"
 #include "mlp_coop.h"
 #include "mlp_index.h"
@@ -121,6 +122,7 @@ struct dvda_mlp_hip_ctx {
     bool decoded;              // a decode call has run on the current index (the next one resets the segments first)
     uint32_t lanes_per_seg;
     uint32_t pcm_layout;           // DVDA_PCM_PLANAR / DVDA_PCM_INTERLEAVED
+    uint32_t chain_form;           // 0: by the batch (few deferred segments: two passes, else the fused kernel); 1: fused; 2: two passes
     // the index's launch sequence as a hipGraph, replayed while a caller indexes the same buffers again and
     // again (a pipeline that reuses its staging buffers, the bench): one graph launch instead of ~18 launches
     hipGraphExec_t idx_graph;
@@ -249,6 +251,7 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     c->d_init_fir = nullptr;
     c->lanes_per_seg = 0;           // chosen per batch from the indexed substream counts
     c->pcm_layout = DVDA_PCM_PLANAR;
+    c->chain_form = 0;
     const size_t ns = (size_t)max_segments;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -910,6 +913,16 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
                                    dim3(DEC_THREADS), 0, st, a);
             }
         }
+        if (c->chain_form == 2 || (c->chain_form == 0 && segs <= CHAIN_SMALL_SEGS)) {
+            // few chains (one title, a small batch): the lean two-pass form (mlp_chain_small.h)
+            // filter: 16 lanes per chain (at most one chain per deferred segment)
+            hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);
+            // rematrix: one lane per PCM frame (a workgroup walks its segment 256 PCM frames at a time; segments of more
+            // than 16 such blocks share the walk between several workgroups)
+            const uint32_t max_rows = blocking ? c->h_summary->chain_max_rows : 0;
+            ca.remat_blocks = (max_rows + 4095) / 4096 ? (max_rows + 4095) / 4096 : 1;
+            hipLaunchKernelGGL(k_chain_rematrix, dim3(segs * ca.remat_blocks), dim3(256), 0, st, ca);
+        } else {
         // the chains longest first (k_chain_fused's workgroups take eight neighbours of that order)
         HIP_TRY(hipMemsetAsync(c->d_chain_hist, 0, CHAIN_BUCKETS * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_chain_hist, dim3((segs + 255) / 256), dim3(256), 0, st, ca);
@@ -917,6 +930,7 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         hipLaunchKernelGGL(k_chain_scatter, dim3((segs + 255) / 256), dim3(256), 0, st, ca);
         // filter + rematrix in one walk over the planes: two waves per eight chains (at most one chain per deferred segment)
         hipLaunchKernelGGL(k_chain_fused, dim3((unsigned)(((uint64_t)segs + 7) / 8)), dim3(FU_THREADS), 0, st, ca);
+        }
         HIP_TRY(hipMemsetAsync(&c->d_summary->seq_streams, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 1u, 0u);
@@ -968,6 +982,14 @@ extern "C" int dvda_mlp_hip_set_pcm_layout(dvda_mlp_hip_ctx *c, uint32_t layout)
     if (!c || layout > DVDA_PCM_WAV16)
         return DVDA_HIP_EINVAL;
     c->pcm_layout = layout;
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_set_chain_form(dvda_mlp_hip_ctx *c, uint32_t form)
+{
+    if (!c || form > 2)
+        return DVDA_HIP_EINVAL;
+    c->chain_form = form;
     return DVDA_HIP_OK;
 }
 

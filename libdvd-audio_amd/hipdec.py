@@ -49,7 +49,7 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_mlp_hip_version", "dvda_mlp_hip_selftest_huff", "dvda_mlp_hip_selftest_bits",
            "dvda_mlp_hip_bounds_violations", "dvda_mlp_hip_decode_async", "dvda_mlp_hip_reserve",
            "dvda_mlp_hip_decode_time",
-           "dvda_mlp_hip_set_lanes_per_segment",
+           "dvda_mlp_hip_set_lanes_per_segment", "dvda_mlp_hip_set_chain_form",
            "dvda_mlp_hip_set_pcm_layout", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
@@ -88,6 +88,7 @@ def lib():
         L.dvda_mlp_hip_decode_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u32)]
         L.dvda_mlp_hip_set_lanes_per_segment.argtypes = [vp, u32]
         L.dvda_mlp_hip_set_pcm_layout.argtypes = [vp, u32]
+        L.dvda_mlp_hip_set_chain_form.argtypes = [vp, u32]
         L.dvda_mlp_hip_version.restype = ctypes.c_char_p
         L.dvda_hip_open_mlpdecoder.restype = vp
         L.dvda_hip_open_mlpdecoder.argtypes = [ctypes.c_uint] * 5 + [ctypes.c_int]
@@ -126,6 +127,7 @@ def _check(rc, what):
 
 
 PCM_PLANAR, PCM_INTERLEAVED, PCM_WAV24, PCM_WAV16 = 0, 1, 2, 3      # DVDA_PCM_* of include/dvda_mlp_hip.h
+CHAIN_FORM = 0      # tests: 1 / 2 force the fused / two-pass form of the chain passes on every Context made afterwards
 
 
 class Context:
@@ -137,6 +139,8 @@ class Context:
                "dvda_mlp_hip_create")
         _check(lib().dvda_mlp_hip_set_lanes_per_segment(self._h, lanes_per_segment), "set_lanes")
         _check(lib().dvda_mlp_hip_set_pcm_layout(self._h, layout), "set_pcm_layout")
+        if CHAIN_FORM:
+            _check(lib().dvda_mlp_hip_set_chain_form(self._h, CHAIN_FORM), "set_chain_form")
         self.device = device
         self.n_streams = 0
 
