@@ -463,6 +463,31 @@ static int first_audio_packet(const uint8_t *p, unsigned *codec, unsigned *pad2,
 }
 
 /* ------------------------------------------------------------------ device helpers */
+/* DVDA_DISC_TIMING=1: where opening an MLP track spends its time, on stderr (tools/disc_bench.py; diagnostic) */
+#include <time.h>
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static int disc_timing(void)
+{
+    static int on = -1;
+    if (on < 0)
+        on = getenv("DVDA_DISC_TIMING") != NULL;
+    return on;
+}
+#define T_MARK(what)                                                             \
+    do {                                                                         \
+        if (disc_timing()) {                                                     \
+            (void)hipDeviceSynchronize();                                        \
+            const double t_ = now_ms();                                          \
+            fprintf(stderr, "  [disc] %-28s %8.2f ms\n", what, t_ - t_mark);     \
+            t_mark = t_;                                                         \
+        }                                                                        \
+    } while (0)
+
 static int dev_alloc(void **p, size_t bytes)
 {
     *p = NULL;
@@ -530,6 +555,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
     const unsigned in_track = k->s.last >= first ? k->s.last - first + 1 : 1;
     unsigned extra = 8;
     uint64_t total = 0, begin = 0, end = 0;
+    double t_mark = now_ms();
 
     for (;;) {
         /* sectors of the track plus a few behind it: the stream runs on to the next major sync */
@@ -551,6 +577,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         const unsigned got = aob_read(aobs, first, want, h_sec);
         if (got == 0)
             goto fail;
+        T_MARK("sectors read from the files");
         const size_t cap = (size_t)got * SECTOR;
         if (!dev_alloc((void **)&d_sec, cap) || !dev_alloc((void **)&d_mlp, cap + 64) ||
             !dev_alloc((void **)&d_work, dvda_pcm_hip_workspace_words(got) * sizeof(uint32_t)))
@@ -572,6 +599,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
             goto fail;
         if (hipMemcpy(h_base, d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
             goto fail;
+        T_MARK("to the device + demux");
         const int64_t s0 = find_sync_dev(d_mlp, 0, total);
         if (s0 < 0) {
             if (got < want || first + got >= aobs->total)
@@ -600,6 +628,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
     }
     if (end <= begin)
         goto fail;
+    T_MARK("major syncs at both ends");
 
     {
         const uint64_t len = end - begin;
@@ -633,6 +662,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
         }
         if (dvda_mlp_hip_stream_info(ctx, &info, 1, NULL) != DVDA_HIP_OK || info.channels == 0)
             goto fail;
+        T_MARK("context + index");
         const unsigned rate = rate_of(info.group0_rate);
         const uint64_t per_au = rate == 48000 || rate == 44100 ? 40 : rate == 96000 || rate == 88200 ? 80 : 160;
         uint64_t stride = info.mlp_frames * per_au;
@@ -666,6 +696,7 @@ static DVDA_Track_Reader *open_mlp(struct aob_set *aobs, const DVDA_Track *k)
             d_pcm = NULL;
             stride = (info.pcm_frames + 3) & ~(uint64_t)3;
         }
+        T_MARK("decode");
         if (info.status & ~(uint32_t)DVDA_ST_BENIGN)
             goto fail;                       /* the reference assert()s on such a stream */
         r = calloc(1, sizeof(*r));
@@ -923,11 +954,13 @@ unsigned long long dvda_hip_reader_wav_payload(DVDA_Track_Reader *r, const unsig
         return 0;
     if (r->d_wav) {
         /* the decode wrote the payload: one copy to the host */
+        double t_mark = now_ms();
         free(r->wav);
         r->wav = malloc(r->wav_bytes ? r->wav_bytes : 1);
         if (!r->wav || r->served != 0 ||
             hipMemcpy(r->wav, r->d_wav, r->wav_bytes, hipMemcpyDeviceToHost) != hipSuccess)
             return 0;
+        T_MARK("payload to the host");
         r->served = r->frames;
         *payload = r->wav;
         return r->wav_bytes;

@@ -6,13 +6,16 @@
 // there are (a filter wave and an output wave hand every unit over through LDS); the filter below, which does nothing
 // but the recursion, runs a lone chain at 156 ns per unit, and the rematrix pass behind it is fully parallel.  ONE
 // chained title of 512 access units: 3.7 ms through the fused kernel, 1.8 ms through these two (round 4, measured).
-// The host picks them when a batch defers at most CHAIN_SMALL_SEGS segments (mlp_hip.hip).
+// The host picks them when at most CHAIN_SMALL_STREAMS streams of the batch wait for the chain passes (mlp_hip.hip):
+// one title however long -- a disc tier track of 65 536 access units is ONE chain of 655 360 units: 0.29 s through the
+// fused kernel, 0.1 s here --, a small batch.
 #pragma once
 #include "mlp_chain.h"
 
 namespace mlp {
 
-constexpr uint32_t CHAIN_SMALL_SEGS = 4096;     // deferred segments up to which the two-pass form is used
+constexpr uint32_t CHAIN_SMALL_STREAMS = 512;   // streams with deferred segments up to which the two-pass form is used ...
+constexpr uint32_t CHAIN_SMALL_SEGS = 4096;     // ... and, where the host does not know that count (non-blocking decode), deferred segments
 
 #ifndef DVDA_CHAIN_DEPTH
 #define DVDA_CHAIN_DEPTH 8

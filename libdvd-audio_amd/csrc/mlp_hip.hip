@@ -913,7 +913,11 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
                                    dim3(DEC_THREADS), 0, st, a);
             }
         }
-        if (c->chain_form == 2 || (c->chain_form == 0 && segs <= CHAIN_SMALL_SEGS)) {
+        // (how many CHAINS there are is what decides -- a chain is serial, and the fused kernel's pace per chain is a third of
+        //  the lean filter's -- and chains are at most a few per stream: the streams that wait for these passes, counted by
+        //  k_finalize, stand in for them; the non-blocking call, which reads nothing back, goes by its reservation)
+        const bool few = blocking ? c->h_summary->waiting <= CHAIN_SMALL_STREAMS : segs <= CHAIN_SMALL_SEGS;
+        if (c->chain_form == 2 || (c->chain_form == 0 && few)) {
             // few chains (one title, a small batch): the lean two-pass form (mlp_chain_small.h)
             // filter: 16 lanes per chain (at most one chain per deferred segment)
             hipLaunchKernelGGL(k_chain_filter, dim3((unsigned)(((uint64_t)segs * 16 + 63) / 64)), dim3(64), 0, st, ca);

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--aus", type=int, default=16384)
     ap.add_argument("--tmp", default=None)
     ap.add_argument("--no-tier-b", action="store_true")
+    ap.add_argument("--devices", default="", help="passed to dvda2wav_hip: comma-separated device entries, one worker "
+                                                   "thread each (e.g. 0,0,0: three workers on one GPU)")
     ap.add_argument("--chained", action="store_true",
                     help="tracks as an encoder writes them: no raw lead-in at the restart points, the FIR history runs "
                          "through each track (the chain passes decode them)")
@@ -51,7 +53,7 @@ def main():
             samples += f * 6
         ats = disc.write_disc_titles(tmp, [tracks])
         aob = os.path.getsize(os.path.join(ats, "ATS_01_1.AOB"))
-        res = {"tracks": a.tracks, "samples": samples, "aob_bytes": aob, "chained": bool(a.chained)}
+        res = {"tracks": a.tracks, "samples": samples, "aob_bytes": aob, "chained": bool(a.chained), "devices": a.devices or "0"}
         env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "libdvd-audio_amd") + ":/opt/rocm/lib:" +
                    os.environ.get("LD_LIBRARY_PATH", ""))
         outs = {}
@@ -62,7 +64,8 @@ def main():
             os.makedirs(out)
             for rep in range(2 if name == "gpu" else 1):          # second GPU run: page cache + driver warm
                 t0 = time.time()
-                r = subprocess.run([exe, "-A", ats, "-d", out], capture_output=True, text=True, env=env)
+                cmd = [exe, "-A", ats, "-d", out] + (["--devices", a.devices] if a.devices and name == "gpu" else [])
+                r = subprocess.run(cmd, capture_output=True, text=True, env=env)
                 dt = time.time() - t0
                 assert r.returncode == 0, r.stderr[-2000:]
             res[name + "_seconds"] = round(dt, 3)
