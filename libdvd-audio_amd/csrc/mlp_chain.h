@@ -417,10 +417,15 @@ __device__ __forceinline__ void fu_use(T &v)
 {
     asm volatile("" : "+v"(v));
 }
+// (m0 is named as clobbered on purpose: the compiler keeps nothing of its own in it across the statement; clang warns
+//  about reserved registers in clobber lists whatever they are there for)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void fu_dma16(const void *src, uint32_t lds_base)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_base) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 #if defined(DVDA_EXP_STAMP)
 #define FU_STAMP(i)                                                      \
