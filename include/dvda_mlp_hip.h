@@ -354,6 +354,11 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *decoder, const u
                                            size_t len, const int32_t **planar, unsigned *channels);
 unsigned dvda_hip_mlpdecoder_status(const dvda_hip_mlpdecoder *decoder);
 size_t dvda_hip_mlpdecoder_queued_bytes(const dvda_hip_mlpdecoder *decoder);
+/* Which path the decoder is on.  0: its state lives on the device and a call decodes exactly the access units it was
+ * given (one workgroup, csrc/mlp_coop.h k_coop<false, true>; csrc/mlp_step.h) -- the usual case.  1: the stream left what
+ * that path takes (an access unit of non-standard length, src/mlp.c:719-738, or one larger than 4 KB) and every call
+ * decodes from the stream's last major sync on through the batch tier, as rounds 1-3 did for every stream. */
+int dvda_hip_mlpdecoder_path(const dvda_hip_mlpdecoder *decoder);
 
 #ifdef __cplusplus
 }

@@ -111,9 +111,13 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
     uint32_t bad[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
     bool done[2] = {false, false};              // the decode lane of that substream stops here or earlier anyway
     uint32_t S = 0;
+    uint32_t want_sync = 0;
+    const bool streaming = (sr.flags & (1u << 28)) != 0;    // SEG_STREAMING (mlp_coop.h)
     if (!(sr.flags & (SEG_DEAD | (1u << 0) | (1u << 4) | (1u << 16))) && sr.nframes &&
-        streams[sr.stream].first_seg != 0xFFFFFFFFu)
-        S = (streams[sr.stream].sync >> 24) & 0xFu;         // the stream's latched substream count (as k_decode)
+        streams[sr.stream].first_seg != 0xFFFFFFFFu) {
+        want_sync = streams[sr.stream].sync;
+        S = (want_sync >> 24) & 0xFu;                       // the stream's latched substream count (as k_decode)
+    }
     // v * x^e for e in [0, 255)
     auto shift = [&](uint32_t v, uint32_t e) { return v ? (uint32_t)s_exp[(uint32_t)s_log[v] + e] : 0u; };
     if (S == 1u || S == 2u) {
@@ -127,13 +131,23 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
             const uint32_t fsize = 2u * (H.h0 & 0xFFFu);
             const uint64_t frame_end = cur + fsize;
             uint32_t i0 = H.h4, i1 = H.h6, i2 = H.h8;           // substream info words (frames without a major sync)
-            const bool dropped = f != 0 && sr.ndrop != 0 && fsize >= 32u && H.h4 == 0xF872u && H.h6 == 0x6FBBu &&
-                                 ((H.b20 >> 4) == 1u || (H.b20 >> 4) == 2u);    // src/mlp.c:449-460, as k_decode
-            if (f == 0)
+            const bool has_sync = fsize >= 32u && H.h4 == 0xF872u && H.h6 == 0x6FBBu &&
+                                  ((H.b20 >> 4) == 1u || (H.b20 >> 4) == 2u);
+            bool dropped = f != 0 && sr.ndrop != 0 && has_sync;                 // src/mlp.c:449-460, as k_decode
+            bool sync_unit = f == 0;
+            if (streaming) {
+                // (the streaming tier's one segment: the stream's own major sync may sit on any unit, k_coop<false, true>)
+                const uint32_t pks = (H.h8 >> 12) | (((H.h8 >> 8) & 0xFu) << 4) | (((H.h8 >> 4) & 0xFu) << 8) |
+                                     ((H.h8 & 0xFu) << 12) | ((H.h10 & 0x1Fu) << 16);
+                const bool same = has_sync && ((pks ^ want_sync) & 0x00FFFFFFu) == 0;
+                sync_unit = same;
+                dropped = has_sync && !same;
+            }
+            if (sync_unit)
                 chk_info32(bytes, cur, i0, i1, i2);
             // the next unit's header leaves now (the buffer is readable 64 bytes past its end)
             H = chk_header(bytes, frame_end);
-            const uint64_t pos = cur + (f == 0 ? 32u : 4u);
+            const uint64_t pos = cur + (sync_unit ? 32u : 4u);
             cur = frame_end;
             if (dropped)
                 continue;

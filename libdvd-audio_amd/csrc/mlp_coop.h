@@ -142,6 +142,28 @@ struct CoopSub {
                                 // + the two noise coefficients
 };
 
+// What the streaming tier (mlp_stream.c: the mlp.h mirror, one call per packet) keeps ON THE DEVICE between two calls:
+// one substream's decoder state at an access-unit boundary -- reference struct substream + the filter histories
+// (src/mlp.c:103-115, 297-304) as this kernel holds them -- so that a call decodes the access units it was given
+// and nothing before them.  (Rounds 1-3 re-decoded from the last major sync on every call: 0.57 ms per packet.)
+struct CoopState {
+    uint32_t valid;
+    uint32_t sc[15];            // flags, block_size, min_ch, max_ch, max_mat_ch, noise_shift, seed, matrix_len,
+                                // bypass_mask, outch_pack, oshift_pack, qss_pack, nslots, have_restart
+    CoopSub sub;
+    int32_t h[8][8], ih[8][8];  // FIR / IIR histories of the lanes that carry a channel
+};
+struct CoopResult {
+    uint32_t status;            // DVDA_ST_* of this call's access units (both substreams)
+    uint32_t frames_out;        // access units that yielded PCM
+    uint32_t rows_written;      // PCM frames written
+    uint32_t sync_seen;         // 1 + index of the last access unit of this call that carries the stream's own major sync
+    int32_t fir[2][48];         // the FIR histories in front of that unit ([substream][slot * 8 + tap]: what
+                                // dvda_mlp_hip_segment_fir hands out for the segment before it)
+};
+constexpr uint32_t SEG_STREAMING = 1u << 28;    // SegRec.flags of the streaming tier's one segment: major syncs may sit
+                                                // on any of its access units (k_au_check, k_coop<false, true>)
+
 // PARSE = false: the fast pass for small batches (everything up to PCM).
 // PARSE = true : the chain passes' parse pass for small batches -- workgroup j takes deferred segment def_list[j] and
 //   leaves what k_decode<.., PARSE> leaves (mlp_decode.h): residuals, bypassed LSBs and noise seeds in the segment's
@@ -149,10 +171,13 @@ struct CoopSub {
 //   rematrix parameters its last block left; k_chain_filter / k_chain_rematrix take it from there.  (One lane of
 //   k_decode needs 1.6 ms for a segment of eight units whatever the batch holds: for ONE chained title that was
 //   half of the whole decode.)
-template <bool PARSE>
+// RESUME (streaming tier): one workgroup, segment 0 of a hand-made index; the decoder state comes from and goes back
+//   to CoopState; a major sync may sit on any access unit; the first block may run FIR taps (the history is here).
+template <bool PARSE, bool RESUME = false>
 __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
 {
-    if (!PARSE && !coop_takes(a))
+    static_assert(!(PARSE && RESUME), "one mode at a time");
+    if (!PARSE && !RESUME && !coop_takes(a))
         return;
     __shared__ uint32_t s_stage[COOP_STAGE_DW];
     __shared__ int32_t s_val[6][COOP_VSTRIDE];          // residuals -> filtered values, MLP channel order (channels 0..5:
@@ -237,6 +262,41 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         (&s_val[0][0])[i] = 0;
     for (uint32_t i = lane; i < (uint32_t)COOP_ROWS; i += 64u)
         s_byp[i] = 0;
+    bool resumed = false;
+    CoopState *const cst = RESUME ? a.coop_state + sub : nullptr;
+    CoopResult *const cres = RESUME ? a.coop_result : nullptr;
+    if constexpr (RESUME) {
+        if (threadIdx.x == 0) {
+            cres->status = 0;
+            cres->frames_out = cres->rows_written = cres->sync_seen = 0;
+        }
+        resumed = rfl(cst->valid) != 0;
+        if (resumed) {
+            flags = rfl(cst->sc[0]);
+            block_size = rfl(cst->sc[1]);
+            min_ch = rfl(cst->sc[2]);
+            max_ch = rfl(cst->sc[3]);
+            max_mat_ch = rfl(cst->sc[4]);
+            noise_shift = rfl(cst->sc[5]);
+            seed = rfl(cst->sc[6]);
+            matrix_len = rfl(cst->sc[7]);
+            bypass_mask = rfl(cst->sc[8]);
+            outch_pack = rfl(cst->sc[9]);
+            oshift_pack = rfl(cst->sc[10]);
+            qss_pack = rfl(cst->sc[11]);
+            nslots = rfl(cst->sc[12]);
+            have_restart = rfl(cst->sc[13]) != 0;
+            for (uint32_t i = lane; i < sizeof(CoopSub) / 4u; i += 64u)
+                reinterpret_cast<uint32_t *>(&P)[i] = reinterpret_cast<const uint32_t *>(&cst->sub)[i];
+            if (lane < 8u) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    h[j] = cst->h[lane][j];
+                    ih[j] = cst->ih[lane][j];
+                }
+            }
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (two)
         __syncthreads();
@@ -304,7 +364,36 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         // ---- major sync: the segment's first unit has one (validated by the index).  Any other unit that carries a
         //      valid one was walked through by the index because its stream parameters differ: the reference drops
         //      it, restart header and all (src/mlp.c:449-460)
-        if (f == 0) {
+        if (RESUME) {
+            // (streaming tier: the stream's own major sync starts what the batch tier calls a segment, wherever in the
+            //  call it sits; one with other parameters is a dropped unit, as below)
+            if (rd.peek32() == 0xF8726FBBu && fsize >= 32u) {
+                const uint32_t save = rd.pos;
+                rd.seek(bit0 + 8u * 8u);
+                const uint32_t b8 = rd.read(8), b9 = rd.read(8);
+                rd.read(8);
+                const uint32_t b11 = rd.read(8);
+                rd.seek(bit0 + 20u * 8u);
+                const uint32_t count = rd.read(4);
+                rd.seek(save);
+                if (count == 1u || count == 2u) {
+                    const uint32_t pks = (b8 >> 4) | ((b8 & 0xFu) << 4) | ((b9 >> 4) << 8) | ((b9 & 0xFu) << 12) | ((b11 & 0x1Fu) << 16);
+                    if (((pks ^ stream_sync) & SYNC_PARAMS) == 0) {
+                        rd.seek(save + 28u * 8u);
+                        // the histories in front of this unit: what a caller that has to decode it again starts from
+                        if (lane < 6u) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                cres->fir[sub][lane * 8u + j] = lane < nslots ? h[j] : 0;
+                        }
+                        if (is_last && lane == 0)
+                            cres->sync_seen = f + 1u;
+                    } else {
+                        dropped = true;
+                    }
+                }
+            }
+        } else if (f == 0) {
             rd.seek(rd.pos + 28u * 8u);
         } else if (rd.peek32() == 0xF8726FBBu && fsize >= 32u && sr.ndrop != 0) {
             const uint32_t save = rd.pos;
@@ -600,7 +689,12 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                                         } else {
                                             shift = iir_shift;
                                         }
-                                        if (!PARSE && fir_order && f == 0 && blocks_in_frame == 0)
+                                        if (RESUME) {
+                                            if (fir_order && !resumed && frames_out == 0 && blocks_in_frame == 0) {
+                                                ok = false;             // FIR taps on a fresh decoder: the reference reads
+                                                e1 = ST_ENVELOPE;       // out of bounds (as the sequential pass reports it)
+                                            }
+                                        } else if (!PARSE && fir_order && f == 0 && blocks_in_frame == 0)
                                             status |= ST_CHAINED;      // needs the previous segment's history
                                         P.sho[k] = hoff - huff_center(codebook, lb);
                                         P.pk[k] = codebook | (lb << 2) | (q << 7) | (shift << 11) | (iir_order << 15) |
@@ -1009,7 +1103,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             frames_out++;
         // (the segment behind this one continues its history: both go to the chain passes -- looked at after the
         //  first two units only; later the request is ignored and the segment is decoded here, which is as good)
-        const bool ask = !PARSE && !quit && f < 2u && f + 1u < sr.nframes;
+        const bool ask = !PARSE && !RESUME && !quit && f < 2u && f + 1u < sr.nframes;
         uint32_t yield = 0;
         if (ask) {
             const uint32_t y = __hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1046,6 +1140,42 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             }
             if (status)
                 atomicOr(&a.seg_status[segi], status);
+        }
+        return;
+    }
+    if constexpr (RESUME) {
+        // ---- the decoder state as the call's last access unit leaves it; what the call did
+        if (lane == 0) {
+            cst->sc[0] = flags;
+            cst->sc[1] = block_size;
+            cst->sc[2] = min_ch;
+            cst->sc[3] = max_ch;
+            cst->sc[4] = max_mat_ch;
+            cst->sc[5] = noise_shift;
+            cst->sc[6] = seed;
+            cst->sc[7] = matrix_len;
+            cst->sc[8] = bypass_mask;
+            cst->sc[9] = outch_pack;
+            cst->sc[10] = oshift_pack;
+            cst->sc[11] = qss_pack;
+            cst->sc[12] = nslots;
+            cst->sc[13] = have_restart ? 1u : 0u;
+            cst->valid = 1u;
+            if (status)
+                atomicOr(&cres->status, status);
+            if (is_last) {
+                cres->frames_out = frames_out;
+                cres->rows_written = rows_written;
+            }
+        }
+        for (uint32_t i = lane; i < sizeof(CoopSub) / 4u; i += 64u)
+            reinterpret_cast<uint32_t *>(&cst->sub)[i] = reinterpret_cast<const uint32_t *>(&P)[i];
+        if (lane < 8u) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                cst->h[lane][j] = h[j];
+                cst->ih[lane][j] = ih[j];
+            }
         }
         return;
     }

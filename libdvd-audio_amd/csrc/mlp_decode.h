@@ -260,6 +260,8 @@ struct DecodeArgs {
     WsCaps caps;                   // what the workspaces hold (consulted by the range-checked build only, mlp_bounds.h)
     uint32_t coop;                 // who decodes the batch: 0 the device decides (coop_takes), 64 always the wave-cooperative
                                    // kernel (mlp_coop.h), anything else always the lane kernels
+    struct CoopState *coop_state;  // streaming tier (k_coop<false, true>): the decoder state between calls, [2 substreams]
+    struct CoopResult *coop_result;    // ... and what the call did
 };
 
 // Which batches the wave-cooperative kernel takes (measured, tools/coop_bench.py, MI355X): one wave scans an access

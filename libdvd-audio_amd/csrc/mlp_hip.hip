@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/dvda_mlp_hip.h"
+#include "mlp_step.h"
 #include "mlp_decode.h"
 #include "mlp_chain.h"
 #include "mlp_chain_small.h"
@@ -1214,6 +1215,191 @@ extern "C" int dvda_mlp_hip_segment_fir(dvda_mlp_hip_ctx *c, uint32_t segment, i
                             (size_t)c->iir_lanes * sizeof(int32_t), sizeof(int32_t), 48,
                             hipMemcpyDeviceToHost));
     }
+    return DVDA_HIP_OK;
+}
+
+// ------------------------------------------------------------------ streaming tier: the decoder state stays on the device
+// (mlp_step.h; host side: mlp_stream.c)
+struct StepDesc {           // what the host writes in front of the packet's bytes: a one-segment index made by hand
+    SegRec seg;
+    StreamRec streams;
+    uint32_t seg_fbase[2];
+    uint32_t n_seg;
+    uint32_t state_valid;   // 0: the decoder is fresh (k_coop<false, true> looks at CoopState::valid, set from this)
+    uint64_t out_off, out_stride;
+    uint32_t cls[4];
+};
+constexpr size_t STEP_DESC_BYTES = 256;
+static_assert(sizeof(StepDesc) <= STEP_DESC_BYTES, "the descriptor fits its place");
+static_assert(sizeof(dvda_mlp_step_result) == sizeof(CoopResult), "the result record is the kernel's");
+constexpr size_t STEP_PCM_BYTES = (size_t)DVDA_STEP_MAX_UNITS * 160u * 6u * 4u;
+
+struct dvda_mlp_hip_stepper {
+    int device;
+    hipStream_t st;
+    uint8_t *d_in;          // [StepDesc | bytes + 64]: one copy up per step
+    uint8_t *d_masks;
+    uint16_t *d_parts;
+    uint32_t *d_tile_count; // [2]
+    uint32_t *d_small;      // seg_check[2] | seg_status | seg_rows | yield | seg_meta[2]
+    DecodeSummary *d_summary;
+    CoopState *d_state;     // [2]
+    uint8_t *d_out;         // [CoopResult | pcm]: one copy down per step
+    uint8_t *h_in, *h_out;  // pinned mirrors
+};
+
+__global__ void k_step_begin(CoopState *st, const StepDesc *d, uint32_t *small)
+{
+    if (threadIdx.x < 2 && !d->state_valid)
+        st[threadIdx.x].valid = 0;
+    if (threadIdx.x < 8)
+        small[threadIdx.x] = threadIdx.x < 2 ? 0xFFFFFFFFu : 0u;       // "no unit fails its check" until k_au_check says otherwise
+}
+
+extern "C" void dvda_mlp_hip_stepper_destroy(dvda_mlp_hip_stepper *s)
+{
+    if (!s)
+        return;
+    (void)hipSetDevice(s->device);
+    if (s->st)
+        (void)hipStreamSynchronize(s->st);
+    (void)hipFree(s->d_in);
+    (void)hipFree(s->d_masks);
+    (void)hipFree(s->d_parts);
+    (void)hipFree(s->d_tile_count);
+    (void)hipFree(s->d_small);
+    (void)hipFree(s->d_summary);
+    (void)hipFree(s->d_state);
+    (void)hipFree(s->d_out);
+    (void)hipHostFree(s->h_in);
+    (void)hipHostFree(s->h_out);
+    if (s->st)
+        (void)hipStreamDestroy(s->st);
+    free(s);
+}
+
+extern "C" int dvda_mlp_hip_stepper_create(dvda_mlp_hip_stepper **out, int device)
+{
+    if (!out)
+        return DVDA_HIP_EINVAL;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return DVDA_HIP_ENODEV;
+    dvda_mlp_hip_stepper *s = (dvda_mlp_hip_stepper *)calloc(1, sizeof(*s));
+    if (!s)
+        return DVDA_HIP_ENOMEM;
+    s->device = device;
+    const size_t in_bytes = STEP_DESC_BYTES + DVDA_STEP_MAX_BYTES + 128;
+    const size_t chunks = (DVDA_STEP_MAX_BYTES + 128) / 16 + 8;
+    const size_t out_bytes = sizeof(CoopResult) + STEP_PCM_BYTES;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&s->d_in, in_bytes) == hipSuccess && hipMalloc((void **)&s->d_masks, chunks) == hipSuccess &&
+              hipMalloc((void **)&s->d_parts, chunks * 2) == hipSuccess &&
+              hipMalloc((void **)&s->d_tile_count, 4 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&s->d_small, 16 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&s->d_summary, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary)) == hipSuccess &&
+              hipMalloc((void **)&s->d_state, 2 * sizeof(CoopState)) == hipSuccess &&
+              hipMalloc((void **)&s->d_out, out_bytes) == hipSuccess &&
+              hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&s->h_out, out_bytes, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(s->d_in, 0, in_bytes) == hipSuccess && hipMemset(s->d_state, 0, 2 * sizeof(CoopState)) == hipSuccess &&
+         hipMemset(s->d_out, 0, out_bytes) == hipSuccess && hipMemset(s->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary)) == hipSuccess &&
+         hipMemset(s->d_small, 0, 16 * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) {
+        dvda_mlp_hip_stepper_destroy(s);
+        return DVDA_HIP_ENODEV;         // no GPU (or no memory on it): there is no CPU decoder here
+    }
+    memset(s->h_in, 0, in_bytes);
+    *out = s;
+    return DVDA_HIP_OK;
+}
+
+extern "C" int dvda_mlp_hip_stepper_step(dvda_mlp_hip_stepper *s, const uint8_t *bytes, size_t len, uint32_t n_units,
+                                         uint32_t packed_sync, int fresh, const dvda_mlp_step_result **res,
+                                         const int32_t **pcm, uint64_t *stride, unsigned *channels)
+{
+    if (!s || !bytes || !res || !pcm || !stride || len == 0 || n_units == 0)
+        return DVDA_HIP_EINVAL;
+    if (len > DVDA_STEP_MAX_BYTES || n_units > DVDA_STEP_MAX_UNITS)
+        return DVDA_HIP_ECAPACITY;
+    const uint32_t rpa = rows_per_au((packed_sync >> 8) & 0xFu);
+    const uint32_t nch = channel_count((packed_sync >> 16) & 0x1Fu);
+    if (rpa == 0 || nch == 0)
+        return DVDA_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t rows_cap = (uint64_t)n_units * rpa;
+    // ---- the hand-made index of one segment + the bytes, up in one copy
+    StepDesc *d = reinterpret_cast<StepDesc *>(s->h_in);
+    memset(d, 0, sizeof(*d));
+    d->seg.off = 0;
+    d->seg.end = len;
+    d->seg.stream = 0;
+    d->seg.nframes = n_units;
+    d->seg.flags = SEG_STREAMING;
+    d->seg.sync = packed_sync;
+    d->seg.ndrop = 0;
+    d->seg.prev = 0xFFFFFFFFu;
+    d->streams.first_seg = 0;
+    d->streams.n_seg = 1;
+    d->streams.sync = packed_sync;
+    d->seg_fbase[0] = 0;
+    d->seg_fbase[1] = n_units;
+    d->n_seg = 1;
+    d->state_valid = fresh ? 0u : 1u;
+    d->out_off = 0;
+    d->out_stride = rows_cap;
+    d->cls[0] = d->cls[1] = 1;
+    uint8_t *hb = s->h_in + STEP_DESC_BYTES;
+    memcpy(hb, bytes, len);
+    memset(hb + len, 0, 128);
+    const size_t up = STEP_DESC_BYTES + ((len + 15) & ~(size_t)15) + 64;
+    HIP_TRY(hipMemcpyAsync(s->d_in, s->h_in, up, hipMemcpyHostToDevice, s->st));
+    const StepDesc *dd = reinterpret_cast<const StepDesc *>(s->d_in);
+    const uint8_t *d_bytes = s->d_in + STEP_DESC_BYTES;
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(64), 0, s->st, s->d_state, dd, s->d_small);
+    // ---- parity / CRC-8: per-chunk partial sums, joined per substream (mlp_check.h)
+    hipLaunchKernelGGL(k_sync_mask, dim3(1), dim3(IDX_THREADS), 0, s->st, d_bytes, (uint64_t)len, s->d_masks,
+                       s->d_tile_count, s->d_parts);
+    hipLaunchKernelGGL(k_au_check, dim3(1), dim3(CHK_THREADS), 0, s->st, d_bytes, s->d_parts, &dd->seg, &dd->n_seg, 1u,
+                       &dd->streams, s->d_small);
+    // ---- the units themselves: one workgroup, state in, state out
+    DecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bytes = d_bytes;
+    a.total_bytes = len;
+    a.seg = &dd->seg;
+    a.seg_fbase = dd->seg_fbase;
+    a.n_seg_ptr = &dd->n_seg;
+    a.max_seg = 1;
+    a.streams = const_cast<StreamRec *>(&dd->streams);
+    a.pcm = reinterpret_cast<int32_t *>(s->d_out + sizeof(CoopResult));
+    a.out_off = &dd->out_off;
+    a.out_stride = &dd->out_stride;
+    a.seg_status = s->d_small + 2;
+    a.seg_rows = s->d_small + 3;
+    a.yield_req = s->d_small + 4;
+    a.seg_meta = s->d_small + 5;
+    a.seg_check = s->d_small;
+    a.total_lanes = 2;
+    a.summary = s->d_summary;
+    a.cls = dd->cls;
+    a.coop = 64;
+    a.caps.max_seg = 1;
+    a.caps.max_streams = 1;
+    a.caps.lanes = 2;
+    a.coop_state = s->d_state;
+    a.coop_result = reinterpret_cast<CoopResult *>(s->d_out);
+    hipLaunchKernelGGL((k_coop<false, true>), dim3(1), dim3(COOP_THREADS), 0, s->st, a);
+    // ---- result record + PCM down in one copy
+    const size_t down = sizeof(CoopResult) + (size_t)rows_cap * nch * sizeof(int32_t);
+    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, down, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));
+    *res = reinterpret_cast<const dvda_mlp_step_result *>(s->h_out);
+    *pcm = reinterpret_cast<const int32_t *>(s->h_out + sizeof(CoopResult));
+    *stride = rows_cap;
+    if (channels)
+        *channels = nch;
     return DVDA_HIP_OK;
 }
 

@@ -13,7 +13,15 @@
  *     stream's initial history on the next call;
  *   - PCM frames of the retained segment that were already returned are skipped.
  *
- * Every call is one small GPU batch: this is the compatibility tier, not the fast path.
+ * Round 4: the decoder state itself stays on the device between calls (mlp_step.h; k_coop<false, true>, mlp_coop.h):
+ * a call sends its packet's whole access units up, ONE workgroup decodes exactly those from the state the call
+ * before left, PCM and a small result record come down -- nothing in front of the packet is decoded again, no
+ * index is built.  The queue discipline above stays (bytes from the last major sync on, the FIR history in front
+ * of it, frames already returned): a stream the stepping kernel does not take -- an access unit of non-standard
+ * length, or one larger than its stage -- falls back, for good, to the batch-tier path that was all of this file
+ * until round 3 and decodes from those three things.
+ *
+ * Every call is one small GPU job: this is the compatibility tier, not the fast path.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -22,11 +30,15 @@
 #include <string.h>
 
 #include "../../include/dvda_mlp_hip.h"
+#include "mlp_step.h"
 
 struct dvda_hip_mlpdecoder {
     int device;
     unsigned params[5];          /* as given at open (the reference stores and ignores them too) */
-    dvda_mlp_hip_ctx *ctx;
+    dvda_mlp_hip_stepper *step;  /* the decoder state on the device + the one-workgroup decode of a packet's units */
+    int stepped;                 /* a step has run: the device holds state */
+    int slow;                    /* the stream left what the stepping kernel takes: batch-tier path from here on */
+    dvda_mlp_hip_ctx *ctx;       /* batch-tier path (made when first needed) */
     uint32_t ctx_segments;
     /* byte queue: starts at a major-sync access unit once one has been seen */
     uint8_t *q;
@@ -79,7 +91,7 @@ dvda_hip_mlpdecoder *dvda_hip_open_mlpdecoder(unsigned g0_bps, unsigned g1_bps, 
     d->params[3] = g1_rate;
     d->params[4] = channel_assignment;
     d->ctx_segments = 4096;
-    if (dvda_mlp_hip_create(&d->ctx, device, 1, d->ctx_segments) != DVDA_HIP_OK) {
+    if (dvda_mlp_hip_stepper_create(&d->step, device) != DVDA_HIP_OK) {
         free(d);
         return NULL;                    /* no GPU: fail loudly, there is no CPU decoder here */
     }
@@ -96,7 +108,9 @@ void dvda_hip_close_mlpdecoder(dvda_hip_mlpdecoder *d)
     if (!d)
         return;
     (void)hipSetDevice(d->device);
-    dvda_mlp_hip_destroy(d->ctx);
+    dvda_mlp_hip_stepper_destroy(d->step);
+    if (d->ctx)
+        dvda_mlp_hip_destroy(d->ctx);
     (void)hipFree(d->d_bytes);
     (void)hipFree(d->d_meta);
     (void)hipFree(d->d_pcm);
@@ -108,6 +122,7 @@ void dvda_hip_close_mlpdecoder(dvda_hip_mlpdecoder *d)
 
 unsigned dvda_hip_mlpdecoder_status(const dvda_hip_mlpdecoder *d) { return d ? d->status : ~0u; }
 size_t dvda_hip_mlpdecoder_queued_bytes(const dvda_hip_mlpdecoder *d) { return d ? d->qlen - d->decoded_end : 0; }
+int dvda_hip_mlpdecoder_path(const dvda_hip_mlpdecoder *d) { return d ? d->slow : -1; }
 
 static int grow_dev(void **p, size_t *cap, size_t need)
 {
@@ -193,8 +208,116 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
     if (complete_end <= d->decoded_end)
         return 0;                                   /* nothing newly decodable: bytes stay queued */
 
+    /* ---- the new access units, from the state the call before left on the device */
+    if (!d->slow) {
+        const uint8_t *sp = d->sync_params;
+        const uint32_t packed = (uint32_t)(sp[0] >> 4) | ((uint32_t)(sp[0] & 0x0F) << 4) | ((uint32_t)(sp[1] >> 4) << 8) |
+                                ((uint32_t)(sp[1] & 0x0F) << 12) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+        const unsigned rpa = rows_per_au(sp[1] >> 4);
+        size_t at = d->decoded_end, units_all = 0, rows_cap_all, got = 0;
+        int leave = 0, have_new_fir = 0, stepped = d->stepped, n_steps = 0;
+        int32_t new_fir[2 * 48];
+        const int32_t *one_pcm = NULL;
+        uint64_t one_stride = 0;
+        unsigned nch = 0;
+        for (pos = at; pos < complete_end; pos += 2 * ((((size_t)d->q[pos] & 0x0F) << 8) | d->q[pos + 1]))
+            units_all++;
+        rows_cap_all = units_all * (rpa ? rpa : 1);
+        /* (a packet of more units than one step takes -- not what a disc reader sends -- is put together here) */
+        if ((units_all > DVDA_STEP_MAX_UNITS || complete_end - at > DVDA_STEP_MAX_BYTES) && rows_cap_all * 6 * 4 > d->h_pcm_cap) {
+            free(d->h_pcm);
+            d->h_pcm_cap = rows_cap_all * 6 * 4 * 2 + 4096;
+            d->h_pcm = (int32_t *)malloc(d->h_pcm_cap);
+            if (!d->h_pcm) {
+                d->h_pcm_cap = 0;
+                return 0;
+            }
+        }
+        while (at < complete_end && !leave) {
+            size_t end = at, units = 0;
+            const dvda_mlp_step_result *res = NULL;
+            const int32_t *pcm = NULL;
+            uint64_t stride = 0;
+            while (end < complete_end && units < DVDA_STEP_MAX_UNITS) {
+                const size_t size = 2 * ((((size_t)d->q[end] & 0x0F) << 8) | d->q[end + 1]);
+                if (end + size - at > DVDA_STEP_MAX_BYTES)
+                    break;
+                end += size;
+                units++;
+            }
+            if (units == 0 || rpa == 0 ||
+                dvda_mlp_hip_stepper_step(d->step, d->q + at, end - at, (uint32_t)units, packed, !stepped, &res, &pcm, &stride,
+                                          &nch) != DVDA_HIP_OK) {
+                leave = 1;              /* (a rate code outside the table, ...: the batch tier reports it) */
+                break;
+            }
+            stepped = 1;
+            n_steps++;
+            if (res->status & (DVDA_ST_TIMING | DVDA_ST_SEQ)) {
+                leave = 1;              /* not what the stepping kernel takes: the batch tier, from the last major sync */
+                break;
+            }
+            if (res->status & ~(unsigned)DVDA_ST_BENIGN) {
+                d->stepped = 1;
+                d->status |= res->status;           /* the reference would have assert()ed */
+                return 0;
+            }
+            if (res->sync_seen) {
+                memcpy(new_fir, res->fir, sizeof(new_fir));
+                have_new_fir = 1;
+            }
+            if (n_steps == 1 && end == complete_end) {
+                one_pcm = pcm;                      /* the usual case: one step, its pinned buffer is the answer */
+                one_stride = stride;
+            } else {
+                if (rows_cap_all * nch * 4 > d->h_pcm_cap)
+                    return 0;                       /* (sized above for six channels: cannot happen) */
+                for (c = 0; c < nch; c++)
+                    memcpy(d->h_pcm + (size_t)c * rows_cap_all + got, pcm + (size_t)c * stride, (size_t)res->rows_written * 4);
+            }
+            got += res->rows_written;
+            at = end;
+        }
+        d->stepped = stepped;
+        if (!leave) {
+            for (c = 0; c < nch; c++)
+                if (planar)
+                    planar[c] = one_pcm ? one_pcm + (size_t)c * one_stride : d->h_pcm + (size_t)c * rows_cap_all;
+            if (channels)
+                *channels = nch;
+            /* ---- keep what a fall-back needs: bytes from the last major sync on, the FIR history in front of it, how many
+             *      of its frames have been handed out (the batch-tier path's own invariants, below) */
+            if (n_sync >= 2) {
+                uint64_t rows_after = 0;
+                for (pos = last_sync; pos < complete_end;) {
+                    const size_t size = 2 * ((((size_t)d->q[pos] & 0x0F) << 8) | d->q[pos + 1]);
+                    const int foreign = sync_at(d->q, pos, size) &&
+                                        (d->q[pos + 8] != sp[0] || d->q[pos + 9] != sp[1] || (d->q[pos + 11] & 0x1F) != sp[2]);
+                    if (!foreign)
+                        rows_after += rpa;
+                    pos += size;
+                }
+                if (have_new_fir) {
+                    memcpy(d->fir, new_fir, sizeof(d->fir));
+                    d->have_fir = 1;
+                }
+                d->rows_before = rows_after;
+                memmove(d->q, d->q + last_sync, d->qlen - last_sync);
+                d->qlen -= last_sync;
+                d->decoded_end = complete_end - last_sync;
+            } else {
+                d->rows_before += got;
+                d->decoded_end = complete_end;
+            }
+            return (unsigned)got;
+        }
+        d->slow = 1;
+    }
+
     /* ---- one small batch on the GPU over q[0, complete_end) */
     if (hipSetDevice(d->device) != hipSuccess)
+        return 0;
+    if (!d->ctx && dvda_mlp_hip_create(&d->ctx, d->device, 1, d->ctx_segments) != DVDA_HIP_OK)
         return 0;
     if (n_sync + 1 > d->ctx_segments) {
         dvda_mlp_hip_destroy(d->ctx);

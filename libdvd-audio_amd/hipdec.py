@@ -53,7 +53,7 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_mlp_hip_set_pcm_layout", "dvda_mlp_hip_segment_info",
            "dvda_mlp_hip_segment_fir", "dvda_mlp_hip_set_initial_fir",
            "dvda_hip_open_mlpdecoder", "dvda_hip_close_mlpdecoder", "dvda_hip_mlpdecoder_decode_packet",
-           "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes",
+           "dvda_hip_mlpdecoder_status", "dvda_hip_mlpdecoder_queued_bytes", "dvda_hip_mlpdecoder_path",
            "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result",
            "dvda_mlp_hip_demux_sectors", "dvda_mlp_hip_pack_wav",
            "dvda_mlp_hip_shard", "dvda_mlp_hip_create_multi", "dvda_mlp_hip_destroy_multi",
@@ -102,6 +102,7 @@ def lib():
         L.dvda_hip_mlpdecoder_status.argtypes = [vp]
         L.dvda_hip_mlpdecoder_queued_bytes.restype = ctypes.c_size_t
         L.dvda_hip_mlpdecoder_queued_bytes.argtypes = [vp]
+        L.dvda_hip_mlpdecoder_path.argtypes = [vp]
         L.dvda_pcm_hip_workspace_words.restype = ctypes.c_size_t
         L.dvda_pcm_hip_workspace_words.argtypes = [u32]
         L.dvda_pcm_hip_decode_sectors.argtypes = [vp, u32, ctypes.c_uint, ctypes.c_uint, vp, u64, vp, vp]
@@ -428,6 +429,11 @@ class MLPDecoder:
     @property
     def queued_bytes(self):
         return int(lib().dvda_hip_mlpdecoder_queued_bytes(self._h))
+
+    @property
+    def path(self):
+        """0: decoder state on the device, a call decodes its own access units; 1: batch-tier path (dvda_hip_mlpdecoder_path)"""
+        return int(lib().dvda_hip_mlpdecoder_path(self._h))
 
     def close(self):
         if self._h:

@@ -173,6 +173,7 @@ def test_streaming_tier_mirrors_mlp_h(pkg, oracle, feature, chunk):
             got_n = dec.decode_packet(piece, samples)
             assert dec.status & ~hip.ST_BENIGN == 0, hex(dec.status)
             assert got_n == want_n, "packet at %d: %d vs %d" % (off, got_n, want_n)
+        path = dec.path
     finally:
         ol.mlp_oracle_close(od)
         dec.close()
@@ -180,6 +181,41 @@ def test_streaming_tier_mirrors_mlp_h(pkg, oracle, feature, chunk):
     assert st == 0
     got = np.asarray(samples, np.int32)
     assert got.shape == want.shape and np.array_equal(got, want)
+    # standard streams stay on the path that keeps the decoder state on the device (a call decodes its own units only)
+    if feature != "all":
+        assert path == 0
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_streaming_tier_state_on_the_device_and_its_fall_back(pkg, oracle, S):
+    """Tier B keeps the decoder state on the device (k_coop<false, true>): IIR taps, six matrices, parameter and matrix
+    changes inside a unit, restarts inside a unit, later major syncs with other parameters all stay on that path.  An
+    access unit of non-standard length sends the stream to the batch-tier path for good -- same PCM either way."""
+    syn, hip = pkg.synth, pkg.hipdec
+    SF = syn.SF
+    fast = SF["CHAINED"] | SF["FIRRAND"] | SF["IIR"] | SF["PARAMBLOCKS"] | SF["MATRIXRAND"] | SF["MIDMATRIX"] | \
+        SF["QSS"] | SF["OUTSHIFT"] | SF["VARBLOCK"] | SF["MIXBOOKS"] | SF["MIDRESTART"]
+    for feats, want_path in ((fast, 0), (fast | SF["VARROWS"], 1)):
+        for seed in range(4):
+            cfg = syn.make_cfg(assignment=12 if S == 2 or seed % 2 == 0 else 1, rate_code=seed % 3, n_substreams=S, n_aus=36,
+                               profile=1, features=feats, restart_interval=[4, 3, 8, 5][seed])
+            data, frames = syn.stream(cfg, 4100 + seed)
+            nch = syn.channels(cfg.assignment)
+            want, r, st = oracle.decode(data, nch, frames)
+            assert st == 0
+            dec = hip.MLPDecoder(cfg.bps_code, cfg.bps_code, cfg.rate_code, cfg.rate_code, cfg.assignment)
+            samples = [[] for _ in range(nch)]
+            try:
+                for off in range(0, len(data), 2011):
+                    dec.decode_packet(np.ascontiguousarray(data[off:off + 2011]), samples)
+                    assert dec.status & ~hip.ST_BENIGN == 0, hex(dec.status)
+                path = dec.path
+            finally:
+                dec.close()
+            got = np.asarray(samples, np.int32)
+            assert got.shape == want.shape and np.array_equal(got, want), (S, seed, want_path)
+            if want_path == 0:
+                assert path == 0, (S, seed)
 
 
 def test_edge_cases_truncated_ragged_and_single_unit(pkg, oracle):
