@@ -270,7 +270,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             cres->status = 0;
             cres->frames_out = cres->rows_written = cres->sync_seen = 0;
         }
-        resumed = rfl(cst->valid) != 0;
+        resumed = !a.coop_fresh && rfl(cst->valid) != 0;
         if (resumed) {
             flags = rfl(cst->sc[0]);
             block_size = rfl(cst->sc[1]);

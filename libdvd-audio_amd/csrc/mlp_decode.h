@@ -262,6 +262,7 @@ struct DecodeArgs {
                                    // kernel (mlp_coop.h), anything else always the lane kernels
     struct CoopState *coop_state;  // streaming tier (k_coop<false, true>): the decoder state between calls, [2 substreams]
     struct CoopResult *coop_result;    // ... and what the call did
+    uint32_t coop_fresh;           // ... != 0: a decoder's first call (no state yet)
 };
 
 // Which batches the wave-cooperative kernel takes (measured, tools/coop_bench.py, MI355X): one wave scans an access

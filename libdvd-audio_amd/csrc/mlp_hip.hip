@@ -1225,7 +1225,7 @@ struct StepDesc {           // what the host writes in front of the packet's byt
     StreamRec streams;
     uint32_t seg_fbase[2];
     uint32_t n_seg;
-    uint32_t state_valid;   // 0: the decoder is fresh (k_coop<false, true> looks at CoopState::valid, set from this)
+    uint32_t state_valid;   // (informational: whether the decoder had state; the kernel is told by DecodeArgs::coop_fresh)
     uint64_t out_off, out_stride;
     uint32_t cls[4];
 };
@@ -1237,23 +1237,44 @@ constexpr size_t STEP_PCM_BYTES = (size_t)DVDA_STEP_MAX_UNITS * 160u * 6u * 4u;
 struct dvda_mlp_hip_stepper {
     int device;
     hipStream_t st;
-    uint8_t *d_in;          // [StepDesc | bytes + 64]: one copy up per step
+    uint8_t *d_in;          // [StepDesc | bytes + 64]: the device's view of h_in (pinned host memory: the kernels read the
+                            // packet where the host put it -- 2 KB over PCIe costs less than a copy's launch)
     uint8_t *d_masks;
     uint16_t *d_parts;
     uint32_t *d_tile_count; // [2]
     uint32_t *d_small;      // seg_check[2] | seg_status | seg_rows | yield | seg_meta[2]
     DecodeSummary *d_summary;
     CoopState *d_state;     // [2]
-    uint8_t *d_out;         // [CoopResult | pcm]: one copy down per step
-    uint8_t *h_in, *h_out;  // pinned mirrors
+    uint8_t *d_out;         // [CoopResult | pcm]: the device's view of h_out (the PCM is written where the host reads it)
+    uint8_t *h_in, *h_out;  // pinned, mapped
 };
 
-__global__ void k_step_begin(CoopState *st, const StepDesc *d, uint32_t *small)
+// parity / CRC-8 of the step's access units by ONE workgroup: the per-chunk partial sums (k_sync_mask's, mlp_index.h),
+// then the substreams' checks from them (k_au_check's, mlp_check.h) -- two launches of the batch tier, here one
+__global__ __launch_bounds__(IDX_THREADS) void k_step_check(const uint8_t *__restrict__ bytes, uint32_t total_bytes,
+                                                            uint16_t *__restrict__ parts, const StepDesc *__restrict__ d,
+                                                            uint32_t *__restrict__ seg_check)
 {
-    if (threadIdx.x < 2 && !d->state_valid)
-        st[threadIdx.x].valid = 0;
-    if (threadIdx.x < 8)
-        small[threadIdx.x] = threadIdx.x < 2 ? 0xFFFFFFFFu : 0u;       // "no unit fails its check" until k_au_check says otherwise
+    __shared__ __attribute__((aligned(16))) uint8_t s_slice[16 * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_log[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_exp[512];
+    for (int i = threadIdx.x; i < 16 * 256 / 16; i += IDX_THREADS)
+        reinterpret_cast<uint4 *>(s_slice)[i] = reinterpret_cast<const uint4 *>(d_chk.slice)[i];
+    for (int i = threadIdx.x; i < 256 / 16; i += IDX_THREADS)
+        reinterpret_cast<uint4 *>(s_log)[i] = reinterpret_cast<const uint4 *>(d_chk.log)[i];
+    for (int i = threadIdx.x; i < 512 / 16; i += IDX_THREADS)
+        reinterpret_cast<uint4 *>(s_exp)[i] = reinterpret_cast<const uint4 *>(d_chk.exp)[i];
+    __syncthreads();
+    const uint32_t n_chunks = (total_bytes + 15u) >> 4;
+    for (uint32_t chunk = threadIdx.x; chunk < n_chunks; chunk += IDX_THREADS) {
+        uint32_t part;
+        (void)mask_chunk(bytes, total_bytes, chunk, s_slice, part);
+        parts[chunk] = (uint16_t)part;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)CHK_GROUP)
+        au_check_group(0, threadIdx.x, bytes, parts, &d->seg, &d->streams, seg_check, s_slice, s_log, s_exp);
 }
 
 extern "C" void dvda_mlp_hip_stepper_destroy(dvda_mlp_hip_stepper *s)
@@ -1263,14 +1284,12 @@ extern "C" void dvda_mlp_hip_stepper_destroy(dvda_mlp_hip_stepper *s)
     (void)hipSetDevice(s->device);
     if (s->st)
         (void)hipStreamSynchronize(s->st);
-    (void)hipFree(s->d_in);
     (void)hipFree(s->d_masks);
     (void)hipFree(s->d_parts);
     (void)hipFree(s->d_tile_count);
     (void)hipFree(s->d_small);
     (void)hipFree(s->d_summary);
     (void)hipFree(s->d_state);
-    (void)hipFree(s->d_out);
     (void)hipHostFree(s->h_in);
     (void)hipHostFree(s->h_out);
     if (s->st)
@@ -1294,23 +1313,25 @@ extern "C" int dvda_mlp_hip_stepper_create(dvda_mlp_hip_stepper **out, int devic
     const size_t chunks = (DVDA_STEP_MAX_BYTES + 128) / 16 + 8;
     const size_t out_bytes = sizeof(CoopResult) + STEP_PCM_BYTES;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void **)&s->d_in, in_bytes) == hipSuccess && hipMalloc((void **)&s->d_masks, chunks) == hipSuccess &&
+              hipMalloc((void **)&s->d_masks, chunks) == hipSuccess &&
               hipMalloc((void **)&s->d_parts, chunks * 2) == hipSuccess &&
               hipMalloc((void **)&s->d_tile_count, 4 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&s->d_small, 16 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&s->d_summary, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary)) == hipSuccess &&
               hipMalloc((void **)&s->d_state, 2 * sizeof(CoopState)) == hipSuccess &&
-              hipMalloc((void **)&s->d_out, out_bytes) == hipSuccess &&
-              hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&s->h_out, out_bytes, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMemset(s->d_in, 0, in_bytes) == hipSuccess && hipMemset(s->d_state, 0, 2 * sizeof(CoopState)) == hipSuccess &&
-         hipMemset(s->d_out, 0, out_bytes) == hipSuccess && hipMemset(s->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary)) == hipSuccess &&
+              hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocMapped) == hipSuccess &&
+              hipHostMalloc((void **)&s->h_out, out_bytes, hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&s->d_in, s->h_in, 0) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&s->d_out, s->h_out, 0) == hipSuccess;
+    ok = ok && hipMemset(s->d_state, 0, 2 * sizeof(CoopState)) == hipSuccess &&
+         hipMemset(s->d_summary, 0, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary)) == hipSuccess &&
          hipMemset(s->d_small, 0, 16 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         dvda_mlp_hip_stepper_destroy(s);
         return DVDA_HIP_ENODEV;         // no GPU (or no memory on it): there is no CPU decoder here
     }
     memset(s->h_in, 0, in_bytes);
+    memset(s->h_out, 0, out_bytes);
     *out = s;
     return DVDA_HIP_OK;
 }
@@ -1353,16 +1374,10 @@ extern "C" int dvda_mlp_hip_stepper_step(dvda_mlp_hip_stepper *s, const uint8_t 
     uint8_t *hb = s->h_in + STEP_DESC_BYTES;
     memcpy(hb, bytes, len);
     memset(hb + len, 0, 128);
-    const size_t up = STEP_DESC_BYTES + ((len + 15) & ~(size_t)15) + 64;
-    HIP_TRY(hipMemcpyAsync(s->d_in, s->h_in, up, hipMemcpyHostToDevice, s->st));
     const StepDesc *dd = reinterpret_cast<const StepDesc *>(s->d_in);
     const uint8_t *d_bytes = s->d_in + STEP_DESC_BYTES;
-    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(64), 0, s->st, s->d_state, dd, s->d_small);
     // ---- parity / CRC-8: per-chunk partial sums, joined per substream (mlp_check.h)
-    hipLaunchKernelGGL(k_sync_mask, dim3(1), dim3(IDX_THREADS), 0, s->st, d_bytes, (uint64_t)len, s->d_masks,
-                       s->d_tile_count, s->d_parts);
-    hipLaunchKernelGGL(k_au_check, dim3(1), dim3(CHK_THREADS), 0, s->st, d_bytes, s->d_parts, &dd->seg, &dd->n_seg, 1u,
-                       &dd->streams, s->d_small);
+    hipLaunchKernelGGL(k_step_check, dim3(1), dim3(IDX_THREADS), 0, s->st, d_bytes, (uint32_t)len, s->d_parts, dd, s->d_small);
     // ---- the units themselves: one workgroup, state in, state out
     DecodeArgs a;
     memset(&a, 0, sizeof(a));
@@ -1390,11 +1405,9 @@ extern "C" int dvda_mlp_hip_stepper_step(dvda_mlp_hip_stepper *s, const uint8_t 
     a.caps.lanes = 2;
     a.coop_state = s->d_state;
     a.coop_result = reinterpret_cast<CoopResult *>(s->d_out);
+    a.coop_fresh = fresh ? 1u : 0u;
     hipLaunchKernelGGL((k_coop<false, true>), dim3(1), dim3(COOP_THREADS), 0, s->st, a);
-    // ---- result record + PCM down in one copy
-    const size_t down = sizeof(CoopResult) + (size_t)rows_cap * nch * sizeof(int32_t);
-    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, down, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(hipStreamSynchronize(s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));       // (the kernel's stores to host memory are there when it has ended)
     *res = reinterpret_cast<const dvda_mlp_step_result *>(s->h_out);
     *pcm = reinterpret_cast<const int32_t *>(s->h_out + sizeof(CoopResult));
     *stride = rows_cap;
