@@ -400,6 +400,53 @@ def gen_mixed(syn, specs, seed0):
 
 
 # ----------------------------------------------------------------------------- sub-records (N = 1)
+def streaming_tier(pkg, oracle_mod=None):
+    """Tier B, the mlp.h mirror (dvda_hip_mlpdecoder_decode_packet): one 6-ch / 96 kHz title of 1 024 access units fed
+    in PES-payload sized packets (2 011 bytes), the C entry point called directly; the PCM of every call collected and
+    compared with the oracle's for the whole title.  Never `value`: the contract is a call per packet."""
+    import ctypes
+    syn, hip = pkg.synth, pkg.hipdec
+    out = {}
+    for name, extra in (("recipe", {}), ("chained", dict(profile=1, features=syn.SF["CHAINED"]))):
+        cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=1024, **extra)
+        b, frames = syn.stream(cfg, 5)
+        L = hip.lib()
+        planar = (ctypes.POINTER(ctypes.c_int32) * 6)()
+        nch = ctypes.c_uint()
+        pieces = [np.ascontiguousarray(b[o:o + 2011]) for o in range(0, len(b), 2011)]
+        best = None
+        for rep in range(3):
+            dec = hip.MLPDecoder(2, 2, 1, 1, 12)
+            chans = [[] for _ in range(6)]
+            got = 0
+            keep = rep == 0
+            t0 = time.perf_counter()
+            for p in pieces:
+                n = L.dvda_hip_mlpdecoder_decode_packet(dec._h, p.ctypes.data, len(p), planar, ctypes.byref(nch))
+                if keep and n:
+                    for c in range(6):
+                        chans[c].append(np.ctypeslib.as_array(planar[c], shape=(n,)).copy())
+                got += n
+            dt = time.perf_counter() - t0
+            path, status = dec.path, dec.status
+            dec.close()
+            if keep:
+                pcm = np.stack([np.concatenate(c) for c in chans]) if got else np.zeros((6, 0), np.int32)
+            if got != frames or (status & ~hip.ST_BENIGN):
+                raise SystemExit("sub-record streaming_tier: %d of %d PCM frames, status %#x" % (got, frames, status))
+            best = dt if best is None or dt < best else best
+        ok = None
+        if oracle_mod is not None:
+            want, r, st = oracle_mod.decode(b, 6, frames)
+            ok = bool(st == 0 and want.shape == pcm.shape and np.array_equal(want, pcm))
+            if not ok:
+                raise SystemExit("sub-record streaming_tier: PCM differs from the oracle's")
+        out[name] = {"value": round(got * 6 / best / 1e6, 2), "unit": "Msamples/s", "ms_per_call": round(best / len(pieces) * 1e3, 4),
+                     "calls": len(pieces), "packet_bytes": 2011, "path": "decoder state on the device" if path == 0 else "batch tier",
+                     "bit_exact": ok}
+    return out
+
+
 def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     """Other shapes of the same path, each: Msamples/s over `steps` back-to-back steps, k_decode ms,
     a bit-exact sample check against the oracle.  The headline stays the main record."""
@@ -1128,6 +1175,8 @@ def main():
             out["sub"]["host_to_host_wav24"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
                                                             max(3, sub_steps // 4), wav24=True)
             sys.stderr.write("bench: host_to_host records %.1f s\n" % (time.perf_counter() - t_h))
+            from tests import oracle_lib as _ol
+            out["sub"]["streaming_tier"] = streaming_tier(pkg, _ol.Oracle())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
