@@ -186,6 +186,34 @@ def test_streaming_tier_mirrors_mlp_h(pkg, oracle, feature, chunk):
         assert path == 0
 
 
+def test_streaming_tier_takes_packets_of_any_size(pkg, oracle):
+    """A caller may hand decode_packet far more than a PES payload: more access units than one step of the stepping
+    kernel takes (48 units / 48 KB) are decoded in several steps and returned as one run per channel; a packet that
+    ends inside an access unit leaves the rest queued."""
+    syn, hip = pkg.synth, pkg.hipdec
+    for S, nch_assign, rate in ((1, 12, 1), (2, 12, 2), (1, 1, 0)):
+        cfg = syn.make_cfg(assignment=nch_assign, rate_code=rate, n_substreams=S, n_aus=230, profile=1,
+                           features=syn.SF["CHAINED"] | syn.SF["FIRRAND"] | syn.SF["PARAMBLOCKS"], restart_interval=7)
+        data, frames = syn.stream(cfg, 5150 + S)
+        nch = syn.channels(cfg.assignment)
+        want, r, st = oracle.decode(data, nch, frames)
+        assert st == 0
+        for cuts in ([len(data)], [3, 70001, 70003, len(data) - 1, len(data)], [100000, len(data)]):
+            dec = hip.MLPDecoder(cfg.bps_code, cfg.bps_code, cfg.rate_code, cfg.rate_code, cfg.assignment)
+            samples = [[] for _ in range(nch)]
+            try:
+                lo = 0
+                for hi in cuts:
+                    dec.decode_packet(np.ascontiguousarray(data[lo:hi]), samples)
+                    assert dec.status & ~hip.ST_BENIGN == 0, hex(dec.status)
+                    lo = hi
+                assert dec.path == 0 and dec.queued_bytes < 4
+            finally:
+                dec.close()
+            got = np.asarray(samples, np.int32)
+            assert got.shape == want.shape and np.array_equal(got, want), (S, cuts)
+
+
 @pytest.mark.parametrize("S", [1, 2])
 def test_streaming_tier_state_on_the_device_and_its_fall_back(pkg, oracle, S):
     """Tier B keeps the decoder state on the device (k_coop<false, true>): IIR taps, six matrices, parameter and matrix
