@@ -446,6 +446,21 @@ struct BitReader {
         ofs = o & 31u;
         return v;
     }
+    // the same for a signed field (sign bit first, two's complement), n in [0, 31]
+    __device__ __forceinline__ int32_t read_signed_resident(uint32_t n)
+    {
+        const uint32_t top = peek32();
+        const int32_t v = n ? (int32_t)top >> ((32u - n) & 31u) : 0;
+        const uint32_t o = ofs + n;
+        const bool step = o >= 32u;
+        const uint32_t cand = ld(next);
+        hi = step ? lo : hi;
+        lo = step ? nx : lo;
+        nx = step ? cand : nx;
+        next += step ? 1u : 0u;
+        ofs = o & 31u;
+        return v;
+    }
     __device__ __forceinline__ int32_t read_signed(uint32_t n)
     {
         if (n == 0)
@@ -1065,7 +1080,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     matrix_len = par_seen >> 16;
                 }
                 if (rd.read(1)) {
-                    const bool restart = rd.read(1) != 0;
+                    // (every lane tops its ring up here, together, and the fields below are cut from resident dwords without a
+                    //  test or a loop per field: the generic read() ends in "while the window has run out, step it", which over 64
+                    //  lanes at 64 bit positions ran on nearly every field -- a block header cost a lane 40 us.  A header's groups of
+                    //  fields -- up to the first matrix, a matrix, a channel's parameters -- are at most 16 dwords each, and each group
+                    //  starts with its own top-up)
+                    rd.ensure(HDR_RESIDENT);
+                    const bool restart = rd.read_resident(1) != 0;
                     hdr_restart = restart;
                     if (restart) {
                         // ---- restart header (src/mlp.c:822-851)
@@ -1073,16 +1094,16 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         //  at 64 different positions nearly every read of the parse below had some lane waiting for memory, and the wave
                         //  with it -- 70 memory round trips per header instead of a few)
                         rd.ensure(HDR_RESIDENT);
-                        const uint32_t h0 = rd.read(14);           // 13u sync, 1u noise_type
-                        rd.read(16);                               // output_timestamp
-                        min_ch = rd.read(4);
-                        max_ch = rd.read(4);
-                        max_mat_ch = rd.read(4);
-                        noise_shift = rd.read(4);
-                        seed = rd.read(23);
-                        rd.read(19);
-                        rd.read(9);                                // check_data_present, lossless_check
-                        rd.read(16);
+                        const uint32_t h0 = rd.read_resident(14);           // 13u sync, 1u noise_type
+                        rd.read_resident(16);                               // output_timestamp
+                        min_ch = rd.read_resident(4);
+                        max_ch = rd.read_resident(4);
+                        max_mat_ch = rd.read_resident(4);
+                        noise_shift = rd.read_resident(4);
+                        seed = rd.read_resident(23);
+                        rd.read_resident(19);
+                        rd.read_resident(9);                                // check_data_present, lossless_check
+                        rd.read_resident(16);
                         if (h0 != (0x18F5u << 1) || max_ch < min_ch || max_mat_ch < max_ch) {
                             ok = false;
                             err = ST_RESTART;
@@ -1095,11 +1116,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             err = ST_ENVELOPE;
                         } else {
                             for (uint32_t c = 0; c <= max_mat_ch; c++)
-                                if (rd.read(6) > max_mat_ch) {
+                                if (rd.read_resident(6) > max_mat_ch) {
                                     ok = false;
                                     err = ST_RESTART;
                                 }
-                            rd.read(8);                            // checksum: ignored
+                            rd.read_resident(8);                            // checksum: ignored
                             nslots = max_ch - min_ch + 1;
                             // more channels in one substream than this instance keeps in registers (the two-wave
                             // kernel: WS_SLOTS): the header is parsed to its end -- whether the segment needs the
@@ -1118,22 +1139,22 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     if (ok) {
                         // ---- decoding parameters (src/mlp.c:866-990); flags bit (7-i) = flags[i]
                         if (restart) {
-                            flags = rd.read(1) ? rd.read(8) : 0xFFu;
-                        } else if ((flags & 0x80u) && rd.read(1)) {
-                            flags = rd.read(8);
+                            flags = rd.read_resident(1) ? rd.read_resident(8) : 0xFFu;
+                        } else if ((flags & 0x80u) && rd.read_resident(1)) {
+                            flags = rd.read_resident(8);
                         }
-                        if ((flags & 0x01u) && rd.read(1)) {                       // flags[7]
-                            block_size = rd.read(9);
+                        if ((flags & 0x01u) && rd.read_resident(1)) {                       // flags[7]
+                            block_size = rd.read_resident(9);
                             if (block_size < 8)
                                 ok = false;
                         } else if (restart) {
                             block_size = 8;
                         }
-                        if (ok && (flags & 0x02u) && rd.read(1)) {                 // flags[6]
+                        if (ok && (flags & 0x02u) && rd.read_resident(1)) {                 // flags[6]
                             // ---- matrices (src/mlp.c:1003-1023)
                             if (blocks_in_frame)
                                 matrix_class_change = true;
-                            matrix_len = rd.read(4);
+                            matrix_len = rd.read_resident(4);
                             if (matrix_len > MAXMAT) {
                                 ok = false;
                                 err = ST_ENVELOPE;
@@ -1143,19 +1164,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             outch_pack = 0;
                             for (uint32_t m = 0; m < matrix_len && ok; m++) {
                                 rd.ensure(HDR_RESIDENT);           // (a matrix is at most 145 bits)
-                                const uint32_t oc = rd.read(4);
-                                const uint32_t frac = rd.read(4);
+                                const uint32_t oc = rd.read_resident(4);
+                                const uint32_t frac = rd.read_resident(4);
                                 if (oc > max_mat_ch || frac > 14) {
                                     ok = false;
                                     break;
                                 }
                                 outch_pack |= oc << (4 * m);
-                                bypass_mask |= rd.read(1) << m;
+                                bypass_mask |= rd.read_resident(1) << m;
                                 uint32_t pair = 0, noise = 0;
                                 for (uint32_t c = 0; c < 10; c++) {
                                     int32_t v = 0;
-                                    if (c < max_mat_ch + 3 && rd.read(1))
-                                        v = (int32_t)((uint32_t)rd.read_signed(frac + 2) << (14 - frac));
+                                    if (c < max_mat_ch + 3 && rd.read_resident(1))
+                                        v = (int32_t)((uint32_t)rd.read_signed_resident(frac + 2) << (14 - frac));
                                     if (c == max_mat_ch + 1)
                                         noise |= (uint32_t)v & 0xFFFFu;
                                     if (c == max_mat_ch + 2)
@@ -1188,11 +1209,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             matrix_len = 0;
                             bypass_mask = 0;
                         }
-                        if (ok && (flags & 0x04u) && rd.read(1)) {                 // flags[5]
+                        if (ok && (flags & 0x04u) && rd.read_resident(1)) {                 // flags[5]
                             if (blocks_in_frame)
                                 matrix_class_change = true;
                             for (uint32_t c = 0; c <= max_mat_ch; c++) {
-                                const int32_t v = rd.read_signed(4);
+                                const int32_t v = rd.read_signed_resident(4);
                                 if (v < 0) {
                                     ok = false;
                                     err = ST_ENVELOPE;             // huge unsigned shift in the reference
@@ -1203,11 +1224,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             oshift_pack = 0;
                         }
                         bool qss_changed = false;
-                        if (ok && (flags & 0x08u) && rd.read(1)) {                 // flags[4]
+                        if (ok && (flags & 0x08u) && rd.read_resident(1)) {                 // flags[4]
                             if (blocks_in_frame)
                                 matrix_class_change = true;
                             for (uint32_t c = 0; c <= max_ch; c++)
-                                qss_pack = (qss_pack & ~(0xFu << (4 * c))) | (rd.read(4) << (4 * c));
+                                qss_pack = (qss_pack & ~(0xFu << (4 * c))) | (rd.read_resident(4) << (4 * c));
                             qss_changed = true;
                         } else if (restart) {
                             qss_pack = 0;
@@ -1240,20 +1261,20 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             bool touched = qss_changed;
                             bool new_fir = false, new_iir = false;
                             uint32_t ncf[4] = {0, 0, 0, 0};
-                            if (rd.read(1)) {
+                            if (rd.read_resident(1)) {
                                 touched = true;
-                                if ((flags & 0x10u) && rd.read(1)) {               // flags[3]
+                                if ((flags & 0x10u) && rd.read_resident(1)) {               // flags[3]
                                     // ---- FIR (src/mlp.c:1033-1068)
-                                    fir_order = rd.read(4);
+                                    fir_order = rd.read_resident(4);
                                     new_fir = true;
                                     if (fir_order > 8) {
                                         ok = false;
                                     } else if (fir_order == 0) {
                                         fir_shift = 0;
                                     } else {
-                                        fir_shift = rd.read(4);
-                                        const uint32_t cbits = rd.read(5);
-                                        const uint32_t cshift = rd.read(3);
+                                        fir_shift = rd.read_resident(4);
+                                        const uint32_t cbits = rd.read_resident(5);
+                                        const uint32_t cshift = rd.read_resident(3);
                                         if (cbits < 1 || cbits > 16 || cbits + cshift > 16) {
                                             ok = false;
                                         } else {
@@ -1261,13 +1282,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                             for (int j = 0; j < 8; j++) {
                                                 int32_t v = 0;
                                                 if ((uint32_t)j < fir_order)
-                                                    v = (int32_t)((uint32_t)rd.read_signed(cbits) << cshift);
+                                                    v = (int32_t)((uint32_t)rd.read_signed_resident(cbits) << cshift);
                                                 if (j & 1)
                                                     ncf[j >> 1] |= (uint32_t)v << 16;
                                                 else
                                                     ncf[j >> 1] = (uint32_t)v & 0xFFFFu;
                                             }
-                                            if (rd.read(1))
+                                            if (rd.read_resident(1))
                                                 ok = false;
                                         }
                                     }
@@ -1276,18 +1297,18 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                     fir_shift = 0;
                                     new_fir = true;
                                 }
-                                if (ok && (flags & 0x20u) && rd.read(1)) {         // flags[2]
+                                if (ok && (flags & 0x20u) && rd.read_resident(1)) {         // flags[2]
                                     // ---- IIR (src/mlp.c:1075-1119): cold storage in the workspace
                                     new_iir = true;
-                                    iir_order = rd.read(4);
+                                    iir_order = rd.read_resident(4);
                                     if (iir_order > 8) {
                                         ok = false;
                                     } else if (iir_order == 0) {
                                         iir_shift = 0;
                                     } else {
-                                        iir_shift = rd.read(4);
-                                        const uint32_t cbits = rd.read(5);
-                                        const uint32_t cshift = rd.read(3);
+                                        iir_shift = rd.read_resident(4);
+                                        const uint32_t cbits = rd.read_resident(5);
+                                        const uint32_t cshift = rd.read_resident(3);
                                         if (cbits < 1 || cbits > 16 || cbits + cshift > 16) {
                                             ok = false;
                                         } else {
@@ -1295,11 +1316,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                             for (uint32_t j = 0; j < 8; j++) {
                                                 int32_t v = 0;
                                                 if (j < iir_order)
-                                                    v = (int32_t)((uint32_t)rd.read_signed(cbits) << cshift);
+                                                    v = (int32_t)((uint32_t)rd.read_signed_resident(cbits) << cshift);
                                                 ws[(size_t)j * a.total_lanes] = v;
                                             }
-                                            if (rd.read(1)) {
-                                                const uint32_t sbits = rd.read(4), sshift = rd.read(4);
+                                            if (rd.read_resident(1)) {
+                                                const uint32_t sbits = rd.read_resident(4), sshift = rd.read_resident(4);
                                                 if (sbits == 0) {
                                                     ok = false;
                                                     err = ST_ENVELOPE;
@@ -1307,7 +1328,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                                 for (uint32_t j = 0; j < 8; j++) {
                                                     int32_t v = 0;
                                                     if (j < iir_order)
-                                                        v = (int32_t)((uint32_t)rd.read_signed(sbits) << sshift);
+                                                        v = (int32_t)((uint32_t)rd.read_signed_resident(sbits) << sshift);
                                                     ws[(size_t)(8 + j) * a.total_lanes] = v;   // [8] = most recent
                                                 }
                                             } else {
@@ -1321,12 +1342,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                     iir_order = 0;
                                     iir_shift = 0;
                                 }
-                                if (ok && (flags & 0x40u) && rd.read(1))           // flags[1]
-                                    hoff = rd.read_signed(15);
+                                if (ok && (flags & 0x40u) && rd.read_resident(1))           // flags[1]
+                                    hoff = rd.read_signed_resident(15);
                                 else if (restart)
                                     hoff = 0;
-                                codebook = rd.read(2);
-                                lsbs = rd.read(5);
+                                codebook = rd.read_resident(2);
+                                lsbs = rd.read_resident(5);
                                 if (lsbs > 24)
                                     ok = false;
                             } else if (restart) {
