@@ -111,6 +111,12 @@ typedef int dvda_v4i __attribute__((ext_vector_type(4)));
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
         asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v4_) : "memory");           \
     } while (0)
+// ... followed by the two wait states a store of more than 64 bits needs before its data registers may be written
+#define DVDA_STORE_V4_PAD(dst, a_, b_, c_, d_)                                                      \
+    do {                                                                                            \
+        dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
+    } while (0)
 // the same at a constant byte offset from one base address
 #define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
     do {                                                                                            \
@@ -2103,6 +2109,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
+        // (chain parse pass: do all lanes -- or, in lane pairs, all odd / all even lanes -- complete a line this turn?  The usual
+        //  case: lanes advance row by row together.  Then the lines' channel pieces leave in line order, below)
+        uint32_t coop_flush = 0;
+        if constexpr (PARSE && !GENERAL) {
+            const uint64_t fm = __ballot(flush);
+            coop_flush = fm == ~0ull ? 1u : (PAIRED && fm == 0xAAAAAAAAAAAAAAAAull) ? 2u : (PAIRED && fm == 0x5555555555555555ull) ? 3u : 0u;
+        }
         if (PARSE && flush) {
             // ---- chain parse pass: four PCM frames of all eight planes are ONE 128-byte line of the segment's
             //      workspace ([row / 4][plane][row % 4], res_index()): the lane writes it whole, the filter pass's
@@ -2111,13 +2124,42 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             int32_t *dst = a.res + out_base + (flush_row >> 2) * 32u;
             if (!DVDA_RANGE_OK(out_base + (flush_row >> 2) * 32u, 32, a.caps.res, BT_RES))
                 dst = a.res;
+            if (!coop_flush) {
 #pragma unroll
             for (int c = 0; c < TP; c++)
                 DVDA_STORE_V4_AT(dst, 16 * c, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane],
                                  T[c][2][GENERAL ? 0 : lane], T[c][3][GENERAL ? 0 : lane]);
+            }
             // planes 6 and 7: the four frames' bypassed LSBs and noise seeds (oldest first)
             DVDA_STORE_V4_AT(dst, 16 * 6, pq_b[0], pq_b[1], pq_b[2], pq_b[3]);
             DVDA_STORE_V4_AT(dst, 16 * 7, pq_s[0], pq_s[1], pq_s[2], pq_s[3]);
+        }
+        if constexpr (PARSE && !GENERAL) {
+            if (coop_flush) {
+                // ---- the six channel pieces of every flushing lane's line, dealt to the wave's lanes in LINE order: lanes
+                //      6 o .. 6 o + 5 write the 96 bytes of lane o's line side by side -- a store instruction covers ten
+                //      lines' channel pieces whole instead of one 16-byte piece of each of 64 lines (which is what the
+                //      pass waits for: 3.4e8 partial-line writes for L2 to put together, DESIGN A.4)
+                const int32_t *dsrc = a.res + out_base + (flush_row >> 2) * 32u;
+                if (!flush || !DVDA_RANGE_OK(out_base + (flush_row >> 2) * 32u, 32, a.caps.res, BT_RES))
+                    dsrc = a.res;
+                const uint32_t d_lo = (uint32_t)(uintptr_t)dsrc, d_hi = (uint32_t)((uintptr_t)dsrc >> 32);
+                const int32_t *const T0 = &s_out[wv][0][0][0];
+                const uint32_t n_it = coop_flush == 1u ? 6u : 3u;
+                for (uint32_t it6 = 0; it6 < n_it; it6++) {
+                    const uint32_t q = it6 * 64u + (uint32_t)lane;
+                    const uint32_t o6 = (q * 43691u) >> 18;              // q / 6 for q < 384
+                    const uint32_t pc = q - o6 * 6u;
+                    const uint32_t o = coop_flush == 1u ? o6 : 2u * o6 + (coop_flush == 2u ? 1u : 0u);
+                    const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64), b_hi = (uint32_t)__shfl((int)d_hi, (int)o, 64);
+                    int32_t *const od = reinterpret_cast<int32_t *>(((uint64_t)b_hi << 32) | b_lo) + pc * 4u;
+                    const int32_t *const Tp = T0 + pc * (OUT_ROWS * 64) + o;
+                    // (the store may still be reading its data registers when the next instructions issue, and what follows
+                    //  here is this loop's own arithmetic in whatever registers the compiler likes: two wait states, as the
+                    //  compiler pads its own stores -- tools/hazard_check.py looks at every store placed as inline asm)
+                    DVDA_STORE_V4_PAD(od, Tp[0], Tp[64], Tp[128], Tp[192]);
+                }
+            }
         }
         if (!GENERAL && !PARSE && !ILV && flush) {
             int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
