@@ -1170,13 +1170,17 @@ def main():
             sub_steps = max(5, min(args.steps, 20))
             out["sub"] = sub_records(pkg, torch, dev, local_rank, args, b, sub_steps, 2)
             t_h = time.perf_counter()
-            out["sub"]["host_to_host"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
-                                                      max(3, sub_steps // 4))
-            out["sub"]["host_to_host_wav24"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
-                                                            max(3, sub_steps // 4), wav24=True)
+            only = set(x for x in args.only_sub.split(",") if x)
+            if not only or "host_to_host" in only:
+                out["sub"]["host_to_host"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
+                                                          max(3, sub_steps // 4))
+            if not only or "host_to_host_wav24" in only:
+                out["sub"]["host_to_host_wav24"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
+                                                                max(3, sub_steps // 4), wav24=True)
             sys.stderr.write("bench: host_to_host records %.1f s\n" % (time.perf_counter() - t_h))
-            from tests import oracle_lib as _ol
-            out["sub"]["streaming_tier"] = streaming_tier(pkg, _ol.Oracle())
+            if not only or "streaming_tier" in only:
+                from tests import oracle_lib as _ol
+                out["sub"]["streaming_tier"] = streaming_tier(pkg, _ol.Oracle())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
