@@ -136,6 +136,7 @@ static void usage(const char *prog)
            "  -d DIR, --dir=DIR         output directory (default: the working directory)\n"
            "  -g N, --gpu=N             HIP device (default 0)\n"
            "  -D LIST, --devices=LIST   comma-separated HIP devices: one worker thread per entry takes tracks in turn\n"
+           "                            (default: up to four workers on the device of -g)\n"
            "                            (a device may be named more than once)\n", prog);
 }
 
@@ -174,8 +175,6 @@ int main(int argc, char *argv[])
     }
     /* (DVDA_NO_FUSED_WAV=1 in the environment brings the int32 decode + packing pass back, for comparison) */
     const int fused_wav = getenv("DVDA_NO_FUSED_WAV") == NULL;
-    if (n_devices == 0)
-        devices[n_devices++] = one_device;
     DVDA *dvda = dvda_open(audio_ts, cdrom);
     DVDA_Titleset *ts = dvda ? dvda_open_titleset(dvda, titleset_num) : NULL;
     if (!ts) {
@@ -209,6 +208,13 @@ int main(int argc, char *argv[])
             jobs[n_jobs].title = title;
             jobs[n_jobs++].track = k;
         }
+    }
+    if (n_devices == 0) {
+        /* no --devices: a pool of up to four workers on the one device (-g, default 0) -- one worker's file read and
+           WAV write overlap the others' decodes; a single track needs no pool */
+        const unsigned w = n_jobs >= 4 ? 4 : (n_jobs ? n_jobs : 1);
+        for (unsigned i = 0; i < w; i++)
+            devices[n_devices++] = one_device;
     }
     struct pool pool = {jobs, n_jobs, 0, 0, dir, fused_wav};
     struct worker workers[64];
