@@ -1319,8 +1319,8 @@ extern "C" int dvda_mlp_hip_stepper_create(dvda_mlp_hip_stepper **out, int devic
               hipMalloc((void **)&s->d_small, 16 * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&s->d_summary, (1 + SUMMARY_PARTS) * sizeof(DecodeSummary)) == hipSuccess &&
               hipMalloc((void **)&s->d_state, 2 * sizeof(CoopState)) == hipSuccess &&
-              hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocMapped) == hipSuccess &&
-              hipHostMalloc((void **)&s->h_out, out_bytes, hipHostMallocMapped) == hipSuccess &&
+              hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostMalloc((void **)&s->h_out, out_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer((void **)&s->d_in, s->h_in, 0) == hipSuccess &&
               hipHostGetDevicePointer((void **)&s->d_out, s->h_out, 0) == hipSuccess;
     ok = ok && hipMemset(s->d_state, 0, 2 * sizeof(CoopState)) == hipSuccess &&
