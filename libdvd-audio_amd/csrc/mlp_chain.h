@@ -536,8 +536,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
 #pragma unroll
             for (int q = 0; q < 6; q++)
                 ch[q] = X[q * 8 + p];
-            const uint32_t bypass_bits = (uint32_t)X[6 * 8 + p];
-            const uint32_t seed = (uint32_t)X[7 * 8 + p];
+            const uint32_t seed = (uint32_t)X[6 * 8 + p];       // noise seed (bits 0 .. 22) | bypassed LSBs << 23: the seed's uses
+            const uint32_t bypass_bits = seed >> 23;            // below look at its bits 7 .. 22 only
             if (have_au != oau - 1u) {
                 // ---- the first unit this wave takes of an access unit: its record from its place in the ring
                 have_au = oau - 1u;
@@ -936,6 +936,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
     // below assumes) into ring place `place` -- wave-uniform: the ring is indexed by the turn
     auto dma_unit = [&](uint32_t w, uint32_t place) {
         const int4 *N = Q + (size_t)(w < nu ? w : nu - 1u) * 16u;
+        // (piece 7 of a line is not used -- the bypassed LSBs ride in the seed word, piece 6 -- but its lanes ask all the
+        //  same: masking them off costs the wave more than the 16 bytes cost the memory side, measured 7.96 -> 8.42 ms)
         fu_dma16(N, fu_lds(&s_ring[place][0][0]));          // (no instruction offset: it would move the LDS address too)
         fu_dma16(N + 8, fu_lds(&s_ring[place][1][0]));
     };

@@ -379,8 +379,8 @@ __global__ __launch_bounds__(256) void k_chain_rematrix(ChainArgs a)
 #pragma unroll
         for (int c = 0; c < 6; c++)
             ch[c] = P[c * 4];
-        const uint32_t bypass_bits = (uint32_t)P[6 * 4];
-        const uint32_t seed = (uint32_t)P[7 * 4];
+        const uint32_t seed = (uint32_t)P[6 * 4];           // noise seed (bits 0 .. 22) | bypassed LSBs << 23
+        const uint32_t bypass_bits = seed >> 23;
         const uint32_t *F = a.frec + ((size_t)(pl.x / 40u) + row / rpa) * FREC_WORDS;
         const uint32_t w0 = F[0];
         const uint32_t noise_shift = w0 & 0xFFu, matrix_len = (w0 >> 8) & 0xFFu, mmc = w0 >> 16;

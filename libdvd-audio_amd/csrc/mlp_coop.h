@@ -984,8 +984,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
 #pragma unroll
                     for (int c = 0; c < 6; c++)
                         dst[4 * c] = s_val[c][row];
-                    dst[4 * 6] = (int32_t)s_byp[row];
-                    dst[4 * 7] = (int32_t)sd;
+                    dst[4 * 6] = (int32_t)((sd & 0x7FFFFFu) | (s_byp[row] << 23));      // (as k_decode<.., PARSE>: one word)
                 }
             }
             if (lane == 0) {

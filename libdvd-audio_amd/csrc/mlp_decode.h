@@ -843,7 +843,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint64_t row = row0;              // next output PCM frame index
     uint32_t rows_written = 0;
     uint32_t rows_done = 0;           // rows decoded by this lane (lockstep across the wave)
-    int32_t pq_b[OUT_ROWS] = {0, 0, 0, 0}, pq_s[OUT_ROWS] = {0, 0, 0, 0};   // chain parse pass: see TP
+    int32_t pq_s[OUT_ROWS] = {0, 0, 0, 0};   // chain parse pass (see TP): per staged row, noise seed (its 23 bits) | bypassed LSBs << 23
     uint32_t au_idx = 0;              // chain parse pass: PCM-yielding access units of the segment so far
     uint32_t drops_seen = 0;          // frames dropped so far (major sync with other stream parameters)
 
@@ -1755,11 +1755,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         //      is rematrixed with (stepped once per PCM frame, src/mlp.c:1327-1334)
 #pragma unroll
                         for (int j = 0; j < OUT_ROWS - 1; j++) {
-                            pq_b[j] = pq_b[j + 1];
                             pq_s[j] = pq_s[j + 1];
                         }
-                        pq_b[OUT_ROWS - 1] = (int32_t)bypass_bits;
-                        pq_s[OUT_ROWS - 1] = (int32_t)seed;
+                        // (of the seed only bits 7 .. 22 are ever looked at -- src/mlp.c:1327-1334 -- and a frame has at most six
+                        //  bypassed LSBs: one word, one 16-byte piece of the line instead of two)
+                        pq_s[OUT_ROWS - 1] = (int32_t)((seed & 0x7FFFFFu) | (bypass_bits << 23));
                         const uint32_t shifted = (seed >> 7) & 0xFFFFu;
                         seed = (seed << 16) ^ shifted ^ (shifted << 5);
                     } else {
@@ -2130,9 +2130,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 DVDA_STORE_V4_AT(dst, 16 * c, T[c][0][GENERAL ? 0 : lane], T[c][1][GENERAL ? 0 : lane],
                                  T[c][2][GENERAL ? 0 : lane], T[c][3][GENERAL ? 0 : lane]);
             }
-            // planes 6 and 7: the four frames' bypassed LSBs and noise seeds (oldest first)
-            DVDA_STORE_V4_AT(dst, 16 * 6, pq_b[0], pq_b[1], pq_b[2], pq_b[3]);
-            DVDA_STORE_V4_AT(dst, 16 * 7, pq_s[0], pq_s[1], pq_s[2], pq_s[3]);
+            // piece 6: the four frames' noise seeds | bypassed LSBs << 23 (oldest first); piece 7 of the line is not used
+            DVDA_STORE_V4_AT(dst, 16 * 6, pq_s[0], pq_s[1], pq_s[2], pq_s[3]);
         }
         if constexpr (PARSE && !GENERAL) {
             if (coop_flush) {
