@@ -82,6 +82,28 @@ KERNEL(k_cnd2_add2, "v_cndmask_b32 %0, %1, %0, vcc\nv_cndmask_b32 %2, %1, %2, vc
 KERNEL(k_cnd_e64_pair, "v_cndmask_b32 %0, %1, %0, vcc\nv_cndmask_b32_e64 %2, %1, %2, vcc\n")
 KERNEL(k_addc_stale, "v_addc_co_u32 %0, vcc, %1, %0, vcc\n")
 KERNEL(k_cnd_sdwa_mix, "v_cndmask_b32 %0, %1, %0, vcc\nv_cmp_lt_u32 vcc, %1, %3\n")
+// round 5: candidates for the history shift and the per-sample field arithmetic
+KERNEL(k_pk_mov, "v_pk_mov_b32 %4, %5, %4 op_sel:[1,0]\n")
+KERNEL(k_pk_mov_indep, "v_pk_mov_b32 %4, %5, %5 op_sel:[1,0]\n")
+KERNEL(k_mov_b64, "v_mov_b64 %4, %5\n")
+KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 3, %1\n")
+KERNEL(k_bfi, "v_bfi_b32 %0, %1, %2, %0\n")
+KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2\n")
+KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %0, %1, %2, %0\n")
+KERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2\n")
+KERNEL(k_lshl_add_u64, "v_lshl_add_u64 %4, %4, 1, %5\n")
+KERNEL(k_add_lshl, "v_add_lshl_u32 %0, %0, %1, 1\n")
+KERNEL(k_lshr_imm, "v_lshrrev_b32 %0, 1, %0\n")
+KERNEL(k_lshl_v, "v_lshlrev_b32 %0, %1, %0\n")
+KERNEL(k_and_imm, "v_and_b32 %0, 0x1f00, %0\n")
+KERNEL(k_mad_mix, "v_mad_i64_i32 %4, vcc, %1, %2, %4\nv_add_u32 %0, %1, %0\n")
+KERNEL(k_mad_mix2, "v_mad_i64_i32 %4, vcc, %1, %2, %4\nv_add_u32 %0, %1, %0\nv_and_b32 %3, %1, %3\n")
+KERNEL(k_half_mix, "v_bfe_u32 %0, %0, 3, 16\nv_add_u32 %2, %1, %2\n")
+KERNEL(k_sdwa_sel, "v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n")
+KERNEL(k_readlane, "v_readlane_b32 s10, %0, 3\n")
+KERNEL(k_sadd, "s_add_u32 s10, s10, 1\n")
+KERNEL(k_sadd_vadd, "s_add_u32 s10, s10, 1\nv_add_u32 %0, %1, %0\n")
 
 struct Probe { const char *name; void (*fn)(uint32_t *, uint32_t); int per_rep; };
 
@@ -118,11 +140,19 @@ int main()
         {"v_cndmask vcc + 1 v_mad_i32_i24 (per instr)", k_cnd_mad1, 2}, {"2 v_cndmask vcc + 2 v_add (per instr)", k_cnd2_add2, 4},
         {"v_cndmask e32 + v_cndmask e64 (per instr)", k_cnd_e64_pair, 2}, {"v_addc_co stale vcc chain", k_addc_stale, 1},
         {"v_cndmask + v_cmp other (per instr)", k_cnd_sdwa_mix, 2},
+        {"v_pk_mov_b32 (dependent)", k_pk_mov, 1}, {"v_pk_mov_b32 (independent)", k_pk_mov_indep, 1},
+        {"v_mov_b64", k_mov_b64, 1}, {"v_mov_b32_dpp row_shr", k_mov_dpp, 1}, {"v_lshl_or_b32", k_lshl_or, 1},
+        {"v_bfi_b32", k_bfi, 1}, {"v_or3_b32", k_or3, 1}, {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_xad_u32", k_xad, 1},
+        {"v_lshl_add_u64", k_lshl_add_u64, 1}, {"v_add_lshl_u32", k_add_lshl, 1}, {"v_lshrrev_b32 imm", k_lshr_imm, 1},
+        {"v_lshlrev_b32 vgpr", k_lshl_v, 1}, {"v_and_b32 literal", k_and_imm, 1}, 
+        {"v_mad_i64_i32 + v_add (per instr)", k_mad_mix, 2}, {"v_mad_i64_i32 + 2 simple (per instr)", k_mad_mix2, 3},
+        {"v_bfe_u32 + v_add (per instr)", k_half_mix, 2}, {"v_lshlrev_b32_sdwa", k_sdwa_sel, 1},
+        {"v_readlane_b32", k_readlane, 1}, {"s_add_u32", k_sadd, 1}, {"s_add + v_add (per instr)", k_sadd_vadd, 2},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int waves = 1; waves <= 2; waves++) {
+    for (int waves = 1; waves <= 4; waves++) {
         double base = 0;
         printf("-- %d wave(s) per SIMD\n", waves);
         for (auto &p : probes) {
