@@ -39,6 +39,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "mlp_bounds.h"
 #include "mlp_index.h"
 #include "mlp_tables.h"
@@ -69,6 +70,21 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_HDR_GATE
 #define DVDA_HDR_GATE 1
 #endif
+// the filter's coefficients one per register instead of int16 pairs (saves eight unpacks per sample, costs 24 registers
+// in the six-channel instance)
+#ifndef DVDA_CF_UNPACKED
+#define DVDA_CF_UNPACKED 0
+#endif
+// experiments of round 5 (tools/ab_build.py): the wave stores its PCM together / fills its rings together
+#ifndef DVDA_COOP_OUT
+#define DVDA_COOP_OUT 0
+#endif
+#ifndef DVDA_EARLY_WINDOW
+#define DVDA_EARLY_WINDOW 1
+#endif
+#ifndef DVDA_WAVE_ENSURE
+#define DVDA_WAVE_ENSURE 1
+#endif
 // (round 4, tools/probe/sub_ab.sh: 4 turns / 16 lanes -> 32 / 32: fuzz_fast_features 26.0 -> 33.2 Gsamples/s,
 //  fuzz_all_features 10.3 -> 12.5, the header phase's share of a wave's time 62 -> 38 %; the headline -- lanes in
 //  lockstep, the phase runs when all of them wait -- and the heterogeneous batches do not move)
@@ -96,6 +112,18 @@ constexpr uint32_t HDR_GATE_TURNS = DVDA_HDR_GATE_TURNS, HDR_GATE_LANES = DVDA_H
 #else
 #define DVDA_STAMP(i) ((void)0)
 #endif
+// ... and inside the header phase (one-lane kernels; the lane's own view: dbg[8 ..]): frame header | restart header |
+// parameters up to the channels | the channels' parameters | what follows the parse
+#if defined(DVDA_EXP_STAMP)
+#define DVDA_HSTAMP(i)                                                   \
+    do {                                                                 \
+        const unsigned long long t_ = clock64();                         \
+        hstamp_acc[i] += t_ - hstamp_t;                                  \
+        hstamp_t = t_;                                                   \
+    } while (0)
+#else
+#define DVDA_HSTAMP(i) ((void)0)
+#endif
 // coverage counters of the rarely taken paths (DVDA_EXP_COUNT builds, tools/coverage_run.py)
 #if defined(DVDA_EXP_COUNT)
 #define DVDA_COV(i) do { if (a.dbg) atomicAdd(&a.dbg[(i)], 1ull); } while (0)
@@ -118,12 +146,20 @@ typedef int dvda_v4i __attribute__((ext_vector_type(4)));
         asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
     } while (0)
 // the same at a constant byte offset from one base address
+#if defined(DVDA_EXP_NOSTORE)      // (diagnostic: what the PCM stores cost -- the data is computed and read from the tile, not written)
+#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
+    do {                                                                                            \
+        dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
+        asm volatile("" ::"v"(dst), "v"(v4_) : "memory");                                           \
+    } while (0)
+#else
 #define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
         asm volatile("global_store_dwordx4 %0, %1, off offset:%2"                                   \
                      ::"v"(dst), "v"(v4_), "n"(off_) : "memory");                                   \
     } while (0)
+#endif
 
 // (8-byte store at a constant byte offset: the tail of a 72-byte run of packed 24-bit samples)
 typedef int dvda_v2i __attribute__((ext_vector_type(2)));
@@ -166,8 +202,19 @@ struct DecodeSummary {
                                    // have to agree, and the host makes sure nothing waits unreported if they do not)
     uint32_t pad[2];
 };
-constexpr uint32_t HDR_RESIDENT = 16;       // dwords the header parser tops the ring up to before a group of reads (one
-                                            // chunk: the most ensure() may ask of a two-chunk ring)
+// Dwords the header parser tops the ring up to before a group of fields, counted from the dword of the next unread bit:
+// a group of G bits needs (31 + G + 31) / 32 + 1 of them (its first bit anywhere in its dword, one more dword for the
+// 64-bit window of its last field).  Round 5: the groups are cut so that none needs more than 9 -- the row loop leaves
+// a lane at least that far ahead at the end of nearly every row (it keeps 12 at a row's start and fetches 16 when it
+// is below 16: a row takes 6 of them on the BASELINE recipe), so a block header seldom waits for a memory round trip
+// any more.  With ONE size for all groups (16: rounds 3-4) nearly every header of a wave paid one, the whole wave for
+// any lane: 25 000 cycles per block header in the headline batch (tools/stamp_run.py), 8.6 % of the kernel's time.
+constexpr uint32_t HDR_BLOCK = 5;           // decoding parameters without a restart header and without matrices: 91 bits
+constexpr uint32_t HDR_RESTART = 8;         // a restart header: 169 bits
+constexpr uint32_t HDR_MATRIX = 9;          // a matrix (145 bits) and, behind the last, output shifts + quant steps (66)
+constexpr uint32_t HDR_FIR = 7;             // a channel's first bit + FIR parameters: 148 bits
+constexpr uint32_t HDR_IIR = 7;             // IIR parameters up to the taps: 145 bits
+constexpr uint32_t HDR_IIR_STATE = 7;       // IIR state (129 bits) + Huffman offset, code book, LSB count (23)
 constexpr uint32_t SUMMARY_PARTS = 64;      // the fast pass adds into summary[1 + block % 64]; k_finalize folds them into summary[0]
 constexpr int FREC_WORDS = 36;     // per access unit: 4 header words + 6 matrices x 5 + pad
 // Block records (round 4: fixed places, so that the pass that reads them can ask for a record before it knows
@@ -309,22 +356,29 @@ __device__ __forceinline__ int32_t huff_center(uint32_t codebook, uint32_t lb)
     return ss >= 0 ? (1 << ss) : 0;
 }
 
-// Ring layout: [dword index mod RING_DWORDS][lane].  A lane's dword d sits at
-// (d mod RING_DWORDS) * 64 + lane, so whatever position each lane reads, lane l always hits
-// bank l mod 32: ring reads and writes are conflict-free and an address costs two instructions.
-// One extra plane behind the ring mirrors plane 0, so "dword d and dword d + 1" is always
-// "address and address + one plane": the row loop fetches its two look-ahead dwords with a single
-// two-address LDS read and one address computation.  `first_plane`: the chunk starts at plane 0.
+// Ring layout: [plane][lane], a lane's dword d in plane 32 - (d mod RING_DWORDS) -- planes 1 .. 32, in FALLING
+// order of the dword index -- so whatever position each lane reads, lane l always hits bank l mod 32: ring reads
+// and writes are conflict-free.  Plane 0 mirrors plane 32 (the dwords that are 0 mod 32), so "dword d + 1 and
+// dword d" is always "address and address + one plane": the 64-bit window at dword d is ONE two-address LDS read
+// whose first result is the window's low half and whose second its high half, the order a register pair wants
+// (round 5: with the planes in rising order the compiler swapped the two results with two moves per symbol).
+// `first_plane`: the chunk starts at a dword that is 0 mod 32.
+__device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
+// (round 5: the ring holds the stream's dwords in big-endian value order -- swapped here, once per dword, instead of
+//  by every reader: the row loop cuts each symbol from a 64-bit window it reads from the ring, two dwords per symbol)
 __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, const uint4 &b, const uint4 &c,
                                              const uint4 &d, bool first_plane)
 {
     // dst = slot of the chunk's first dword; the chunk is 16-dword aligned, so no wrap inside it
+    // (planes fall as the dword index rises: dword i of the chunk sits i planes BELOW dst)
+    const uint32_t a0 = be32(a.x);
+    uint32_t *const e = dst - 15 * 64;                  // the chunk's last dword
     if (first_plane)
-        dst[RING_DWORDS * 64] = (a.x);
-    dst[0 * 64] = (a.x);  dst[1 * 64] = (a.y);  dst[2 * 64] = (a.z);  dst[3 * 64] = (a.w);
-    dst[4 * 64] = (b.x);  dst[5 * 64] = (b.y);  dst[6 * 64] = (b.z);  dst[7 * 64] = (b.w);
-    dst[8 * 64] = (c.x);  dst[9 * 64] = (c.y);  dst[10 * 64] = (c.z); dst[11 * 64] = (c.w);
-    dst[12 * 64] = (d.x); dst[13 * 64] = (d.y); dst[14 * 64] = (d.z); dst[15 * 64] = (d.w);
+        dst[-RING_DWORDS * 64] = a0;                    // plane 32 -> its mirror, plane 0
+    e[15 * 64] = a0;         e[14 * 64] = be32(a.y); e[13 * 64] = be32(a.z); e[12 * 64] = be32(a.w);
+    e[11 * 64] = be32(b.x);  e[10 * 64] = be32(b.y); e[9 * 64] = be32(b.z);  e[8 * 64] = be32(b.w);
+    e[7 * 64] = be32(c.x);   e[6 * 64] = be32(c.y);  e[5 * 64] = be32(c.z);  e[4 * 64] = be32(c.w);
+    e[3 * 64] = be32(d.x);   e[2 * 64] = be32(d.y);  e[1 * 64] = be32(d.z);  e[0 * 64] = be32(d.w);
 }
 
 // ---------------------------------------------------------------- cold helpers
@@ -358,27 +412,43 @@ __device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride,
 // MSB-first reader (contract of reference src/bitstream.c:1077-1111, 1198-1206)
 // over a per-lane LDS ring (layout above: [dword mod RING_DWORDS][lane]).
 //
-// Three stream dwords are held in registers: (hi, lo) form the 64-bit window the
-// current symbol is cut from at bit offset ofs (< 32 between symbols) and nx is
-// the dword after them, already loaded -- so advancing the window never waits
-// for LDS.  The row loop advances branch-free (select by ofs >> 5); the cold
-// header parser uses read()/advance().  Dword indices are 32-bit: a batch
-// buffer is limited to 16 GiB (checked by dvda_mlp_hip_index).
+// Round 5: the reader keeps ONE word of position -- the absolute bit position of the next unread bit, modulo
+// 2^32; the ring is 1 024 bits, so its low ten bits are the place in the ring -- and every read cuts its field from
+// a 64-bit window fetched from the ring with one two-address LDS read (dword d and d + 1: the mirror plane).
+// Rounds 1-4 held three stream dwords in registers and stepped them by selects: 15 instructions per symbol for what
+// is now five (position += length; plane = bits 5..9; address; read), and the read of the NEXT symbol's window is
+// in flight while this symbol's value goes through the filter.  Absolute 64-bit positions are rebuilt by the cold
+// code from a nearby reference (tell_near); dword indices are 32-bit: a batch buffer is limited to 16 GiB
+// (checked by dvda_mlp_hip_index).
 struct BitReader {
     const uint4 *gsrc;      // global bytes as 16-byte units
     uint32_t *ring;         // this lane's column: wave ring + lane
     uint32_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
-    uint32_t hi, lo, nx;    // stream dwords next-3, next-2, next-1 (big-endian order)
-    uint32_t ofs;           // bit offset of the next unread bit inside (hi:lo)
-    uint32_t next;          // absolute index of the dword after nx
+    uint32_t pos;           // bit position of the next unread bit (absolute, modulo 2^32)
     uint32_t fillpos;       // ring holds dwords [lo_valid, fillpos); fillpos is a multiple of 16
     uint32_t lo_valid;
 
     __device__ __forceinline__ uint32_t *slot(uint32_t d) const
     {
-        return ring + ((d & (RING_DWORDS - 1)) << 6);
+        return ring + ((RING_DWORDS - (d & (RING_DWORDS - 1))) << 6);
     }
-    __device__ __forceinline__ uint32_t ld(uint32_t d) const { return __builtin_bswap32(*slot(d)); }
+    // the stream's 64 bits from the dword of the next unread bit on (big-endian value order): dword d + 1 is one
+    // plane below dword d (the mirror plane below dword 31's)
+    __device__ __forceinline__ uint64_t window() const
+    {
+        const uint32_t *p = ring + ((~(pos >> 5) & (RING_DWORDS - 1)) << 6);
+        return ((uint64_t)p[64] << 32) | p[0];
+    }
+    // LDS byte address of that window's low half (for the row loop's own read instruction)
+    __device__ __forceinline__ uint32_t window_lds() const
+    {
+        return (uint32_t)(uintptr_t)ring + ((~(pos >> 5) & (RING_DWORDS - 1)) << 8);
+    }
+    // dwords resident at / after the dword of the next unread bit
+    __device__ __forceinline__ int32_t ahead() const
+    {
+        return (int32_t)((fillpos << 5) - (pos & ~31u)) >> 5;
+    }
     __device__ __forceinline__ void filled()
     {
         fillpos += CHUNK_DWORDS;
@@ -391,19 +461,24 @@ struct BitReader {
         ring_fill_sync(gsrc + (c >> 2), slot(fillpos), (fillpos & (RING_DWORDS - 1)) == 0);
         filled();
     }
-    __device__ __forceinline__ void ensure(uint32_t n)           // n dwords resident at/after next
+    // n <= 16 dwords resident from the dword of the next unread bit on (a fill overwrites the dwords 32 below its
+    // own: with n <= 16 never one at or after the reading position)
+    // (round 5: when ANY lane of the wave that is here has to fill, every lane that has room for a chunk fills with it.
+    //  A synchronous fill is a memory round trip for the whole wave, whoever asked for it; lanes that fill only when they
+    //  themselves run short do so at different fields of a header, and a restart header with six channels' parameters --
+    //  45 dwords through a 32-dword ring -- cost the wave a dozen round trips and more, 6 000 cycles each: "6 600 cycles
+    //  per read_signed" in round 4's stamps.  Filled together the lanes stay together: three or four.)
+    __device__ __forceinline__ void ensure(uint32_t n)
     {
-        while (__builtin_expect((int32_t)(fillpos - next) < (int32_t)n, 0))
+#if DVDA_WAVE_ENSURE
+        while (__builtin_expect(__any(ahead() < (int32_t)n), 0)) {
+            if (ahead() <= (int32_t)(RING_DWORDS - CHUNK_DWORDS))
+                fill_sync();
+        }
+#else
+        while (__builtin_expect(ahead() < (int32_t)n, 0))
             fill_sync();
-    }
-    __device__ __forceinline__ void advance()
-    {
-        ensure(1);
-        hi = lo;
-        lo = nx;
-        nx = ld(next);
-        next++;
-        ofs -= 32;
+#endif
     }
     // repositions the reader
     __device__ __forceinline__ void seek_byte(uint64_t byte_pos)
@@ -413,68 +488,48 @@ struct BitReader {
             fillpos = t & ~(uint32_t)(CHUNK_DWORDS - 1);        // outside the ring: restart it
             lo_valid = fillpos;
         }
-        next = t;
-        ensure(3);
-        hi = ld(t);
-        lo = ld(t + 1);
-        nx = ld(t + 2);
-        next = t + 3;
-        ofs = (uint32_t)(byte_pos & 3) * 8;
+        pos = (uint32_t)byte_pos << 3;
     }
-    __device__ __forceinline__ uint64_t tell_bits() const { return (uint64_t)(next - 3) * 32 + ofs; }
-    __device__ __forceinline__ uint32_t peek32() const
+    // the absolute bit position, rebuilt around a reference no further than 2^31 bits away
+    __device__ __forceinline__ uint64_t tell_near(uint64_t ref_bits) const
     {
-        return (uint32_t)(((((uint64_t)hi) << 32) | lo) << ofs >> 32);
+        return ref_bits + (uint64_t)(int64_t)(int32_t)(pos - (uint32_t)ref_bits);
+    }
+    // is the reader past this absolute bit position (no further than 2^31 bits away)?
+    __device__ __forceinline__ bool past(uint32_t end_bits_lo) const { return (int32_t)(pos - end_bits_lo) > 0; }
+    __device__ __forceinline__ uint32_t peek32()
+    {
+        ensure(2);
+        return (uint32_t)((window() << (pos & 31u)) >> 32);
     }
     // n in [0, 32]
     __device__ __forceinline__ uint32_t read(uint32_t n)
     {
         const uint32_t top = peek32();
-        const uint32_t v = n ? top >> (32 - n) : 0u;
-        ofs += n;
-        while (ofs >= 32)
-            advance();
-        return v;
+        pos += n;
+        return n ? top >> (32 - n) : 0u;
     }
-    // n in [0, 31], branch-free; the caller guarantees that the dword at `next` is resident
-    // (the row loop keeps 12 dwords ahead)
+    // n in [0, 31]; the caller guarantees that the two dwords at the reading position are resident
+    // (the row loop keeps 12 dwords ahead, the header parser tops up to HDR_RESIDENT before a group of fields)
     __device__ __forceinline__ uint32_t read_resident(uint32_t n)
     {
-        const uint32_t top = peek32();
-        const uint32_t v = (top >> 1) >> (31u - n);                  // n == 0 -> 0
-        const uint32_t o = ofs + n;
-        const bool step = o >= 32u;
-        const uint32_t cand = ld(next);
-        hi = step ? lo : hi;
-        lo = step ? nx : lo;
-        nx = step ? cand : nx;
-        next += step ? 1u : 0u;
-        ofs = o & 31u;
-        return v;
+        const uint32_t top = (uint32_t)((window() << (pos & 31u)) >> 32);
+        pos += n;
+        return (top >> 1) >> (31u - n);                              // n == 0 -> 0
     }
     // the same for a signed field (sign bit first, two's complement), n in [0, 31]
     __device__ __forceinline__ int32_t read_signed_resident(uint32_t n)
     {
-        const uint32_t top = peek32();
-        const int32_t v = n ? (int32_t)top >> ((32u - n) & 31u) : 0;
-        const uint32_t o = ofs + n;
-        const bool step = o >= 32u;
-        const uint32_t cand = ld(next);
-        hi = step ? lo : hi;
-        lo = step ? nx : lo;
-        nx = step ? cand : nx;
-        next += step ? 1u : 0u;
-        ofs = o & 31u;
-        return v;
+        const uint32_t top = (uint32_t)((window() << (pos & 31u)) >> 32);
+        pos += n;
+        return n ? (int32_t)top >> ((32u - n) & 31u) : 0;
     }
     __device__ __forceinline__ int32_t read_signed(uint32_t n)
     {
         if (n == 0)
             return 0;
         const int32_t v = (int32_t)peek32() >> (32 - n);         // sign bit first, two's complement
-        ofs += n;
-        while (ofs >= 32)
-            advance();
+        pos += n;
         return v;
     }
 };
@@ -775,9 +830,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
     rd.ring = &s_ring[wv][0][lane];
     rd.max_chunk = (uint32_t)(((a.total_bytes + 63) >> 6) << 4);  // the chunk holding the spare bytes
-    rd.hi = rd.lo = rd.nx = 0;
-    rd.ofs = 0;
-    rd.next = 3;
+    rd.pos = 0;
     rd.fillpos = 0;
     rd.lo_valid = 0;
     // parity / CRC-8 of the segment's substreams: checked byte-parallel by k_au_check (mlp_check.h) before this
@@ -785,8 +838,25 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t chk = active ? DVDA_AT(a.seg_check, (size_t)segi * 2u + sub, 2ull * a.caps.max_seg, BT_CHECK) : 0xFFFFFFFFu;
 
     // ---- per-lane decoder state (reference struct substream, src/mlp.c:103-115), in VGPRs
-    int32_t st[NS][8];                // FIR history: st[k][0] = most recent output
-    uint32_t cf[NS][4];               // FIR coefficients, int16 pairs, zero beyond the order
+    // FIR history, st(k, 0) = most recent output, two values per 64-bit register pair (the even one in the low
+    // half): the row loop shifts a slot's history with three v_pk_mov_b32 and one move instead of eight (round 5)
+    uint64_t sp[NS][4];
+    auto st_get = [&](int k, int j) -> int32_t {
+        return (j & 1) ? (int32_t)(uint32_t)(sp[k][j >> 1] >> 32) : (int32_t)(uint32_t)sp[k][j >> 1];
+    };
+    auto st_set = [&](int k, int j, int32_t v) {
+        if (j & 1)
+            sp[k][j >> 1] = (sp[k][j >> 1] & 0xFFFFFFFFull) | ((uint64_t)(uint32_t)v << 32);
+        else
+            sp[k][j >> 1] = (sp[k][j >> 1] & 0xFFFFFFFF00000000ull) | (uint32_t)v;
+    };
+    // FIR coefficients, zero beyond the order: one register each where the filter runs (round 5: the row loop
+    // unpacked eight int16 halves per sample); the chain parse pass only hands them on and keeps them packed
+    // (the four-slot instance of the two-wave layout has the registers: 5.52 -> 5.35 ms on the two-substream batch; the
+    //  six-slot instance does not: 3.64 -> 4.25 ms with the spills that buys)
+    constexpr bool CFU = (DVDA_CF_UNPACKED || NS <= 4) && !PARSE;
+    constexpr int CFW = CFU ? 8 : 4;
+    int32_t cf[NS][CFW];
     uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
                                       // fir_order<<19 | fir_shift<<23 | iir_shift<<27 | (codebook != 0)<<31
     int32_t sho[NS];                  // signed huffman offset (src/mlp.c:1152-1176)
@@ -796,10 +866,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #pragma unroll
     for (int k = 0; k < NS; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            st[k][j] = 0;
-#pragma unroll
         for (int j = 0; j < 4; j++)
+            sp[k][j] = 0;
+#pragma unroll
+        for (int j = 0; j < CFW; j++)
             cf[k][j] = 0;
         pk[k] = 24u << 2;                         // codebook 0, 24 LSBs
         sho[k] = -(1 << 23);
@@ -814,7 +884,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         for (int k = 0; k < NS; k++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                st[k][j] = a.init_fir[((size_t)sr.stream * 2 + sub) * 48 + k * 8 + j];
+                st_set(k, j, a.init_fir[((size_t)sr.stream * 2 + sub) * 48 + k * 8 + j]);
     }
     uint32_t flags = 0xFF;
     uint32_t block_size = 8;
@@ -834,7 +904,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     bool seg_iir = false;             // chain parse pass: some block of this segment ran IIR taps (seg_meta bit 9)
 
     uint64_t cur = sr.off;            // byte offset of the next frame
-    uint64_t ss_end_bit = 0;          // end of this lane's substream data (bits, absolute)
+    uint32_t ss_end_bit = 0;          // end of this lane's substream data (bits, absolute, modulo 2^32: compared by rd.past())
     uint32_t rows_left = 0;           // rows left in the current block
     bool in_frame = false;
     uint32_t frame_rows = 0;          // rows emitted in the current frame
@@ -911,6 +981,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #if defined(DVDA_EXP_STAMP)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = clock64();
+    unsigned long long hstamp_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long hstamp_t = 0;
 #endif
     for (;;) {
         DVDA_STAMP(5);
@@ -933,6 +1005,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         }
         gate_turn++;
         if (__builtin_expect(hdr_now, 0)) {
+#if defined(DVDA_EXP_STAMP)
+            hstamp_t = clock64();
+#endif
             // (a loop only because of dropped frames: a frame that carries a major sync with other stream
             //  parameters yields nothing and the next one is looked at, src/mlp.c:449-460)
             while (active && !in_frame) {
@@ -943,7 +1018,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         for (int k = 0; k < NS; k++)
 #pragma unroll
                             for (int j = 0; j < 8; j++)
-                                a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + seg_lane] = st[k][j];
+                                a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + seg_lane] = st_get(k, j);
                     }
                     if (GENERAL || PARSE)
                         a.seg_meta[seg_lane] = min_ch | (max_ch << 4) | (1u << 8) | (seg_iir ? 1u << 9 : 0u);
@@ -1026,7 +1101,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         }
                         end_prev = end;
                     }
-                    const uint64_t data0 = rd.tell_bits() >> 3;   // first substream byte
+                    const uint64_t data0 = rd.tell_near(cur * 8u) >> 3;   // first substream byte
                     const uint64_t ss_lo = data0 + my_start;
                     const uint64_t ss_hi = data0 + my_end;
                     if (bad || data0 + end_prev > frame_end || (check0 && my_end - my_start < 2)) {
@@ -1034,7 +1109,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         active = false;
                     } else {
                         const uint64_t data_hi = check0 ? ss_hi - 2 : ss_hi;
-                        ss_end_bit = data_hi * 8;
+                        ss_end_bit = (uint32_t)data_hi << 3;
                         rd.seek_byte(ss_lo);
                         // (parity + CRC-8 over [ss_lo, ss_hi - 2), src/mlp.c:675-706: k_au_check's verdict is
                         //  looked at when the access unit ends)
@@ -1047,6 +1122,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
             // (looked at on the segment's first few block headers only: the request comes within the first loop
             //  turn of the lane behind this one, or -- that lane's wave starting late -- not in time at all)
+            DVDA_HSTAMP(0);
             if (!GENERAL && !PARSE && active && frames_done < 2 && (frames_done | blocks_in_frame) != 0 &&
                 (__hip_atomic_load(&a.yield_req[segi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
                  __hip_atomic_load(&s_nchained[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= YIELD_LONELY)) {
@@ -1091,7 +1167,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     //  lanes at 64 bit positions ran on nearly every field -- a block header cost a lane 40 us.  A header's groups of
                     //  fields -- up to the first matrix, a matrix, a channel's parameters -- are at most 16 dwords each, and each group
                     //  starts with its own top-up)
-                    rd.ensure(HDR_RESIDENT);
+                    rd.ensure(HDR_BLOCK);
                     const bool restart = rd.read_resident(1) != 0;
                     hdr_restart = restart;
                     if (restart) {
@@ -1099,7 +1175,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         // (the whole wave tops its rings up HERE, together: a lane needs a refill once or twice per header, but over 64 lanes
                         //  at 64 different positions nearly every read of the parse below had some lane waiting for memory, and the wave
                         //  with it -- 70 memory round trips per header instead of a few)
-                        rd.ensure(HDR_RESIDENT);
+                        rd.ensure(HDR_RESTART);
                         const uint32_t h0 = rd.read_resident(14);           // 13u sync, 1u noise_type
                         rd.read_resident(16);                               // output_timestamp
                         min_ch = rd.read_resident(4);
@@ -1138,12 +1214,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         if (blocks_in_frame)
                             matrix_class_change = true;            // seed / matrix defaults change mid-frame
                     }
+                    DVDA_HSTAMP(1);
                     if (!have_restart && ok) {
                         ok = false;
                         err = ST_ENVELOPE;                         // parameters before any restart header
                     }
                     if (ok) {
                         // ---- decoding parameters (src/mlp.c:866-990); flags bit (7-i) = flags[i]
+                        if (restart)
+                            rd.ensure(HDR_BLOCK);
                         if (restart) {
                             flags = rd.read_resident(1) ? rd.read_resident(8) : 0xFFu;
                         } else if ((flags & 0x80u) && rd.read_resident(1)) {
@@ -1169,7 +1248,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             bypass_mask = 0;
                             outch_pack = 0;
                             for (uint32_t m = 0; m < matrix_len && ok; m++) {
-                                rd.ensure(HDR_RESIDENT);           // (a matrix is at most 145 bits)
+                                rd.ensure(HDR_MATRIX);             // (a matrix is at most 145 bits)
                                 const uint32_t oc = rd.read_resident(4);
                                 const uint32_t frac = rd.read_resident(4);
                                 if (oc > max_mat_ch || frac > 14) {
@@ -1240,9 +1319,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             qss_pack = 0;
                             qss_changed = true;
                         }
+                        DVDA_HSTAMP(2);
                         // ---- per-channel parameters (runtime loop: cold code)
                         for (uint32_t k = 0; k < nslots && ok; k++) {
-                            rd.ensure(HDR_RESIDENT);               // (a channel's parameters are at most 16 dwords)
+                            rd.ensure(HDR_FIR);
                             const uint32_t c = min_ch + k;
                             uint32_t pk_old = 0;
                             int32_t sho_old = 0;
@@ -1255,7 +1335,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                     if (PARSE) {
 #pragma unroll
                                         for (int j = 0; j < 4; j++)
-                                            cf_old[j] = cf[kk][j];
+                                            cf_old[j] = !CFU ? (uint32_t)cf[kk][CFU ? 0 : j]
+                                                             : (((uint32_t)cf[kk][CFU ? 2 * j : 0] & 0xFFFFu) |
+                                                                ((uint32_t)cf[kk][CFU ? 2 * j + 1 : 0] << 16));
                                     }
                                 }
                             uint32_t codebook = pk_old & 3u;
@@ -1303,6 +1385,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                     fir_shift = 0;
                                     new_fir = true;
                                 }
+                                rd.ensure(HDR_IIR);
                                 if (ok && (flags & 0x20u) && rd.read_resident(1)) {         // flags[2]
                                     // ---- IIR (src/mlp.c:1075-1119): cold storage in the workspace
                                     new_iir = true;
@@ -1325,6 +1408,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                                     v = (int32_t)((uint32_t)rd.read_signed_resident(cbits) << cshift);
                                                 ws[(size_t)j * a.total_lanes] = v;
                                             }
+                                            rd.ensure(HDR_IIR_STATE);
                                             if (rd.read_resident(1)) {
                                                 const uint32_t sbits = rd.read_resident(4), sshift = rd.read_resident(4);
                                                 if (sbits == 0) {
@@ -1403,8 +1487,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                             sho[kk] = nsho;
                                             if (new_fir) {
 #pragma unroll
-                                                for (int j = 0; j < 4; j++)
-                                                    cf[kk][j] = ncf[j];
+                                                for (int j = 0; j < 4; j++) {
+                                                    if constexpr (!CFU) {
+                                                        cf[kk][CFU ? 0 : j] = (int32_t)ncf[j];
+                                                    } else {
+                                                        cf[kk][CFU ? 2 * j : 0] = lo16(ncf[j]);
+                                                        cf[kk][CFU ? 2 * j + 1 : 0] = hi16(ncf[j]);
+                                                    }
+                                                }
                                             }
                                         }
                                     iir_any = (iir_any & ~(1u << k)) | ((iir_order ? 1u : 0u) << k);
@@ -1444,6 +1534,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         }
                     }
                 }
+                DVDA_HSTAMP(3);
                 if (!have_restart && ok) {
                     ok = false;
                     err = ST_ENVELOPE;
@@ -1549,6 +1640,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
+        if (hdr_now)
+            DVDA_HSTAMP(4);
         if (!WSPEC && !__any(active))
             break;                     // (two-wave layout: the block leaves together, at the exchange)
         DVDA_STAMP(0);
@@ -1558,14 +1651,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // (cold top-up), hash what the parser has passed, and fetch the next 64-byte chunk now
         // so that it lands in the ring while this row is being decoded.
         if (active) {
-            if ((int32_t)(rd.fillpos - rd.next) < 12)
+            if (rd.ahead() < 12)
                 DVDA_COV(14);                // synchronous ring top-up inside the row loop
             rd.ensure(12);
         }
         DVDA_STAMP(7);
         // both 64-byte halves of a 128-byte line are requested in consecutive rows, while the line
         // is still in L2 (one HBM fetch per line); a new line is started when half the ring is free
-        const int32_t ahead_now = (int32_t)(rd.fillpos - rd.next);
+        const int32_t ahead_now = rd.ahead();
         const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS);
         // Four registers each, written by the loads below and read under the same `pf`.  They must hold a DEFINED
         // value on the lanes that do not load.  Zero-filling them with instructions made the compiler wait for
@@ -1602,7 +1695,17 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         const uint32_t xstride = (ILV && ilv_direct) ? 64u : (uint32_t)OUT_ROWS * 64u;       // channel to channel
         int32_t *const xrow = xtile + ((ILV && ilv_direct) ? xslot * (6u * 64u) : xslot * 64u);
         int32_t *const xw_mine = xrow + min_ch * xstride;
-        auto row_head = [&]() {
+        // UNI: every lane of the wave that decodes a row this turn carries the same number of channels, nu of them
+        // (all the lanes of a wave of one stream shape -- what lane packing makes of any batch): the slot loop then runs
+        // on a scalar count, and nothing in it is selected by "does this lane have the slot": a slot's parameters, its
+        // history (shifted by register pairs) and its value are the lane's own in every lane.  Otherwise slots beyond
+        // a lane's channel count read 0 bits and keep their state, select by select (rounds 1-4: always).
+        auto row_head = [&](auto uni_c) {
+            // (NU != 0: the wave's count, a compile-time constant -- straight-line code from the first slot to the last;
+            //  with a scalar count and a branch behind every slot the compiler moved the slot's whole history back into
+            //  other registers at every join)
+            constexpr int NU = decltype(uni_c)::value;
+            constexpr bool UNI = NU != 0;
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
             // all of the row's bypassed LSBs (at most one per matrix) are cut from the window at once
             // and dealt to their matrices in stream order -- straight-line, no per-bit read
@@ -1624,6 +1727,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                 }
             }
+            uint64_t win = rd.window();
             uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
             // IIR taps anywhere in the wave (sequential pass only: in the fast pass such a segment is ST_COLD)
             const bool wave_iir = GENERAL && __any(iir_any != 0);
@@ -1631,58 +1735,65 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             for (int k = 0; k < NS; k++) {
                 // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
-                const bool in = (uint32_t)k < nslots;
-                if (k >= 2 && !__any(in)) {
-                    if constexpr (!WSPEC)
-                        val[k] = 0;
-                    continue;
+                const bool in = UNI || (uint32_t)k < nslots;
+                uint64_t m_in = 0;
+                if constexpr (UNI) {
+                    if (k >= NU) {
+                        if constexpr (!WSPEC)
+                            val[k] = 0;
+                        continue;
+                    }
+                } else {
+                    if (k >= 2 && !__any(in)) {
+                        if constexpr (!WSPEC)
+                            val[k] = 0;
+                        continue;
+                    }
+                    // (the selects below take this mask from an SGPR pair, as inline asm: left to the compiler they become
+                    //  runs of v_cndmask_b32_e32 on vcc, which issue at a tenth of the rate -- profiles/r05_valu_issue_rates.txt;
+                    //  the mask is made here, a slot's length ahead of its first use: tools/hazard_check.py)
+                    m_in = __builtin_amdgcn_ballot_w64(in);
+                    asm volatile("" : "+s"(m_in));
                 }
-                const uint32_t pkk = in ? pk[k] : 0u;
+                const uint32_t pkk = UNI ? pk[k] : (in ? pk[k] : 0u);
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
                 const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
-                // the two dwords behind the window: one address, one two-address LDS read (mirror plane)
-                const uint32_t *look = rd.slot(rd.next);
-                const uint32_t cand1 = __builtin_bswap32(look[0]), cand2 = __builtin_bswap32(look[64]);
-                const uint64_t win = (((uint64_t)rd.hi) << 32) | rd.lo;
-                const uint32_t top = (uint32_t)((win << rd.ofs) >> 32);
+                // the symbol is cut from the 64 bits at the reading position (a code of at most 9 bits and at most 24
+                // LSBs behind an offset of at most 31)
+                if constexpr (UNI && DVDA_EARLY_WINDOW) {
+                    if (k > 0)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win));      // (the read placed by hand in the slot before)
+                }
+                const uint32_t ofs = rd.pos & 31u;
+                const uint32_t top = (uint32_t)((win << ofs) >> 32);
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);      // bit 8 of the 9-bit peek
                 asm volatile("" : "+s"(m_esc));
                 const uint32_t e = huff_decode_m(cb, top >> 23, m_esc, bmask);
                 const uint32_t msb = e & 0xFFu;
                 const uint32_t len = e >> 8;
                 msb_or |= msb;                            // valid values are < 0x20
-                const uint32_t o2 = rd.ofs + len;
+                const uint32_t o2 = ofs + len;
+                rd.pos += len + lb;
+                // ... and the next symbol's window is asked for at once: the read is in flight while this symbol's
+                // LSBs are cut and its value goes through the filter.  With the lanes' slot count a compile-time constant
+                // the read is placed by hand, as early as the position is known -- left to the compiler it sank into the
+                // filter's multiply-adds, a dozen instructions in front of its use, and a lone wave waited 140 cycles per
+                // symbol for LDS (tools/stamp_run.py) -- and waited for by hand at the next slot's top (the compiler does
+                // not count an asm's LDS read: its own waits can only come out longer; tools/hazard_check.py checks that
+                // nothing touches the pair in between).  The last slot asks for nothing.
+                uint64_t win_next = 0;
+                if constexpr (UNI && DVDA_EARLY_WINDOW) {
+                    if (k + 1 < NU)
+                        // (the slot's newest history pair and the window in hand ride through the asm: the filter and the
+                        //  cutting of the LSBs below start from them, so the scheduler cannot put either in front of the read)
+                        asm volatile("ds_read2st64_b32 %0, %3 offset1:1" : "=v"(win_next), "+v"(sp[k][0]), "+v"(win) : "v"(rd.window_lds()));
+                } else {
+                    win_next = rd.window();                       // (the last slot's read serves nobody: dropped by the compiler)
+                }
                 const uint32_t top2 = (uint32_t)((win << o2) >> 32);
                 const uint32_t lsbv = (top2 >> 1) >> (31u - lb);          // lb == 0 -> 0
-                const uint32_t o3 = o2 + lb;                              // <= 31 + 9 + 24 = 64
-                const uint32_t adv = o3 >> 5;                             // 0, 1 or 2 dwords consumed
-                // a symbol rarely spans two whole dwords (ofs + code + LSBs >= 64): the one-dword step is
-                // the straight path, the second step sits behind a wave-uniform test
-                // (the compare is issued here and the selects a few instructions later: back to back the
-                //  first select waits two states for it; distance verified by tools/hazard_check.py)
-                uint64_t step = __builtin_amdgcn_ballot_w64(adv != 0);
-                asm volatile("" : "+s"(step));
                 const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
-                // (three-operand form: with the result tied to the first source the compiler copied
-                //  hi / lo / nx before every select, they are still needed by the rare second step)
-                uint32_t nh, nl, nn;
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nh) : "v"(rd.hi), "v"(rd.lo), "s"(step));
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nl) : "v"(rd.lo), "v"(rd.nx), "s"(step));
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nn) : "v"(rd.nx), "v"(cand1), "s"(step));
-                if (__builtin_expect(__any(adv == 2), 0)) {
-                    const bool two = adv == 2;
-                    if (two && in)
-                        DVDA_COV(8);                 // two-dword window step
-                    nh = two ? rd.nx : nh;
-                    nl = two ? cand1 : nl;
-                    nn = two ? cand2 : nn;
-                }
-                rd.hi = nh;
-                rd.lo = nl;
-                rd.nx = nn;
-                rd.next += adv;
-                rd.ofs = o3 & 31u;
                 int32_t value;
                 if constexpr (PARSE) {
                     // chain parse pass: the residual itself is the product (the filter pass runs the recurrence)
@@ -1691,14 +1802,20 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     (void)wave_iir;
                 } else {
                 // ---- FIR/IIR reconstruction (src/mlp.c:1278-1300)
-                int64_t acc0 = (int64_t)lo16(cf[k][0]) * (int64_t)st[k][0];
-                int64_t acc1 = (int64_t)hi16(cf[k][0]) * (int64_t)st[k][1];
-                acc0 += (int64_t)lo16(cf[k][1]) * (int64_t)st[k][2];
-                acc1 += (int64_t)hi16(cf[k][1]) * (int64_t)st[k][3];
-                acc0 += (int64_t)lo16(cf[k][2]) * (int64_t)st[k][4];
-                acc1 += (int64_t)hi16(cf[k][2]) * (int64_t)st[k][5];
-                acc0 += (int64_t)lo16(cf[k][3]) * (int64_t)st[k][6];
-                acc1 += (int64_t)hi16(cf[k][3]) * (int64_t)st[k][7];
+                auto tap = [&](int j) -> int32_t {
+                    if constexpr (CFU)
+                        return cf[k][CFU ? j : 0];
+                    else
+                        return (j & 1) ? hi16((uint32_t)cf[k][CFU ? 0 : j >> 1]) : lo16((uint32_t)cf[k][CFU ? 0 : j >> 1]);
+                };
+                int64_t acc0 = (int64_t)tap(0) * (int64_t)st_get(k, 0);
+                int64_t acc1 = (int64_t)tap(1) * (int64_t)st_get(k, 1);
+                acc0 += (int64_t)tap(2) * (int64_t)st_get(k, 2);
+                acc1 += (int64_t)tap(3) * (int64_t)st_get(k, 3);
+                acc0 += (int64_t)tap(4) * (int64_t)st_get(k, 4);
+                acc1 += (int64_t)tap(5) * (int64_t)st_get(k, 5);
+                acc0 += (int64_t)tap(6) * (int64_t)st_get(k, 6);
+                acc1 += (int64_t)tap(7) * (int64_t)st_get(k, 7);
                 int64_t acc = acc0 + acc1;
                 bool iir_on = false;
                 if (__builtin_expect(wave_iir, 0)) {
@@ -1710,11 +1827,28 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 const int32_t ssum = (int32_t)(acc >> shift);
                 value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
-                // history moves only for channels this lane really carries
+                if constexpr (UNI) {
+                    // the history moves up by one value: pair j takes the odd half of pair j - 1 and its own even half
+                    // (v_pk_mov_b32: low result = the half of source 0 that op_sel[0] names, high result = the half of
+                    //  source 1 that op_sel[1] names)
+                    asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][3]) : "v"(sp[k][2]));
+                    asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][2]) : "v"(sp[k][1]));
+                    asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][1]) : "v"(sp[k][0]));
+                    sp[k][0] = (sp[k][0] << 32) | (uint32_t)value;
+                } else {
+                    // history moves only for channels this lane really carries
+                    uint32_t h[8];
 #pragma unroll
-                for (int j = 7; j > 0; j--)
-                    st[k][j] = in ? st[k][j - 1] : st[k][j];
-                st[k][0] = in ? value : st[k][0];
+                    for (int j = 0; j < 8; j++)
+                        h[j] = (uint32_t)st_get(k, j);
+#pragma unroll
+                    for (int j = 7; j > 0; j--)
+                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(h[j]) : "v"(h[j - 1]), "s"(m_in));
+                    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(h[0]) : "v"((uint32_t)value), "s"(m_in));
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        sp[k][j] = ((uint64_t)h[2 * j + 1] << 32) | h[2 * j];
+                }
                 if (__builtin_expect(wave_iir, 0)) {
                     if (iir_on)
                         iir_push(a.iir_ws + (size_t)(k * 16) * a.total_lanes + gl, a.total_lanes,
@@ -1725,14 +1859,26 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     if (in)
                         xw_mine[k * xstride] = value;     // straight into the tile
                 } else {
-                    val[k] = in ? value : 0;
+                    val[k] = UNI ? value : (in ? value : 0);
                 }
+                win = win_next;
             }
             if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {
                 status |= ST_HUFFMAN;
                 active = false;
             }
             DVDA_STAMP(2);
+        };
+        // (called by the lanes that decode a row this turn)
+        auto row_head_any = [&]() {
+            const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)nslots);
+            const bool uni = __all(nslots == nu);
+            if (uni && nu == (uint32_t)NS)
+                row_head(std::integral_constant<int, NS>{});
+            else if (NS > 2 && uni && nu == 2u)
+                row_head(std::integral_constant<int, (NS > 2 ? 2 : 0)>{});
+            else
+                row_head(std::integral_constant<int, 0>{});
         };
         auto row_tail = [&](int32_t (&ch)[MAXCH]) {
             if (owner && (!adopt || active)) {
@@ -1826,7 +1972,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         status |= ST_TIMING;   // the general pass decodes such a stream in order
                         active = false;
                     }
-                    if (rd.tell_bits() > ss_end_bit) {
+                    if (rd.past(ss_end_bit)) {
                         status |= ST_EOF;
                         active = false;
                     }
@@ -1898,7 +2044,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                     in_frame = false;
                     frames_done++;
-                } else if (rd.tell_bits() > ss_end_bit) {
+                } else if (rd.past(ss_end_bit)) {
                     status |= ST_EOF;
                     active = false;
                 }
@@ -1910,7 +2056,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         const bool in_row = active && (!HDR_GATE || rows_left != 0) && (!adopt || it >= (uint32_t)OUT_ROWS);
         if constexpr (WSPEC) {
             if (in_row)
-                row_head();
+                row_head_any();
             if (lends) {
                 // ---- this turn's row of the other lane's tile: there or not, what it is rematrixed with
                 s_tag[WSPEC ? ws_grp : 0][(it / OUT_ROWS) & 1u][it & (OUT_ROWS - 1)][WSPEC ? lane : 0] =
@@ -1955,7 +2101,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 row_tail(ch);
             }
         } else if (in_row) {
-            row_head();
+            row_head_any();
             if (PAIRED && PARSE) {
                 // substreams of one segment sit in adjacent lanes; the residuals go straight into the tile column of
                 // the lane that flushes it (the last substream's: the odd lane of a two-substream segment)
@@ -2017,6 +2163,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             DVDA_STAMP(6);
         }
 #endif
+        // (round 5: the wait for the chunk, written out and NOT under `pf`.  Left to the compiler it sits inside the
+        //  branch below, and the path around that branch -- no lane loaded -- reaches the top of the next turn with,
+        //  for all the compiler can tell, loads still on their way into p0..p3: it then put an s_waitcnt vmcnt(0) in
+        //  front of the asm that defines them, at the top of EVERY turn, where it waits for nothing of the kind --
+        //  but for the PCM stores issued a few instructions earlier, a store's whole round trip every flush: 12 % of
+        //  a wave's time, tools/stamp_run.py.  vmcnt(0), lgkmcnt / expcnt not waited for: 0x0F70)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (pf) {
             ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3, (rd.fillpos & (RING_DWORDS - 1)) == 0);
             rd.filled();
@@ -2024,7 +2177,35 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
         //      older memory operation, so stores issued before it would be waited for as well; issued
         //      here they have a whole row to drain before the next wait
-        if (!GENERAL && !PARSE && ILV && flush) {
+        // ---- round 5: the wave stores together.  A lane's flush is 96 contiguous bytes, but as six 16-byte stores of its
+        //      own it is 64 lanes x 6 pieces in 64 places per instruction, and it is requests, not bytes, that the memory
+        //      side runs out of (tools/probe/mem_pattern.hip: this kernel's loads and stores alone, without a single
+        //      decode instruction, take 2.6 us per PCM frame and wave -- what k_decode took -- and 2.1 us when the lanes
+        //      of a wave work together on each other's runs).  When every lane of the wave flushes this turn (lanes in
+        //      lockstep: what lane packing makes of a batch) and the tile is in output order, lane l stores piece
+        //      q mod 6 of lane q / 6's run, q = 64 i + l in the i-th of six instructions: an instruction covers ten
+        //      or eleven runs whole.
+        bool coop_out = false;
+        if constexpr (ILV && !GENERAL && !PARSE) {
+            if (DVDA_COOP_OUT && ilv_direct && a.wav_bits == 0u)
+                coop_out = __ballot(flush) == ~0ull;
+        }
+        if (coop_out) {
+            const int32_t *const dsrc = a.pcm + out_base + flush_row * 6u;
+            const uint32_t d_lo = (uint32_t)(uintptr_t)dsrc, d_hi = (uint32_t)((uintptr_t)dsrc >> 32);
+            const int32_t *const T0 = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][0];
+#pragma unroll
+            for (uint32_t it6 = 0; it6 < 6u; it6++) {
+                const uint32_t q = it6 * 64u + (uint32_t)lane;
+                const uint32_t o = (q * 43691u) >> 18;               // q / 6 for q < 384
+                const uint32_t pc = q - o * 6u;
+                const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64), b_hi = (uint32_t)__shfl((int)d_hi, (int)o, 64);
+                int32_t *const od = reinterpret_cast<int32_t *>(((uint64_t)b_hi << 32) | b_lo) + pc * 4u;
+                const int32_t *const Tp = T0 + pc * (4 * 64) + o;    // (the tile in output order: value v of a run in plane v)
+                DVDA_STORE_V4_PAD(od, Tp[0], Tp[64], Tp[128], Tp[192]);
+            }
+        }
+        if (!GENERAL && !PARSE && ILV && flush && !coop_out) {
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
             const int32_t *Tl = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
@@ -2209,6 +2390,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     if (lane == 0 && a.dbg)
         for (int i = 0; i < 8; i++)
             atomicAdd(&a.dbg[i + (WSPEC ? 8 * (int)ws_last : 0)], stamp_acc[i]);      // two-wave layout: per role
+    if (!WSPEC && lane == 0 && a.dbg)
+        for (int i = 0; i < 5; i++)
+            atomicAdd(&a.dbg[8 + i], hstamp_acc[i]);
 #endif
     if (!GENERAL && !PARSE && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
         // FIR history at the segment's end, for a following segment that depends on it
@@ -2216,7 +2400,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         for (int k = 0; k < NS; k++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st[k][j];
+                a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st_get(k, j);
         a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8);
     }
     // ---- what the passes behind the fast pass will have to do (the host reads the summary): summed over the
@@ -2360,9 +2544,7 @@ __global__ __launch_bounds__(64) void k_selftest_bits(const uint8_t *bytes, uint
     rd.gsrc = reinterpret_cast<const uint4 *>(bytes);
     rd.ring = &s_ring[0][0];
     rd.max_chunk = (uint32_t)((((uint64_t)n_bytes + 63) >> 6) << 4);
-    rd.hi = rd.lo = rd.nx = 0;
-    rd.ofs = 0;
-    rd.next = 3;
+    rd.pos = 0;
     rd.fillpos = 0;
     rd.lo_valid = 0;
     rd.seek_byte(0);

@@ -59,7 +59,10 @@ for w in which:
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=n_aus, profile=1, features=SF["CHAINED"])
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1)
         run(w, flat, offs, sizes, frames, np.full(1, 6), n_aus // 8 + 8, 1, "interleaved", steps=20)
-    elif w == "headline":
+    elif w.startswith("headline"):
+        # headline = the bench batch (4 096 titles: two rounds of two waves per SIMD); headlineN = N x 512 titles, i.e.
+        # N x 512 waves of k_decode on the chip's 1 024 SIMDs (headline2: one wave per SIMD, headline4: two)
+        half = int(w[8:] or 8)
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=512)
-        flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
-        run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 64, 4, "interleaved")
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 512)
+        run(w, flat, offs, sizes, frames, np.full(512, 6), 512 * half * 64, half, "interleaved")

@@ -4,7 +4,7 @@ wave's loop iteration spends its cycles (shares, not absolute times)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["DVDA_MLP_HIP_LIB"] = os.path.join(ROOT, "libdvd-audio_amd", "exp_stamp.so")
+os.environ["DVDA_MLP_HIP_LIB"] = os.path.join(ROOT, "libdvd-audio_amd", os.environ.get("STAMP_LIB", "exp_stamp.so"))
 import numpy as np, torch
 import libdvd_audio_amd as pkg
 syn, hip = pkg.synth, pkg.hipdec
@@ -28,9 +28,9 @@ elif len(sys.argv) > 1 and sys.argv[1] in ("fuzz_fast", "fuzz_all"):
     n = len(sizes)
 else:
     SS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048       # titles: 2 048 = two waves per SIMD, 512 = half of the SIMDs one
     cfg = syn.make_cfg(assignment=12, rate_code=1, n_aus=512, n_substreams=SS)
-    flat, offs, sizes, frames = syn.batch(cfg, 1, 2048)
-    n = 2048
+    flat, offs, sizes, frames = syn.batch(cfg, 1, n)
     nchs = np.full(n, 6, np.int64)
     nseg = n * 64
 dev = torch.device("cuda", 0)
@@ -55,7 +55,13 @@ for role in range(2 if SS == 2 else 1):
     for nme, x in zip(names, v):
         print("  %-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / max(v.sum(), 1), x))
 v = np.array(list(out)[8:16], dtype=np.float64)
-if v.sum() > 0:
+if SS == 1 and v.sum() > 0 and n > 1024:
+    t = np.array(list(out)[0:8], dtype=np.float64).sum()
+    print("inside the header phase (lane 0's clock; shares of the wave's whole time):")
+    for nme, x in zip(["frame header + substream info", "restart header", "parameters up to the channels", "channels' parameters",
+                       "behind the parse"], v):
+        print("  %-32s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / max(t, 1), x))
+elif v.sum() > 0:
     print("cooperative kernel (k_coop), shares of its waves' time:")
     for nme, x in zip(["staging + framing", "block headers", "symbol scan", "residuals", "filter", "meeting + rematrix + output",
                        "loop frame", "-"], v):
