@@ -915,7 +915,8 @@ def plumbing_rank(args, rank, world):
         mine = np.arange(len(sizes))
     rows = int(frames[mine].sum())
     summ = pkg.shard.reduce_summary(dist if world > 1 else None, torch.device("cpu"), rows, rows * 6,
-                                    int(sizes[mine].sum()), 0, len(mine), 0.001 * (rank + 1), checked=False)
+                                    int(sizes[mine].sum()), 0, len(mine), 0.001 * (rank + 1), checked=False,
+                                    per_rank=(0.0, 0.0, 1.0 * (rank + 1)))
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "Msamples/s", "n_gpus": world, "plumbing_only": True,
                           "scaling": "strong" if args.workload == "c4" else "weak",
@@ -926,7 +927,10 @@ def plumbing_rank(args, rank, world):
                           "ranks": {"seconds_min": summ["seconds_min"], "compressed_bytes_max": summ["bytes_max"],
                                     "compressed_bytes_min": summ["bytes_min"],
                                     "load_imbalance": round(summ["bytes_max"] * world / max(summ["compressed_bytes"], 1), 4),
-                                    "bit_exact_on_every_rank": summ["all_verified"]}}))
+                                    "bit_exact_on_every_rank": summ["all_verified"],
+                                    "world_size": summ["world_size"], "ranks_counted": summ["ranks_counted"],
+                                    "per_rank": [{"rank": r, "k_decode_ms": v[0], "roofline_frac": v[1], "ms_per_step": v[2]}
+                                                 for r, v in enumerate(summ["per_rank"])]}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1077,9 +1081,12 @@ def main():
     # ---- whole-job aggregate: the path's one collective is this summary (RCCL all-reduce of a
     #      few words over xGMI; nothing on the data path is exchanged)
     checksum = int(b.d_pcm.to(torch.int64).sum().item())
+    # (every rank's own k_decode time and roofline fraction travel with the summary: an N > 1 line carries them per rank)
+    rank_frac = (b.comp_bytes + 4.0 * b.samples) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0
     summ = pkg.shard.reduce_summary(dist if world > 1 else None, dev if backend == "nccl" else torch.device("cpu"),
                                     b.rows_total, b.samples, b.comp_bytes, 0, checksum, elapsed,
-                                    verified=bool(bit_exact), checked=checked != 0)
+                                    verified=bool(bit_exact), checked=checked != 0,
+                                    per_rank=(kernel_ms, rank_frac, elapsed / args.steps * 1e3))
     elapsed_max = summ["seconds"]
     job_samples = float(summ["samples"])
 
@@ -1144,7 +1151,12 @@ def main():
                             "compressed_bytes_max": summ["bytes_max"], "compressed_bytes_min": summ["bytes_min"],
                             "load_imbalance": round(summ["bytes_max"] / mean_bytes, 4) if mean_bytes else None,
                             "bit_exact_on_every_rank": summ["all_verified"],
-                            "titles_checked_per_rank": checked}
+                            "titles_checked_per_rank": checked,
+                            # (round 5: the line says by itself that N ranks took part -- the process group's size and the
+                            #  all-reduced count of ranks -- and what each of them measured)
+                            "world_size": summ["world_size"], "ranks_counted": summ["ranks_counted"],
+                            "per_rank": [{"rank": r, "k_decode_ms": round(v[0], 4), "roofline_frac": round(v[1], 5),
+                                          "ms_per_step": round(v[2], 4)} for r, v in enumerate(summ["per_rank"])]}
             out["config"]["bit_exact"] = (bool(bit_exact) and bool(summ["all_verified"])) if checked else None
         if serial:
             out["serial_step"] = serial

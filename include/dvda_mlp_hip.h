@@ -89,6 +89,9 @@ extern "C" {
 #define DVDA_ST_YIELD        (1u << 27)  /* the segment in front of a chained one (or one of the few segments
                                             without a chain among many with one), decoded by the chain passes
                                             with them instead of alone by the fast pass (informational)  */
+#define DVDA_ST_DEVICE       (1u << 29)  /* streaming tier only: a HIP runtime call failed inside a step -- not a
+                                            property of the stream; the decoder stops (it does not fall back to the
+                                            batch tier on the same device without a word)                     */
 /* DVDA_ST_CHAINED, _MIDFRAME, _COLD, _YIELD, _TIMING and _SEQ are raised by the fast pass and then decoded exactly by
  * the passes behind it (chain passes: parse in parallel, the filter recursion alone per channel, rematrix
  * in parallel; or the sequential pass); they stay set as information.  Bits that do not invalidate the PCM: */
@@ -222,6 +225,12 @@ typedef struct dvda_mlp_multi_summary {
     uint64_t compressed_bytes_max_device; /* the largest share one device entry got (load balance)        */
     uint32_t streams_with_errors;         /* streams whose status has a bit outside DVDA_ST_BENIGN        */
     uint32_t devices;                     /* device entries the list was dealt to                         */
+    /* (round 5) what a caller needs to judge a run on N devices without a profiler: wall time of the slowest and the
+     * fastest device entry (copy in + index + decode + copy out, its host thread's clock), and the load imbalance
+     * of the deal = largest share of the compressed bytes / mean share (1.0 = even)                              */
+    double device_ms_max;
+    double device_ms_min;
+    double imbalance;
 } dvda_mlp_multi_summary;
 
 /* part_of[i] = which of `parts` parts stream i (sizes[i] bytes) goes to */
@@ -231,6 +240,8 @@ int dvda_mlp_hip_create_multi(dvda_mlp_hip_multi **multi, const int *devices, ui
                               uint32_t max_streams, uint32_t max_segments);
 void dvda_mlp_hip_destroy_multi(dvda_mlp_hip_multi *multi);
 uint32_t dvda_mlp_hip_multi_devices(const dvda_mlp_hip_multi *multi);
+/* wall time (ms) the last dvda_mlp_hip_decode_multi spent on device entry `entry`, and the compressed bytes it got */
+int dvda_mlp_hip_multi_device_time(const dvda_mlp_hip_multi *multi, uint32_t entry, double *ms, uint64_t *bytes);
 /* Decodes n_streams host streams (streams[i], lengths[i] bytes) and returns when all of them are done.  pcm[i]
  * receives stream i in `layout` (DVDA_PCM_*): planar = [channel][capacity_frames[i]] int32, interleaved =
  * [frame][channel] int32, WAV24 / WAV16 = the packed payload; capacity_frames[i] = PCM frames per channel pcm[i]

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     __shared__ CoopSub s_sub[2];
     __shared__ uint32_t s_err[2];
     __shared__ uint32_t s_yield;
+    __shared__ uint32_t s_res_status;       // streaming tier: the call's status, both substreams' waves (see the end)
     uint8_t *const s_wav = reinterpret_cast<uint8_t *>(s_stage);    // packed WAV payload of one output step (64 * 6 * 3
                                                                     // bytes): the unit's bytes are done with by then
     static_assert(64 * 6 * 3 + 16 <= COOP_STAGE_DW * 4, "the WAV staging bytes fit the stage");
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     }
     if (threadIdx.x < 2)
         s_err[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
+        s_res_status = 0;
     // (channels no substream of the stream covers -- a gap between the two substreams, fewer coded channels than the
     //  assignment has -- reach the rematrix and the planes as zeros, the same on every run, not as what an earlier
     //  workgroup left in LDS; every wave that stays clears the whole tile, the barrier below orders it for two)
@@ -266,7 +269,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
     CoopState *const cst = RESUME ? a.coop_state + sub : nullptr;
     CoopResult *const cres = RESUME ? a.coop_result : nullptr;
     if constexpr (RESUME) {
-        if (threadIdx.x == 0) {
+        // (the result record lives in mapped host memory: every word of it is written by ONE lane -- lane 0 of the last
+        //  substream's wave -- with plain stores, in program order)
+        if (is_last && lane == 0) {
             cres->status = 0;
             cres->frames_out = cres->rows_written = cres->sync_seen = 0;
         }
@@ -1160,8 +1165,12 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
             cst->sc[12] = nslots;
             cst->sc[13] = have_restart ? 1u : 0u;
             cst->valid = 1u;
+            // (round 5: the two substreams' waves used to OR their status into the record itself -- a device atomic
+            //  on host memory, which a platform without PCIe atomics drops without a word: a failed parity / CRC-8 /
+            //  timing check would then never have reached mlp_stream.c.  They meet in LDS now, and one plain store
+            //  carries the result)
             if (status)
-                atomicOr(&cres->status, status);
+                atomicOr(&s_res_status, status);
             if (is_last) {
                 cres->frames_out = frames_out;
                 cres->rows_written = rows_written;
@@ -1176,6 +1185,10 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                 cst->ih[lane][j] = ih[j];
             }
         }
+        if (two)
+            __syncthreads();                // (both substreams' waves are here: they left the unit loop together)
+        if (is_last && lane == 0)
+            cres->status = *(volatile uint32_t *)&s_res_status;
         return;
     }
     // ---- what a following segment (or a later call) continues from: the FIR history at the segment's end

@@ -82,6 +82,10 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_EARLY_WINDOW
 #define DVDA_EARLY_WINDOW 1
 #endif
+// the one-shape instance of the fast pass (k_decode<.., FIX>)
+#ifndef DVDA_FIX_INSTANCE
+#define DVDA_FIX_INSTANCE 0
+#endif
 #ifndef DVDA_WAVE_ENSURE
 #define DVDA_WAVE_ENSURE 1
 #endif
@@ -582,10 +586,17 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 // (src/dvd-audio.c:781-792) -- instead of planar pcm[off + wave_channel * stride + frame], the order
 // decode_packet appends to `samples` (src/mlp.c:527-533).  A lane's flush is then ONE contiguous
 // run of 16 * channels bytes (whole 32-byte sectors) instead of six 16-byte pieces in six places.
-template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false>
+// FIX (fast pass, one lane per segment; round 5): the instance for batches of ONE stream shape whose streams carry NS
+// channels in one substream -- what the headline batch is, and any batch of titles of one kind.  Its row loop has the
+// one slot count and nothing else: no second and third version of the slot loop for lanes that disagree, none of the
+// register copies the compiler puts where those versions meet.  A lane that finds another count in a restart header
+// hands its segment to the chain passes (ST_COLD), as a lane of the two-wave kernel with too many channels does.  The
+// host launches both instances; the lanes of the one that is not meant leave at once.
+template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false, bool FIX = false>
 __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     static_assert(!(GENERAL && PARSE), "one mode at a time");
+    static_assert(!FIX || (!PAIRED && !GENERAL && !PARSE), "the one-shape instance is a fast-pass instance");
     static_assert(!GENERAL || PAIRED, "the sequential pass always runs as lane pairs");
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     // fast pass: the batch holds no stream of this kernel's class (set by the index): whole grid exits
@@ -718,7 +729,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         active = false;                                         // reported by the index
     if (active && (sub >= S || sr.nframes == 0))
         active = false;
-    const bool mine = GENERAL || !a.only_S || S == a.only_S;    // else: the other kernel's stream, hands off
+    bool mine = GENERAL || !a.only_S || S == a.only_S;          // else: the other kernel's stream, hands off
+    if (!PAIRED && !GENERAL && !PARSE && DVDA_FIX_INSTANCE) {
+        // one stream shape in the batch (k_link looked) and it is this instance's: the one-shape instance's lane, else
+        // the general instance's
+        const bool one_shape = *a.hetero == 0u && S == 1u && nch_out == (uint32_t)NS && a.only_S == 1u;
+        if (one_shape != FIX)
+            mine = false;
+    }
     if (!mine)
         active = false;
     if (active && S > L) {
@@ -1209,6 +1227,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             // history before it is decided there -- and the segment goes to the chain passes
                             if (NS < 6 && nslots > (uint32_t)NS)
                                 too_wide = true;
+                            if (FIX && nslots != (uint32_t)NS)
+                                too_wide = true;            // (not the count this instance's row loop is made for)
                             have_restart = true;
                         }
                         if (blocks_in_frame)
@@ -1871,6 +1891,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         };
         // (called by the lanes that decode a row this turn)
         auto row_head_any = [&]() {
+            if constexpr (FIX) {
+                row_head(std::integral_constant<int, NS>{});
+                return;
+            }
             const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)nslots);
             const bool uni = __all(nslots == nu);
             if (uni && nu == (uint32_t)NS)

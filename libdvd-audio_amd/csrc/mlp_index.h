@@ -380,6 +380,13 @@ __device__ __forceinline__ void chase_one(uint32_t i, const uint8_t *__restrict_
         r.end = off;
     } else {
         r.sync = packed_sync_at(bytes, off);
+        // (round 5) Is this candidate one of the stream's own -- its parameters those of the major sync the stream begins
+        // with (what the reference latches, src/mlp.c:449-460)?  Then its walk goes through ANY number of major syncs
+        // with other parameters, as the reference drops any number; the bound of MAX_DROP is for the walks of such
+        // foreign candidates themselves (and of candidates of a stream that does not begin with a major sync), which
+        // would otherwise run through every sync of the stream that is unlike them, to its end, each of them.
+        const bool own = sync_frame_at(bytes, s_begin, s_end) &&
+                         ((packed_sync_at(bytes, s_begin) ^ r.sync) & SYNC_PARAMS) == 0;
         uint32_t n = 0;
         // one memory round trip per frame: the 8 header bytes of the frame at p (size field and
         // the place a major sync would sit) are fetched together and carried into the next step
@@ -407,7 +414,7 @@ __device__ __forceinline__ void chase_one(uint32_t i, const uint8_t *__restrict_
                 // segment: the reference drops that frame (restart header and all) and decodes on with
                 // the state it has (src/mlp.c:449-460) -- the walk goes through it (a bounded number of
                 // times: the candidate there walks on its own and must not run to the stream's end)
-                if (((packed_sync_at(bytes, p) ^ r.sync) & SYNC_PARAMS) == 0 || r.ndrop >= MAX_DROP)
+                if (((packed_sync_at(bytes, p) ^ r.sync) & SYNC_PARAMS) == 0 || (!own && r.ndrop >= MAX_DROP))
                     break;
                 r.ndrop++;
             }
@@ -474,19 +481,36 @@ __device__ __forceinline__ void mark_dead_one(uint32_t i, uint32_t n_cand, const
     const uint32_t want = streams[s].sync & SYNC_PARAMS;
     const bool foreign = (seg[i].sync & SYNC_PARAMS) != want;
     // does a chain land exactly here?
-    if (!foreign)
-        for (uint32_t q = i; q-- > 0 && i - q <= MAX_DROP + 1 && seg[q].stream == s;)
-            if (seg[q].end == off && (seg[q].sync & SYNC_PARAMS) == want)
+    // (the look-behind and the look-ahead are bounded in candidates of the stream's OWN parameters -- a run of foreign
+    //  ones, which a walk goes through whole, is stepped over however long it is: round 5, more than MAX_DROP dropped
+    //  in a row)
+    if (!foreign) {
+        uint32_t seen = 0;
+        for (uint32_t q = i; q-- > 0 && seen <= MAX_DROP + 1 && seg[q].stream == s;) {
+            if ((seg[q].sync & SYNC_PARAMS) != want)
+                continue;
+            seen++;
+            if (seg[q].end == off)
                 return;
+        }
+    }
     // nobody lands here: is it inside the span of an earlier chain that lands later (or at the end)?
     const uint64_t s_end = stream_off[s] + stream_len[s];
-    for (uint32_t q = i; q-- > 0 && i - q <= MAX_DROP + 1 && seg[q].stream == s;) {
+    uint32_t seen_b = 0;
+    for (uint32_t q = i; q-- > 0 && seen_b <= MAX_DROP + 1 && seg[q].stream == s;) {
         const uint64_t e = seg[q].end;
-        if (e <= off || seg[q].nframes == 0 || (seg[q].sync & SYNC_PARAMS) != want)
+        if ((seg[q].sync & SYNC_PARAMS) != want)
+            continue;
+        seen_b++;
+        if (e <= off || seg[q].nframes == 0)
             continue;
         bool lands = (e == s_end) || (seg[q].flags & (1u << 21));          // ran to the (truncated) end
-        for (uint32_t j = i + 1; !lands && j < n_cand && j <= i + MAX_DROP + 1 && seg[j].stream == s; j++)
+        uint32_t seen_f = 0;
+        for (uint32_t j = i + 1; !lands && j < n_cand && seen_f <= MAX_DROP + 1 && seg[j].stream == s && seg[j].off <= e; j++) {
             lands = seg[j].off == e;
+            if ((seg[j].sync & SYNC_PARAMS) == want)
+                seen_f++;
+        }
         if (lands) {
             seg[i].flags |= SEG_DEAD;
             seg[i].nframes = 0;

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <new>
 #include <vector>
@@ -24,6 +25,8 @@ struct dvda_mlp_hip_multi {
     std::vector<int> devices;
     std::vector<dvda_mlp_hip_ctx *> ctx;
     uint32_t max_streams, max_segments;
+    std::vector<double> last_ms;            // per device entry: wall time of the last decode_multi
+    std::vector<uint64_t> last_bytes;       // ... and the compressed bytes it was dealt
 };
 
 // shard.shard_titles: greedy longest-processing-time on the compressed size -- streams by size descending (ties:
@@ -71,6 +74,8 @@ extern "C" int dvda_mlp_hip_create_multi(dvda_mlp_hip_multi **out, const int *de
         m->devices.push_back(devices[d]);
         m->ctx.push_back(c);
     }
+    m->last_ms.assign(n_devices, 0.0);
+    m->last_bytes.assign(n_devices, 0);
     *out = m;
     return DVDA_HIP_OK;
 }
@@ -85,6 +90,17 @@ extern "C" void dvda_mlp_hip_destroy_multi(dvda_mlp_hip_multi *m)
 }
 
 extern "C" uint32_t dvda_mlp_hip_multi_devices(const dvda_mlp_hip_multi *m) { return m ? (uint32_t)m->ctx.size() : 0u; }
+
+extern "C" int dvda_mlp_hip_multi_device_time(const dvda_mlp_hip_multi *m, uint32_t entry, double *ms, uint64_t *bytes)
+{
+    if (!m || entry >= m->ctx.size())
+        return DVDA_HIP_EINVAL;
+    if (ms)
+        *ms = m->last_ms[entry];
+    if (bytes)
+        *bytes = m->last_bytes[entry];
+    return DVDA_HIP_OK;
+}
 
 namespace {
 
@@ -101,7 +117,16 @@ struct Job {
     dvda_mlp_stream_info *infos;
     int rc;
     uint64_t bytes;             // compressed bytes this part decoded
+    double ms;                  // wall time of this part (its thread's clock)
+    bool in_caller;             // no thread to be had: the part runs in the caller's thread, whose device is put back
 };
+
+inline double now_ms()
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
 
 template <class T>
 struct DevBuf {
@@ -119,6 +144,16 @@ void *worker(void *arg)
     dvda_mlp_hip_ctx *ctx = j.m->ctx[j.part];
     j.rc = DVDA_HIP_OK;
     j.bytes = 0;
+    j.ms = 0;
+    const double t_begin = now_ms();
+    // (a part that runs in the caller's thread leaves the caller's current device as it found it)
+    int caller_device = -1;
+    if (j.in_caller && hipGetDevice(&caller_device) != hipSuccess)
+        caller_device = -1;
+    struct Restore {
+        int dev;
+        ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } restore{caller_device};
     std::vector<uint32_t> mine;
     for (uint32_t i = 0; i < j.n_streams; i++)
         if (j.part_of[i] == j.part)
@@ -156,6 +191,8 @@ void *worker(void *arg)
     DevBuf<int32_t> d_pcm;
     std::vector<dvda_mlp_stream_info> info(n);
     uint8_t *h_stage = nullptr;
+    // (the source of an asynchronous copy: it lives until the stream has been waited for, on every way out)
+    std::vector<uint64_t> meta(4 * (size_t)n);
     do {
         if (!d_bytes.alloc(total + 64) || !d_meta.alloc(4 * (size_t)n) || !d_pcm.alloc(words) ||
             hipHostMalloc((void **)&h_stage, total + 64, hipHostMallocDefault) != hipSuccess) {
@@ -165,7 +202,6 @@ void *worker(void *arg)
         memset(h_stage, 0, total + 64);
         for (uint32_t k = 0; k < n; k++)
             memcpy(h_stage + off[k], j.streams[mine[k]], len[k]);
-        std::vector<uint64_t> meta(4 * (size_t)n);
         for (uint32_t k = 0; k < n; k++) {
             meta[k] = off[k];
             meta[n + k] = len[k];
@@ -200,12 +236,15 @@ void *worker(void *arg)
             if (e != hipSuccess)
                 j.rc = DVDA_HIP_ENODEV;
         }
-        if (hipStreamSynchronize(st) != hipSuccess)
-            j.rc = DVDA_HIP_ENODEV;
     } while (0);
+    // nothing is freed -- staging, meta, device buffers -- while a copy or a kernel may still use it: the stream is
+    // waited for whichever way the block above was left
+    if (hipStreamSynchronize(st) != hipSuccess && j.rc == DVDA_HIP_OK)
+        j.rc = DVDA_HIP_ENODEV;
     if (h_stage)
         (void)hipHostFree(h_stage);
     (void)hipStreamDestroy(st);
+    j.ms = now_ms() - t_begin;
     return nullptr;
 }
 
@@ -230,17 +269,22 @@ extern "C" int dvda_mlp_hip_decode_multi(dvda_mlp_hip_multi *m, const uint8_t *c
     std::vector<pthread_t> th(parts);
     std::vector<char> started(parts, 0);
     for (uint32_t p = 0; p < parts; p++) {
-        jobs[p] = Job{m, p, streams, lengths, part_of.data(), n_streams, layout, pcm, capacity_frames, infos, 0, 0};
+        jobs[p] = Job{m, p, streams, lengths, part_of.data(), n_streams, layout, pcm, capacity_frames, infos, 0, 0, 0.0, false};
         started[p] = pthread_create(&th[p], nullptr, worker, &jobs[p]) == 0;
-        if (!started[p])
-            worker(&jobs[p]);               // (no thread to be had: the part is decoded here, in turn)
+        if (!started[p]) {
+            jobs[p].in_caller = true;       // (no thread to be had: the part is decoded here, in turn)
+            worker(&jobs[p]);
+        }
     }
     for (uint32_t p = 0; p < parts; p++)
         if (started[p])
             pthread_join(th[p], nullptr);
-    for (uint32_t p = 0; p < parts; p++)
+    for (uint32_t p = 0; p < parts; p++) {
         if (jobs[p].rc != DVDA_HIP_OK)
             rc = jobs[p].rc;
+        m->last_ms[p] = jobs[p].ms;
+        m->last_bytes[p] = jobs[p].bytes;
+    }
     if (summary) {
         // the path's one reduction (bench.py does the same with one all-reduce over RCCL): sums, and the balance
         memset(summary, 0, sizeof(*summary));
@@ -257,6 +301,18 @@ extern "C" int dvda_mlp_hip_decode_multi(dvda_mlp_hip_multi *m, const uint8_t *c
         }
         summary->compressed_bytes = bsum;
         summary->compressed_bytes_max_device = bmax;
+        double tmax = 0, tmin = 0;
+        bool any = false;
+        for (uint32_t p = 0; p < parts; p++) {
+            if (!jobs[p].bytes)
+                continue;                   // (an entry that got no stream did nothing)
+            tmax = !any || jobs[p].ms > tmax ? jobs[p].ms : tmax;
+            tmin = !any || jobs[p].ms < tmin ? jobs[p].ms : tmin;
+            any = true;
+        }
+        summary->device_ms_max = tmax;
+        summary->device_ms_min = tmin;
+        summary->imbalance = bsum ? (double)bmax * parts / (double)bsum : 1.0;
     }
     return rc;
 }

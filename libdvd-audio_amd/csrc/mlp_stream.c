@@ -215,7 +215,7 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
                                 ((uint32_t)(sp[1] & 0x0F) << 12) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
         const unsigned rpa = rows_per_au(sp[1] >> 4);
         size_t at = d->decoded_end, units_all = 0, rows_cap_all, got = 0;
-        int leave = 0, have_new_fir = 0, stepped = d->stepped, n_steps = 0;
+        int leave = 0, have_new_fir = 0, stepped = d->stepped, n_steps = 0, failed = 0, step_rc;
         int32_t new_fir[2 * 48];
         const int32_t *one_pcm = NULL;
         uint64_t one_stride = 0;
@@ -245,10 +245,21 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
                 end += size;
                 units++;
             }
-            if (units == 0 || rpa == 0 ||
-                dvda_mlp_hip_stepper_step(d->step, d->q + at, end - at, (uint32_t)units, packed, !stepped, &res, &pcm, &stride,
-                                          &nch) != DVDA_HIP_OK) {
+            if (units == 0 || rpa == 0) {
                 leave = 1;              /* (a rate code outside the table, ...: the batch tier reports it) */
+                break;
+            }
+            step_rc = dvda_mlp_hip_stepper_step(d->step, d->q + at, end - at, (uint32_t)units, packed, !stepped, &res, &pcm,
+                                                &stride, &nch);
+            if (step_rc == DVDA_HIP_ECAPACITY || step_rc == DVDA_HIP_EINVAL) {
+                leave = 1;              /* not what a step takes: the batch tier decodes (and reports) it */
+                break;
+            }
+            if (step_rc != DVDA_HIP_OK) {
+                /* a HIP runtime failure is not a property of the stream: it is reported, not papered over by a silent
+                   switch to the batch tier (which would meet the same device) */
+                d->status |= DVDA_ST_DEVICE;
+                failed = 1;
                 break;
             }
             stepped = 1;
@@ -258,9 +269,9 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
                 break;
             }
             if (res->status & ~(unsigned)DVDA_ST_BENIGN) {
-                d->stepped = 1;
                 d->status |= res->status;           /* the reference would have assert()ed */
-                return 0;
+                failed = 1;
+                break;
             }
             if (res->sync_seen) {
                 memcpy(new_fir, res->fir, sizeof(new_fir));
@@ -279,6 +290,20 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
             at = end;
         }
         d->stepped = stepped;
+        if (failed) {
+            /* what the steps in front of the failing one decoded is handed out (they are in h_pcm: a call that fails
+               on its first step has nothing), and counted, before the decoder stops for good */
+            if (got == 0 || n_steps < 1 || one_pcm)
+                return 0;
+            for (c = 0; c < nch; c++)
+                if (planar)
+                    planar[c] = d->h_pcm + (size_t)c * rows_cap_all;
+            if (channels)
+                *channels = nch;
+            d->rows_before += got;
+            d->decoded_end = at;
+            return (unsigned)got;
+        }
         if (!leave) {
             for (c = 0; c < nch; c++)
                 if (planar)

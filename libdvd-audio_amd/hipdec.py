@@ -35,7 +35,8 @@ class MultiSummary(ctypes.Structure):
     """dvda_mlp_multi_summary of include/dvda_mlp_hip.h"""
     _fields_ = [("pcm_frames", ctypes.c_uint64), ("samples", ctypes.c_uint64), ("compressed_bytes", ctypes.c_uint64),
                 ("compressed_bytes_max_device", ctypes.c_uint64), ("streams_with_errors", ctypes.c_uint32),
-                ("devices", ctypes.c_uint32)]
+                ("devices", ctypes.c_uint32), ("device_ms_max", ctypes.c_double), ("device_ms_min", ctypes.c_double),
+                ("imbalance", ctypes.c_double)]
 
 
 class HipError(RuntimeError):
@@ -57,7 +58,7 @@ EXPORTS = ("dvda_mlp_hip_create", "dvda_mlp_hip_destroy", "dvda_mlp_hip_index", 
            "dvda_pcm_hip_workspace_words", "dvda_pcm_hip_decode_sectors", "dvda_pcm_hip_result",
            "dvda_mlp_hip_demux_sectors", "dvda_mlp_hip_pack_wav",
            "dvda_mlp_hip_shard", "dvda_mlp_hip_create_multi", "dvda_mlp_hip_destroy_multi",
-           "dvda_mlp_hip_multi_devices", "dvda_mlp_hip_decode_multi")
+           "dvda_mlp_hip_multi_devices", "dvda_mlp_hip_decode_multi", "dvda_mlp_hip_multi_device_time")
 
 
 def lib():
@@ -115,6 +116,7 @@ def lib():
         L.dvda_mlp_hip_destroy_multi.restype = None
         L.dvda_mlp_hip_multi_devices.argtypes = [vp]
         L.dvda_mlp_hip_multi_devices.restype = u32
+        L.dvda_mlp_hip_multi_device_time.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         L.dvda_mlp_hip_decode_multi.argtypes = [vp, vp, vp, u32, u32, vp, vp, ctypes.POINTER(StreamInfo),
                                                 ctypes.POINTER(MultiSummary)]
         _lib = L

@@ -56,10 +56,13 @@ FIXTURES = [
 SYNC_CHANGES = {
     "sync_change_6ch": ((2, 4, 5), 1, None),
     "sync_change_2ch_2ss": ((1, 2, 3), 0, 3),
+    # (round 5) eighty changed major syncs in a row -- more than the 64 the index's walk used to take
+    "sync_change_80_in_a_row": (tuple(range(5, 85)), 0, None),
 }
 FIXTURES += [
     ("sync_change_6ch", 12, 1, 1, 28, 0, 0, 21, 4),
     ("sync_change_2ch_2ss", 1, 1, 2, 30, 0, 0, 22, 5),
+    ("sync_change_80_in_a_row", 1, 0, 1, 100, 0, 0, 23, 1),
 ]
 
 

@@ -132,6 +132,13 @@ def test_bench_launcher_starts_two_ranks_over_gloo():
     assert abs(rec["ranks"]["seconds_min"] - 0.001) < 1e-9 and rec["ranks"]["bit_exact_on_every_rank"] is None
     assert rec["ranks"]["compressed_bytes_max"] >= rec["ranks"]["compressed_bytes_min"] > 0
     assert 1.0 <= rec["ranks"]["load_imbalance"] < 1.2
+    # (round 5) the line says by itself that two ranks took part and what each measured: the process group's size, the
+    # all-reduced count of ranks, one entry per rank (plumbing mode: the step time is the rank's stand-in 1 / 2 ms)
+    assert rec["ranks"]["world_size"] == 2 and rec["ranks"]["ranks_counted"] == 2
+    per = rec["ranks"]["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    assert all(set(p) >= {"rank", "k_decode_ms", "roofline_frac", "ms_per_step"} for p in per)
+    assert [p["ms_per_step"] for p in per] == [1.0, 2.0]
 
 
 def test_bench_c4_shards_the_1024_units_strongly():

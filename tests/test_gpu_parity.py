@@ -650,12 +650,16 @@ def test_changed_major_syncs_are_dropped_like_the_reference(pkg, oracle, S):
     want, r, st = oracle.decode(ten, 6, frames)
     assert r == frames - 80 * 10 and st == 2
     assert inf10[0].status & ~hip.ST_BENIGN == 0 and inf10[0].pcm_frames == r and np.array_equal(pcm10[0], want)
-    # past the walk's bound (64 in a row: csrc/mlp_index.h MAX_DROP): reported, never passed as clean
+    # seventy in a row (rounds 2-4 stopped the walk at 64 and reported the stream): the reference drops any number
+    # (src/mlp.c:449-460), and so does the index's walk of a candidate with the stream's own parameters (round 5)
     cfg_l = syn.make_cfg(assignment=12, rate_code=1, n_substreams=S, n_aus=80, restart_interval=1)
-    long_clean, _ = syn.stream(cfg_l, 616 + S)
+    long_clean, frames_l = syn.stream(cfg_l, 616 + S)
     many, _ = stream_tools.change_sync_params(long_clean, tuple(range(2, 72)), g1_bps=0)
-    _, infm = hip.decode_streams([many])
-    assert infm[0].status & hip.ST["IRREGULAR"]
+    pcmm, infm = _both(hip, [many, long_clean])
+    want, r, st = oracle.decode(many, 6, frames_l)
+    assert r == frames_l - 80 * 70 and st == 2
+    assert infm[0].status & ~hip.ST_BENIGN == 0, hex(infm[0].status)
+    assert infm[0].pcm_frames == r and np.array_equal(pcmm[0], want)
     # streaming tier, PES-payload sized packets
     dec = hip.MLPDecoder(2, 2, 1, 1, 12)
     samples = [[] for _ in range(6)]
@@ -1040,6 +1044,9 @@ def test_title_list_dealt_to_several_devices_from_c(pkg, oracle, layout):
     assert summ.compressed_bytes == sum(len(b) for b in streams)
     owner = hip.shard_c([len(b) for b in streams], 3)
     assert summ.compressed_bytes_max_device == max(sum(len(b) for b, o in zip(streams, owner) if o == r) for r in range(3))
+    # (round 5) what a run on N devices says about itself: the deal's imbalance and the device entries' wall times
+    assert abs(summ.imbalance - summ.compressed_bytes_max_device * 3 / summ.compressed_bytes) < 1e-9 and summ.imbalance >= 1.0
+    assert 0 < summ.device_ms_min <= summ.device_ms_max
     for i, (b, f, nch) in enumerate(zip(streams, frames, nchs)):
         want, r, st = oracle.decode(b, nch, f)
         assert st == 0 and infos[i].pcm_frames == f and infos[i].channels == nch

@@ -230,6 +230,11 @@ int main(int argc, char *argv[])
     for (int i = 0; i < n_devices; i++)
         if (started[i])
             pthread_join(th[i], NULL);
+    /* a track that could not be extracted (no such device, a read error, a decode the library reports) fails the run */
+    if (atomic_load(&pool.failed)) {
+        fprintf(stderr, "*** Error: %u of %u tracks could not be extracted\n", atomic_load(&pool.failed), n_jobs);
+        rc = 1;
+    }
     for (unsigned i = 0; i < n_titles; i++)
         dvda_close_title(titles[i]);
     free(jobs);

@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 out_dir, subs = sys.argv[1], sys.argv[2].split(",")
-STEPS = 4          # --steps 3 --warmup 1 of the traced runs: launches per kernel / STEPS = launches per step
+STEPS = 4          # (replaced per sub-record by the number of its steps found in the trace)
 
 
 def short(n):
@@ -31,17 +31,47 @@ for sub in subs:
     except OSError:
         pass
     rec = (bench or {}).get("sub", {}).get(sub)
-    dur = {}
-    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            dur[short(r["Name"])] = (float(r["AverageNs"]) / 1e6, int(r["Calls"]))
+
+    # ---- which dispatches are the sub-record's?  The headline batch runs in the same process and launches kernels of
+    #      the same names (k_sync_mask, k_decode<6, ..>): a mean over all launches of a name mixes two batches (round 4's
+    #      table did).  Every index call begins with k_init_streams: the dispatches are cut into steps there, in
+    #      dispatch order; the sub-record runs last, so the steps whose k_sync_mask grid is the LAST step's are its own.
+    def own_rows(rows, name_col, grid_col):
+        rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
+        steps, cur = [], []
+        for r in rows:
+            if "k_init_streams" in r[name_col] and cur:
+                steps.append(cur)
+                cur = []
+            cur.append(r)
+        if cur:
+            steps.append(cur)
+
+        def grid(step):
+            for r in step:
+                if "k_sync_mask" in r[name_col]:
+                    return r[grid_col]
+            return None
+        steps = [st for st in steps if grid(st) is not None]
+        if not steps:
+            return [], 0
+        g = grid(steps[-1])
+        mine = [st for st in steps if grid(st) == g]
+        return [r for st in mine for r in st], len(mine)
+
+    dur_acc, n_steps = defaultdict(list), 0
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        rows, n_steps = own_rows(list(csv.DictReader(open(f))), "Kernel_Name", "Grid_Size_X")
+        for r in rows:
+            dur_acc[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    dur = {k: (sum(v) / len(v), len(v)) for k, v in dur_acc.items()}
+    STEPS = max(n_steps, 1)
     ctr = defaultdict(lambda: defaultdict(list))
     for which in ("fetch", "write"):
         for f in glob.glob(os.path.join(d, which, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
+            rows, _ = own_rows(list(csv.DictReader(open(f))), "Kernel_Name", "Grid_Size")
+            for r in rows:
                 ctr[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    # the headline batch runs in the same process (main record): its kernels are in the trace too; the sub-record's
-    # own decode call is told apart by the kernels only it launches being present -- all are listed, by name
     print("== %s" % sub)
     if rec:
         print("   %s Msamples/s, %.3f ms/step, decode call %.3f ms on the device; algorithmic bytes per step %.3f GB" % (
@@ -61,9 +91,7 @@ for sub in subs:
         per_kernel[k] = {"ms": round(ms, 4), "launches_per_step": round(calls / STEPS, 2),
                          "fetch_bytes": int(fb) if fb is not None else None, "write_bytes": int(wb) if wb is not None else None}
     if rec:
-        # bytes of the sub-record's own step: kernels weighted by how often a step launches them.  (The headline batch's
-        # kernels of the same process are in these means too where the names coincide: k_sync_mask, k_decode<6,..,true,false>
-        # of an unchained batch -- stated, not hidden: the chain-pass kernels and the parse pass are the sub-record's alone.)
+        # bytes of the sub-record's own step: every kernel of ITS dispatches, weighted by how often a step launches it
         own = [k for k in per_kernel if any(t in k for t in ("k_chain", "false, true>", "k_coop<true>"))]
         tb = sum((per_kernel[k]["fetch_bytes"] or 0) + (per_kernel[k]["write_bytes"] or 0) for k in own)
         res[sub] = {"samples_per_step": rec["samples_per_step"], "compressed_bytes": rec["compressed_bytes"],
