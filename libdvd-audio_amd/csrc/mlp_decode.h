@@ -79,6 +79,15 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_COOP_OUT
 #define DVDA_COOP_OUT 0
 #endif
+// the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
+// the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
+// the one LDS round trip per row they hide)
+#ifndef DVDA_CARRY_WINDOW
+#define DVDA_CARRY_WINDOW 0
+#endif
+#ifndef DVDA_UNI2
+#define DVDA_UNI2 1
+#endif
 #ifndef DVDA_EARLY_WINDOW
 #define DVDA_EARLY_WINDOW 1
 #endif
@@ -934,6 +943,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     int32_t pq_s[OUT_ROWS] = {0, 0, 0, 0};   // chain parse pass (see TP): per staged row, noise seed (its 23 bits) | bypassed LSBs << 23
     uint32_t au_idx = 0;              // chain parse pass: PCM-yielding access units of the segment so far
     uint32_t drops_seen = 0;          // frames dropped so far (major sync with other stream parameters)
+    uint64_t carry_win = 0;           // the window asked for at the end of a row for the next row's first symbol ...
+    uint32_t carry_pos = 0xFFFFFFFFu; // ... and the reading position it belongs to
 
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
     //      ch[0..7] in MLP channel order, shifted in place
@@ -1747,7 +1758,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                 }
             }
-            uint64_t win = rd.window();
+            // the row's first window: the one the row before asked for when it was through with its last symbol, if the
+            // reading position is still the one it was asked for (a header parse or the row's bypassed LSBs moved it:
+            // then it is read here, and waited for -- which is what every row did before this: a fifth of a two-channel
+            // row's time, tools/shape_bench.py stereo)
+            uint64_t win = carry_win;
+            if (!DVDA_CARRY_WINDOW || __any(rd.pos != carry_pos))
+                win = rd.window();
             uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
             // IIR taps anywhere in the wave (sequential pass only: in the fast pass such a segment is ST_COLD)
             const bool wave_iir = GENERAL && __any(iir_any != 0);
@@ -1887,6 +1904,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 status |= ST_HUFFMAN;
                 active = false;
             }
+            if (DVDA_CARRY_WINDOW) {
+                // the next row's first window, in flight through the rematrix, the ring commit and the stores
+                carry_win = rd.window();
+                carry_pos = rd.pos;
+            }
             DVDA_STAMP(2);
         };
         // (called by the lanes that decode a row this turn)
@@ -1899,7 +1921,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             const bool uni = __all(nslots == nu);
             if (uni && nu == (uint32_t)NS)
                 row_head(std::integral_constant<int, NS>{});
-            else if (NS > 2 && uni && nu == 2u)
+            else if (DVDA_UNI2 && NS > 2 && uni && nu == 2u)
                 row_head(std::integral_constant<int, (NS > 2 ? 2 : 0)>{});
             else
                 row_head(std::integral_constant<int, 0>{});

@@ -50,12 +50,18 @@ for w in which:
                            features=SF["CHAINED"])
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
         run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 65, 4, "interleaved")
+    elif w == "stereo":
+        # the bench's stereo_c2 sub-record: 2-channel titles (BASELINE configs[1]), planar layout
+        cfg = syn.make_cfg(assignment=1, rate_code=1, n_substreams=1, n_aus=512)
+        flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
+        run(w, flat, offs, sizes, frames, np.full(1024, 2), 4096 * 64, 4, "planar")
     elif w == "two":
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=512)
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
         run(w, flat, offs, sizes, frames, np.full(1024, 6), 4096 * 64, 4, "interleaved")
-    elif w in ("one_chained", "one_chained_long"):
-        n_aus = 512 if w == "one_chained" else 8192
+    elif w.startswith("one_chained"):
+        # one_chained = ONE chained title of 512 access units, one_chained_long of 8 192, one_chained_N of N
+        n_aus = 512 if w == "one_chained" else 8192 if w == "one_chained_long" else int(w.split("_")[-1])
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=n_aus, profile=1, features=SF["CHAINED"])
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1)
         run(w, flat, offs, sizes, frames, np.full(1, 6), n_aus // 8 + 8, 1, "interleaved", steps=20)
