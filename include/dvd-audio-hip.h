@@ -87,6 +87,23 @@ DVDA_Track_Reader *dvda_hip_open_track_reader_on(const DVDA_Track *track, int de
 /* != 0: the reader holds the WAV payload only (opened with wav_output): dvda_read() on it returns 0 frames -- NOT
  * because the track is empty; take the payload with dvda_hip_reader_wav_payload() */
 int dvda_hip_reader_wav_only(const DVDA_Track_Reader *reader);
+/* ---- long tracks (round 5).  An MLP track of more than a window of sectors (DVDA_WINDOW_SECTORS in the environment,
+ * default 8192 = 16 MiB) is read, demultiplexed and decoded window by window while it is served, as the reference
+ * streams it (src/dvd-audio.c:751-795): what is resident on the host and on the device is bounded by the window, not
+ * by the track.  dvda_read() works on such a reader as on any other.  Its WAV payload comes piece by piece: */
+/* the next piece of the track's WAV data bytes (valid until the next call on this reader); 0 at the end of the track.
+ * (A reader that is not windowed hands out its whole payload in one piece, once.) */
+unsigned long long dvda_hip_reader_wav_next(DVDA_Track_Reader *reader, const unsigned char **payload);
+/* != 0: the reader decodes in windows (dvda_hip_reader_total_frames() is then the count so far: final when the
+ * track has been read to its end) */
+int dvda_hip_reader_windowed(const DVDA_Track_Reader *reader);
+/* != 0: a window of the track could not be read or decoded (what makes dvda_open_track_reader return NULL when it
+ * happens in a track's first window): dvda_read() / dvda_hip_reader_wav_next() then end early */
+int dvda_hip_reader_failed(const DVDA_Track_Reader *reader);
+/* peaks of what a windowed reader held: bytes of host memory it allocated (pinned buffers, the bytes kept between
+ * windows), and of device memory in use beyond what was in use when it was opened (hipMemGetInfo, sampled after every
+ * window); returns 0 on a reader that is not windowed */
+int dvda_hip_reader_memory(const DVDA_Track_Reader *reader, unsigned long long *host_peak, unsigned long long *device_peak);
 /* status word of the decode behind a reader: DVDA_ST_* bits of dvda_mlp_hip.h (0 = clean) */
 unsigned dvda_hip_reader_status(const DVDA_Track_Reader *reader);
 /* PCM frames the reader holds in total */

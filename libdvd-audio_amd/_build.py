@@ -85,7 +85,7 @@ def build_disc(force=False):
         return DISC_SO
     subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                     "-o", DISC_SO, DISC_SRCS[0], "-L" + HERE, "-ldvda_mlp_hip", "-L/opt/rocm/lib", "-lamdhip64",
-                    "-lm", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    "-lm", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return DISC_SO
 
 

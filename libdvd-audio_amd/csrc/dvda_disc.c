@@ -26,6 +26,7 @@
 #include <dirent.h>
 #include <hip/hip_runtime_api.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -86,8 +87,11 @@ struct DVDA_Track_s {
     struct track_span s;
 };
 
+struct mlp_windows;                 /* a long MLP track read window by window (below) */
+
 struct DVDA_Track_Reader_s {
     dvda_codec_t codec;
+    struct mlp_windows *win;       /* != NULL: the track is decoded in windows of bounded size as it is read */
     unsigned bps_code[2], rate_code[2], assignment;
     unsigned channels, status;
     uint64_t frames, served, stride;
@@ -530,10 +534,13 @@ static int64_t find_sync_dev(const uint8_t *d_bytes, uint64_t from, uint64_t siz
     return at;
 }
 
+static void windows_free(struct mlp_windows *w);
+
 static void reader_free(DVDA_Track_Reader *r)
 {
     if (!r)
         return;
+    windows_free(r->win);
     free(r->pcm);
     (void)hipFree(r->d_wav);
     free(r->wav);
@@ -741,6 +748,521 @@ done:
     return r;
 }
 
+/* ------------------------------------------------------------------ MLP track, in windows (round 5)
+ *
+ * The reference streams a track of any length in O(packet) memory (src/dvd-audio.c:751-795, 1151-1227).  open_mlp()
+ * above takes the whole track as ONE batch -- its sectors, its bytes and its PCM all resident at once: a 74-minute
+ * 6-channel track is ~10 GB on the device and again on the host.  A track of more than WINDOW_SECTORS sectors is
+ * therefore read and decoded window by window:
+ *
+ *   window = the next WINDOW_SECTORS sectors of the track -> GPU demux -> [bytes kept from the window before | new bytes]
+ *   cut    = the LAST major sync of that stream at which a segment starts (the index says where: restart segments
+ *            are the units of parallel decode): everything in front of it is whole segments and is decoded
+ *            now; what follows is kept for the next window.  The first window starts at the first major-sync
+ *            pattern, the last one ends as open_mlp()'s whole track does (src/dvd-audio.c:1167-1194).
+ *   carry  = between two windows nothing but those bytes and the FIR history at the cut (the reference never clears a
+ *            channel's history, src/mlp.c:297-304: dvda_mlp_hip_segment_fir / dvda_mlp_hip_set_initial_fir) -- every
+ *            other decoder field is set again by the restart header at a major sync.
+ *
+ * A producer thread fills a ring of two pinned host buffers (window k + 1 is read, demultiplexed and decoded while
+ * dvda_read() / dvda_hip_reader_wav_next() serve window k); one decode context, one set of device buffers and the two
+ * pinned buffers serve the whole track.  What is resident is bounded by the window, not by the track:
+ * dvda_hip_reader_memory() reports the peaks (tests/test_disc_api.py asserts them).
+ */
+#define WIN_SLOTS 2
+static unsigned window_sectors(void)
+{
+    /* DVDA_WINDOW_SECTORS: window size in 2048-byte sectors (tests use small ones); default 8192 = 16 MiB of sectors,
+       which decode to 32..70 MB of PCM */
+    const char *e = getenv("DVDA_WINDOW_SECTORS");
+    const long v = e ? strtol(e, NULL, 10) : 0;
+    return v >= 64 ? (unsigned)v : 8192u;
+}
+
+struct win_slot {
+    uint8_t *host;              /* pinned: int32 frames [frame][channel], or the packed WAV payload */
+    size_t cap;
+    uint64_t frames;
+};
+
+struct mlp_windows {
+    struct aob_set aobs;        /* the reader's own open files */
+    unsigned first, last;       /* the track's sector range */
+    unsigned next;              /* next sector to read */
+    unsigned window;
+    int device, wav_bits;       /* wav_bits != 0: the decode writes the payload (DVDA_PCM_WAV24 / WAV16) */
+    int started, finished, failed;
+    uint8_t *carry;             /* host: bytes from the last cut on */
+    size_t carry_len, carry_cap;
+    int32_t fir[2 * 48];
+    int have_fir;
+    /* device side, kept for the whole track and grown when a window needs more */
+    dvda_mlp_hip_ctx *ctx;
+    uint32_t ctx_segs;
+    uint8_t *h_sec, *d_sec, *d_mlp, *d_stream;
+    uint32_t *d_work, *h_base;
+    uint64_t *d_meta;
+    int32_t *d_pcm, *d_fir;
+    size_t cap_sec, cap_stream, cap_pcm;        /* sectors, bytes, bytes */
+    /* what the stream is (first window) */
+    dvda_mlp_stream_info info;
+    unsigned status;
+    uint64_t frames_total;
+    /* producer / consumer */
+    pthread_t th;
+    int th_started, stop;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    struct win_slot slot[WIN_SLOTS];
+    unsigned head, tail, count;
+    uint64_t served_in_slot;    /* frames of slot[tail] already handed out */
+    uint8_t *whole;             /* dvda_hip_reader_wav_payload() on a windowed reader: every window appended (unbounded) */
+    /* accounting */
+    size_t host_now, host_peak, dev_free0, dev_peak;
+};
+
+static void win_host_add(struct mlp_windows *w, size_t now_more)
+{
+    w->host_now += now_more;
+    if (w->host_now > w->host_peak)
+        w->host_peak = w->host_now;
+}
+static void win_dev_sample(struct mlp_windows *w)
+{
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && w->dev_free0 > fr && w->dev_free0 - fr > w->dev_peak)
+        w->dev_peak = w->dev_free0 - fr;
+}
+static int win_grow_dev(void **p, size_t *cap, size_t need)
+{
+    if (need <= *cap && *p)
+        return 1;
+    (void)hipFree(*p);
+    *p = NULL;
+    *cap = 0;
+    need += need / 4 + 4096;
+    if (hipMalloc(p, need) != hipSuccess)
+        return 0;
+    *cap = need;
+    return 1;
+}
+
+static void windows_free(struct mlp_windows *w)
+{
+    if (!w)
+        return;
+    if (w->th_started) {
+        pthread_mutex_lock(&w->mu);
+        w->stop = 1;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        pthread_join(w->th, NULL);
+    }
+    (void)hipSetDevice(w->device);
+    if (w->ctx)
+        dvda_mlp_hip_destroy(w->ctx);
+    for (int i = 0; i < WIN_SLOTS; i++)
+        if (w->slot[i].host)
+            (void)hipHostFree(w->slot[i].host);
+    if (w->h_sec)
+        (void)hipHostFree(w->h_sec);
+    free(w->h_base);
+    free(w->carry);
+    free(w->whole);
+    (void)hipFree(w->d_sec);
+    (void)hipFree(w->d_mlp);
+    (void)hipFree(w->d_stream);
+    (void)hipFree(w->d_work);
+    (void)hipFree(w->d_meta);
+    (void)hipFree(w->d_pcm);
+    (void)hipFree(w->d_fir);
+    aob_close_all(&w->aobs);
+    pthread_mutex_destroy(&w->mu);
+    pthread_cond_destroy(&w->cv);
+    free(w);
+}
+
+/* the last segment of the index (a live one: a sync pattern inside another segment's frames is not a cut) -> its number
+ * and byte offset; 0 when the stream has no segment start behind its first byte */
+static int win_last_cut(struct mlp_windows *w, uint32_t n_seg, uint32_t *seg_out, uint64_t *off_out)
+{
+    for (uint32_t s = n_seg; s-- > 0;) {
+        dvda_mlp_segment_info si;
+        if (dvda_mlp_hip_segment_info(w->ctx, s, &si, NULL) != DVDA_HIP_OK)
+            return 0;
+        if (si.status & DVDA_ST_FALSE_SYNC)
+            continue;
+        *seg_out = s;
+        *off_out = si.offset;
+        return si.offset != 0;
+    }
+    return 0;
+}
+
+/* index of stream bytes [0, len) in d_stream; grows the context when it has too few segments */
+static int win_index(struct mlp_windows *w, uint64_t len, uint32_t *n_seg)
+{
+    const uint64_t padded = (len + 15) & ~(uint64_t)15;
+    const uint64_t meta[4] = {0, len, 0, 0};
+    if (hipMemsetAsync(w->d_stream + len, 0, padded + 64 - len, NULL) != hipSuccess ||
+        hipMemcpy(w->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
+        return 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (!w->ctx) {
+            if (dvda_mlp_hip_create(&w->ctx, w->device, 1, w->ctx_segs) != DVDA_HIP_OK)
+                return 0;
+        }
+        if (dvda_mlp_hip_index(w->ctx, w->d_stream, padded, w->d_meta + 0, w->d_meta + 1, 1, NULL) != DVDA_HIP_OK)
+            return 0;
+        const int rc = dvda_mlp_hip_segment_count(w->ctx, n_seg, NULL);
+        if (rc == DVDA_HIP_OK)
+            return 1;
+        if (rc != DVDA_HIP_ECAPACITY || attempt)
+            return 0;
+        dvda_mlp_hip_destroy(w->ctx);
+        w->ctx = NULL;
+        w->ctx_segs = *n_seg + *n_seg / 2 + 64;
+    }
+    return 0;
+}
+
+/* One window into `out`: 1 = out holds frames (possibly none), 0 = failure.  Sets w->finished behind the track's last
+ * window.  Runs in the opener's thread for the first window, in the producer thread afterwards. */
+static int win_produce(struct mlp_windows *w, struct win_slot *out)
+{
+    out->frames = 0;
+    unsigned extra = 8;
+    for (;;) {
+        const int has_track = w->next <= w->last;
+        unsigned in_track = has_track ? w->last - w->next + 1 : 0;
+        int final = in_track <= w->window;
+        if (!final)
+            in_track = w->window;
+        unsigned want = in_track + (final ? extra : 0);
+        if (w->next + want > w->aobs.total || w->next + want < w->next)
+            want = w->aobs.total - w->next;
+        /* ---- sectors -> device -> MLP bytes */
+        if (want > w->cap_sec) {
+            if (w->h_sec) {
+                (void)hipHostFree(w->h_sec);
+                w->host_now -= w->cap_sec * SECTOR;
+            }
+            (void)hipFree(w->d_sec);
+            (void)hipFree(w->d_mlp);
+            (void)hipFree(w->d_work);
+            free(w->h_base);
+            w->h_sec = w->d_sec = w->d_mlp = NULL;
+            w->d_work = w->h_base = NULL;
+            w->cap_sec = 0;
+            const size_t cap = (size_t)want * SECTOR;
+            if (hipHostMalloc((void **)&w->h_sec, cap, hipHostMallocDefault) != hipSuccess)
+                return 0;
+            win_host_add(w, cap);
+            if (!dev_alloc((void **)&w->d_sec, cap) || !dev_alloc((void **)&w->d_mlp, cap + 64) ||
+                !dev_alloc((void **)&w->d_work, dvda_pcm_hip_workspace_words(want) * sizeof(uint32_t)) ||
+                (w->h_base = malloc(((size_t)want + 1) * sizeof(uint32_t))) == NULL)
+                return 0;
+            w->cap_sec = want;
+        }
+        const unsigned got = want ? aob_read(&w->aobs, w->next, want, w->h_sec) : 0;
+        uint64_t total = 0;
+        uint32_t bad = 0;
+        if (got) {
+            if (hipMemcpy(w->d_sec, w->h_sec, (size_t)got * SECTOR, hipMemcpyHostToDevice) != hipSuccess ||
+                dvda_mlp_hip_demux_sectors(w->d_sec, got, w->d_mlp, (size_t)w->cap_sec * SECTOR, w->d_work, NULL) != DVDA_HIP_OK ||
+                dvda_pcm_hip_result(w->d_work, got, &total, &bad, NULL) != DVDA_HIP_OK ||
+                hipMemcpy(w->h_base, w->d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+                return 0;
+        } else if (!final) {
+            return 0;                            /* the files end inside the track */
+        }
+        /* ---- where this window's new bytes begin and end */
+        uint64_t begin = 0, end = total;
+        if (!w->started) {
+            const int64_t s0 = find_sync_dev(w->d_mlp, 0, total);
+            if (s0 < 0) {
+                if (!final || got < want || w->next + got >= w->aobs.total)
+                    return 0;                    /* no major sync anywhere: the reference asserts */
+                extra *= 4;
+                continue;
+            }
+            begin = (uint64_t)s0;
+        }
+        if (final) {
+            /* the end-of-track rule of open_mlp(), on the window that holds the track's last sector */
+            if (got > in_track) {
+                const uint64_t boundary = w->h_base[in_track];
+                const int64_t s1 = find_sync_dev(w->d_mlp, boundary > begin ? boundary : begin, total);
+                if (s1 >= 0) {
+                    end = (uint64_t)s1;
+                } else if (w->next + got >= w->aobs.total) {
+                    end = total - boundary >= 8 ? total - 7 : boundary;
+                } else {
+                    extra *= 4;
+                    continue;
+                }
+            }
+        }
+        if (end < begin)
+            end = begin;
+        /* ---- the stream of this window: what was kept + the new bytes */
+        uint64_t len = w->carry_len + (end - begin);
+        if (!win_grow_dev((void **)&w->d_stream, &w->cap_stream, ((len + 15) & ~(uint64_t)15) + 64 + 16) ||
+            (!w->d_meta && !dev_alloc((void **)&w->d_meta, 4 * sizeof(uint64_t))))
+            return 0;
+        if ((w->carry_len && hipMemcpy(w->d_stream, w->carry, w->carry_len, hipMemcpyHostToDevice) != hipSuccess) ||
+            (end > begin && hipMemcpy(w->d_stream + w->carry_len, w->d_mlp + begin, end - begin, hipMemcpyDeviceToDevice) != hipSuccess))
+            return 0;
+        w->next += final ? got : in_track;
+        w->started = 1;
+        if (len == 0) {
+            w->finished = final;
+            return final;                        /* an empty track does not open */
+        }
+        uint32_t n_seg = 0, cut_seg = 0;
+        uint64_t cut = len;
+        if (w->ctx_segs == 0)
+            w->ctx_segs = (uint32_t)(len / 2048 + 256);
+        if (!win_index(w, len, &n_seg))
+            return 0;
+        if (!final) {
+            if (!win_last_cut(w, n_seg, &cut_seg, &cut)) {
+                /* no segment starts inside this window: all of it waits for the next one */
+                cut = 0;
+            }
+            /* what follows the cut is kept (host copy: the device buffers are the next window's) */
+            const uint64_t keep = len - cut;
+            if (keep > w->carry_cap) {
+                free(w->carry);
+                w->host_now -= w->carry_cap;
+                w->carry_cap = keep + keep / 2 + 4096;
+                w->carry = malloc(w->carry_cap);
+                if (!w->carry) {
+                    w->carry_cap = 0;
+                    return 0;
+                }
+                win_host_add(w, w->carry_cap);
+            }
+            if (keep && hipMemcpy(w->carry, w->d_stream + cut, keep, hipMemcpyDeviceToHost) != hipSuccess)
+                return 0;
+            w->carry_len = keep;
+            if (cut == 0)
+                return 1;                        /* nothing to decode yet (out->frames == 0) */
+            if (!win_index(w, cut, &n_seg))      /* the index of what is decoded now: whole segments */
+                return 0;
+        } else {
+            w->carry_len = 0;
+        }
+        /* ---- decode [0, cut) from the history the window before left */
+        dvda_mlp_stream_info info;
+        if (dvda_mlp_hip_stream_info(w->ctx, &info, 1, NULL) != DVDA_HIP_OK || info.channels == 0)
+            return 0;
+        if (w->have_fir) {
+            if ((!w->d_fir && !dev_alloc((void **)&w->d_fir, sizeof(w->fir))) ||
+                hipMemcpy(w->d_fir, w->fir, sizeof(w->fir), hipMemcpyHostToDevice) != hipSuccess)
+                return 0;
+        }
+        if (dvda_mlp_hip_set_initial_fir(w->ctx, w->have_fir ? w->d_fir : NULL) != DVDA_HIP_OK)
+            return 0;
+        const unsigned rate = rate_of(info.group0_rate);
+        const uint64_t per_au = rate == 48000 || rate == 44100 ? 40 : rate == 96000 || rate == 88200 ? 80 : 160;
+        uint64_t stride = ((info.mlp_frames * per_au + 3) & ~(uint64_t)3);
+        if (stride == 0)
+            stride = 4;
+        const unsigned wbits = w->wav_bits;
+        if (dvda_mlp_hip_set_pcm_layout(w->ctx, wbits == 24 ? DVDA_PCM_WAV24 : wbits == 16 ? DVDA_PCM_WAV16 : DVDA_PCM_INTERLEAVED) != DVDA_HIP_OK)
+            return 0;
+        for (int attempt = 0;; attempt++) {
+            uint64_t meta[4] = {0, cut, 0, stride};
+            const uint64_t words = wbits ? (stride * info.channels * (wbits / 8) + 3) / 4 + 4 : stride * info.channels;
+            if (!win_grow_dev((void **)&w->d_pcm, &w->cap_pcm, words * sizeof(int32_t)) ||
+                hipMemcpy(w->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice) != hipSuccess)
+                return 0;
+            if (dvda_mlp_hip_decode(w->ctx, w->d_pcm, w->d_meta + 2, w->d_meta + 3, NULL) != DVDA_HIP_OK ||
+                dvda_mlp_hip_stream_info(w->ctx, &info, 1, NULL) != DVDA_HIP_OK)
+                return 0;
+            if (!(info.status & DVDA_ST_OVERFLOW))
+                break;
+            if (attempt)
+                return 0;
+            stride = (info.pcm_frames + 3) & ~(uint64_t)3;       /* access units longer than the standard length */
+        }
+        w->status |= info.status;
+        if (info.status & ~(uint32_t)DVDA_ST_BENIGN)
+            return 0;                            /* the reference assert()s on such a stream */
+        if (!w->info.channels)
+            w->info = info;
+        /* ---- the history at the cut, for the next window */
+        if (!final) {
+            uint32_t last_seg = 0;
+            uint64_t dummy = 0;
+            (void)win_last_cut(w, n_seg, &last_seg, &dummy);
+            if (dvda_mlp_hip_segment_fir(w->ctx, last_seg, w->fir, NULL) != DVDA_HIP_OK)
+                return 0;
+            w->have_fir = 1;
+        }
+        /* ---- PCM (or payload) to the host buffer */
+        const size_t bytes = (size_t)info.pcm_frames * info.channels * (wbits ? wbits / 8 : 4);
+        if (bytes > out->cap) {
+            if (out->host) {
+                (void)hipHostFree(out->host);
+                w->host_now -= out->cap;
+            }
+            out->host = NULL;
+            out->cap = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc((void **)&out->host, out->cap, hipHostMallocDefault) != hipSuccess) {
+                out->cap = 0;
+                return 0;
+            }
+            win_host_add(w, out->cap);
+        }
+        if (bytes && hipMemcpy(out->host, w->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            return 0;
+        out->frames = info.pcm_frames;
+        w->frames_total += info.pcm_frames;
+        win_dev_sample(w);
+        w->finished = final;
+        return 1;
+    }
+}
+
+static void *win_thread(void *arg)
+{
+    struct mlp_windows *w = arg;
+    if (hipSetDevice(w->device) != hipSuccess) {
+        pthread_mutex_lock(&w->mu);
+        w->failed = 1;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        return NULL;
+    }
+    for (;;) {
+        pthread_mutex_lock(&w->mu);
+        while (!w->stop && w->count == WIN_SLOTS)
+            pthread_cond_wait(&w->cv, &w->mu);
+        if (w->stop || w->finished || w->failed) {
+            pthread_mutex_unlock(&w->mu);
+            break;
+        }
+        struct win_slot *out = &w->slot[w->head];
+        pthread_mutex_unlock(&w->mu);
+        const int ok = win_produce(w, out);
+        pthread_mutex_lock(&w->mu);
+        if (!ok)
+            w->failed = 1;
+        else if (out->frames) {
+            w->head = (w->head + 1) % WIN_SLOTS;
+            w->count++;
+        }
+        pthread_cond_broadcast(&w->cv);
+        const int done = w->finished || w->failed;
+        pthread_mutex_unlock(&w->mu);
+        if (done)
+            break;
+    }
+    return NULL;
+}
+
+/* the window the consumer reads from: waits for the producer; NULL at the end of the track (or on failure) */
+static struct win_slot *win_current(struct mlp_windows *w)
+{
+    struct win_slot *s = NULL;
+    pthread_mutex_lock(&w->mu);
+    while (w->count == 0 && !w->finished && !w->failed)
+        pthread_cond_wait(&w->cv, &w->mu);
+    if (w->count)
+        s = &w->slot[w->tail];
+    pthread_mutex_unlock(&w->mu);
+    return s;
+}
+static void win_release(struct mlp_windows *w)
+{
+    pthread_mutex_lock(&w->mu);
+    w->tail = (w->tail + 1) % WIN_SLOTS;
+    w->count--;
+    w->served_in_slot = 0;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+}
+
+static DVDA_Track_Reader *open_mlp_windowed(const DVDA_Track *k)
+{
+    struct mlp_windows *w = calloc(1, sizeof(*w));
+    DVDA_Track_Reader *r = calloc(1, sizeof(*r));
+    size_t tot = 0;
+    if (!w || !r) {
+        free(w);
+        free(r);
+        return NULL;
+    }
+    pthread_mutex_init(&w->mu, NULL);
+    pthread_cond_init(&w->cv, NULL);
+    r->win = w;
+    r->codec = DVDA_MLP;
+    w->device = g_device;
+    w->first = w->next = k->s.first;
+    w->last = k->s.last >= k->s.first ? k->s.last : k->s.first;
+    w->window = window_sectors();
+    (void)hipMemGetInfo(&w->dev_free0, &tot);
+    aob_open_all(&w->aobs, k->dir, k->titleset);
+    if (w->aobs.n == 0)
+        goto fail;
+    /* the first window in this thread: the stream's parameters are known when the reader is handed out.  (The output
+       layout is decided by them: a first pass as int32 tells the bit depth, and only a 16- or 24-bit stream can be
+       decoded straight into the payload -- so the first window is decoded once more when it is) */
+    w->wav_bits = 0;
+    {
+        struct win_slot *out = &w->slot[0];
+        for (;;) {
+            if (!win_produce(w, out))
+                goto fail;
+            if (out->frames || w->finished)
+                break;
+        }
+        if (!w->info.channels)
+            goto fail;
+        const unsigned wbits = g_wav_output ? bits_of(w->info.group0_bps) : 0;
+        if (wbits == 16 || wbits == 24) {
+            /* again, as the payload: back to the track's first sector, nothing kept */
+            w->wav_bits = (int)wbits;
+            w->next = w->first;
+            w->started = w->finished = 0;
+            w->carry_len = 0;
+            w->have_fir = 0;
+            w->frames_total = 0;
+            for (;;) {
+                if (!win_produce(w, out))
+                    goto fail;
+                if (out->frames || w->finished)
+                    break;
+            }
+        }
+        if (out->frames) {
+            w->head = 1 % WIN_SLOTS;
+            w->count = 1;
+        }
+    }
+    r->bps_code[0] = w->info.group0_bps;
+    r->bps_code[1] = w->info.group1_bps;
+    r->rate_code[0] = w->info.group0_rate;
+    r->rate_code[1] = w->info.group1_rate;
+    r->assignment = w->info.assignment;
+    r->channels = channels_of(w->info.assignment);
+    r->status = w->status;
+    r->interleaved = 1;
+    if (r->channels == 0 || r->channels != w->info.channels)
+        goto fail;
+    if (!w->finished) {
+        if (pthread_create(&w->th, NULL, win_thread, w) != 0)
+            goto fail;
+        w->th_started = 1;
+    }
+    return r;
+fail:
+    reader_free(r);
+    return NULL;
+}
+
 /* ------------------------------------------------------------------ PCM track */
 static DVDA_Track_Reader *open_pcm(struct aob_set *aobs, const DVDA_Track *k, const uint8_t *params)
 {
@@ -852,7 +1374,7 @@ DVDA_Track_Reader *dvda_hip_open_track_reader_on(const DVDA_Track *k, int device
     return r;
 }
 
-int dvda_hip_reader_wav_only(const DVDA_Track_Reader *r) { return r && r->d_wav != NULL; }
+int dvda_hip_reader_wav_only(const DVDA_Track_Reader *r) { return r && (r->d_wav != NULL || (r->win && r->win->wav_bits)); }
 
 DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *k)
 {
@@ -881,7 +1403,9 @@ DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *k)
         if (rc == 0)
             continue;
         if (codec == CODEC_MLP) {
-            r = open_mlp(&aobs, k);
+            /* a long track is read and decoded window by window (bounded memory); a short one as one batch */
+            const unsigned in_track = k->s.last >= k->s.first ? k->s.last - k->s.first + 1 : 1;
+            r = in_track > window_sectors() ? open_mlp_windowed(k) : open_mlp(&aobs, k);
         } else if (codec == CODEC_PCM && body_len >= 9 && pad2 >= 9) {
             r = open_pcm(&aobs, k, body);
         }
@@ -898,8 +1422,33 @@ dvda_codec_t dvda_codec(const DVDA_Track_Reader *r) { return r->codec; }
 unsigned dvda_bits_per_sample(const DVDA_Track_Reader *r) { return bits_of(r->bps_code[0]); }
 unsigned dvda_sample_rate(const DVDA_Track_Reader *r) { return rate_of(r->rate_code[0]); }
 unsigned dvda_channel_count(const DVDA_Track_Reader *r) { return channels_of(r->assignment); }
-unsigned dvda_hip_reader_status(const DVDA_Track_Reader *r) { return r->status; }
-unsigned long long dvda_hip_reader_total_frames(const DVDA_Track_Reader *r) { return r->frames; }
+unsigned dvda_hip_reader_status(const DVDA_Track_Reader *r) { return r->win ? r->win->status : r->status; }
+/* (a track read in windows knows its length when its last window has been decoded: until then, the frames so far) */
+unsigned long long dvda_hip_reader_total_frames(const DVDA_Track_Reader *r)
+{
+    return r->win ? r->win->frames_total : r->frames;
+}
+int dvda_hip_reader_windowed(const DVDA_Track_Reader *r) { return r && r->win != NULL; }
+int dvda_hip_reader_failed(const DVDA_Track_Reader *r)
+{
+    int f = 0;
+    if (r && r->win) {
+        pthread_mutex_lock(&r->win->mu);
+        f = r->win->failed;
+        pthread_mutex_unlock(&r->win->mu);
+    }
+    return f;
+}
+int dvda_hip_reader_memory(const DVDA_Track_Reader *r, unsigned long long *host_peak, unsigned long long *device_peak)
+{
+    if (!r || !r->win)
+        return 0;
+    if (host_peak)
+        *host_peak = r->win->host_peak;
+    if (device_peak)
+        *device_peak = r->win->dev_peak;
+    return 1;
+}
 
 unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *r)
 {
@@ -916,6 +1465,28 @@ unsigned dvda_riff_wave_channel_mask(const DVDA_Track_Reader *r)
 
 unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
 {
+    if (r->win) {
+        /* a track read in windows: frames out of the window in hand, the next one when it is used up */
+        struct mlp_windows *w = r->win;
+        unsigned done = 0;
+        if (w->wav_bits)
+            return 0;           /* payload only (dvda_hip_reader_wav_next) */
+        while (done < pcm_frames) {
+            struct win_slot *s = win_current(w);
+            if (!s)
+                break;
+            const uint64_t left = s->frames - w->served_in_slot;
+            const unsigned n = left < pcm_frames - done ? (unsigned)left : pcm_frames - done;
+            memcpy(buffer + (size_t)done * r->channels,
+                   (const int32_t *)s->host + (size_t)w->served_in_slot * r->channels, (size_t)n * r->channels * sizeof(int32_t));
+            w->served_in_slot += n;
+            done += n;
+            if (w->served_in_slot == s->frames)
+                win_release(w);
+        }
+        r->served += done;
+        return done;
+    }
     if (r->d_wav)
         return 0;               /* opened under dvda_hip_set_wav_output(1): the track exists as WAV payload only */
     if (!r->pcm) {
@@ -943,8 +1514,67 @@ unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
     return n;
 }
 
+/* The payload window by window: *payload = the next piece of the track's WAV data bytes (valid until the next call on
+ * this reader), returns its size, 0 at the end of the track.  On a reader that is not windowed: the whole payload, once.
+ * An int32 windowed reader (no wav output) is packed on the host, write_signed per value (src/bitstream.c:2846-2857). */
+unsigned long long dvda_hip_reader_wav_next(DVDA_Track_Reader *r, const unsigned char **payload)
+{
+    *payload = NULL;
+    if (!r->win)
+        return r->served == 0 ? dvda_hip_reader_wav_payload(r, payload) : 0;
+    struct mlp_windows *w = r->win;
+    const unsigned bits = bits_of(r->bps_code[0]);
+    if (bits != 16 && bits != 24)
+        return 0;
+    if (w->served_in_slot)                       /* the piece handed out by the call before: done with */
+        win_release(w);
+    struct win_slot *s = win_current(w);
+    if (!s)
+        return 0;
+    const size_t nb = bits / 8;
+    if (!w->wav_bits) {
+        /* int32 frames -> payload, in place (the packed form is shorter) */
+        const int32_t *src = (const int32_t *)s->host;
+        uint8_t *dst = s->host;
+        const uint64_t n = s->frames * r->channels;
+        const uint32_t sign = 1u << (bits - 1);
+        for (uint64_t i = 0; i < n; i++) {
+            const int32_t v = src[i];
+            const uint32_t u = ((uint32_t)v & (sign - 1)) | (v < 0 ? sign : 0u);
+            for (size_t b = 0; b < nb; b++)
+                dst[i * nb + b] = (uint8_t)(u >> (8 * b));
+        }
+    }
+    w->served_in_slot = s->frames;               /* released by the next call */
+    r->served += s->frames;
+    *payload = s->host;
+    return (unsigned long long)s->frames * r->channels * nb;
+}
+
 unsigned long long dvda_hip_reader_wav_payload(DVDA_Track_Reader *r, const unsigned char **payload)
 {
+    if (r->win) {
+        /* the whole payload of a windowed reader, for callers of the one-piece interface: every window appended (this
+           is the one call on such a reader whose memory grows with the track) */
+        struct mlp_windows *w = r->win;
+        size_t have = 0, cap = 0;
+        const unsigned char *piece = NULL;
+        unsigned long long n;
+        *payload = NULL;
+        while ((n = dvda_hip_reader_wav_next(r, &piece)) != 0) {
+            if (have + n > cap) {
+                cap = (have + n) * 2;
+                uint8_t *g = realloc(w->whole, cap);
+                if (!g)
+                    return 0;
+                w->whole = g;
+            }
+            memcpy(w->whole + have, piece, n);
+            have += n;
+        }
+        *payload = w->whole;
+        return have;
+    }
     const unsigned bits = bits_of(r->bps_code[0]);
     const uint64_t left = r->frames - r->served;
     const uint64_t bytes = left * r->channels * (bits / 8);

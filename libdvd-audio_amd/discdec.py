@@ -23,6 +23,7 @@ EXPORTS = [
     "dvda_sample_rate", "dvda_channel_count", "dvda_riff_wave_channel_mask", "dvda_read",
     "dvda_hip_set_device", "dvda_hip_set_wav_output", "dvda_hip_reader_status", "dvda_hip_reader_total_frames",
     "dvda_hip_reader_wav_payload", "dvda_hip_open_track_reader_on", "dvda_hip_reader_wav_only",
+    "dvda_hip_reader_wav_next", "dvda_hip_reader_windowed", "dvda_hip_reader_memory", "dvda_hip_reader_failed",
 ]
 
 _lib = None
@@ -71,6 +72,14 @@ def lib():
         L.dvda_hip_reader_total_frames.argtypes = [vp]
         L.dvda_hip_reader_wav_payload.restype = ctypes.c_ulonglong
         L.dvda_hip_reader_wav_payload.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_ubyte))]
+        L.dvda_hip_reader_wav_next.restype = ctypes.c_ulonglong
+        L.dvda_hip_reader_wav_next.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_ubyte))]
+        L.dvda_hip_reader_windowed.restype = ctypes.c_int
+        L.dvda_hip_reader_windowed.argtypes = [vp]
+        L.dvda_hip_reader_failed.restype = ctypes.c_int
+        L.dvda_hip_reader_failed.argtypes = [vp]
+        L.dvda_hip_reader_memory.restype = ctypes.c_int
+        L.dvda_hip_reader_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
         _lib = L
     return _lib
 
@@ -101,13 +110,15 @@ def layout(audio_ts, titleset=1):
     return out
 
 
-def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0, fused=False):
+def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0, fused=False, pieces=False):
     """Decodes one track on the GPU.  Returns a dict: codec ("PCM"/"MLP"), bits, rate, channels,
     mask, status, and pcm = int32 [frames, channels] (interleaved, RIFF-WAVE order) read with
     dvda_read() in `chunk`-frame calls -- or, with wav=True, payload = the WAV data bytes packed
     on the GPU; fused=True (with wav=True) opens the reader as a WAV-payload-only one (dvda_hip_open_track_reader_on):
     MLP tracks are decoded straight into that payload, no int32 PCM and no packing pass.  Device and output form are
-    the READER's: no process-wide switch is left behind."""
+    the READER's: no process-wide switch is left behind.  pieces=True (with wav=True) takes the payload piece by piece
+    (dvda_hip_reader_wav_next: a long track's windows).  A track read in windows (info["windowed"]) reports the peaks of
+    what it held in info["host_peak"] / info["device_peak"]; info["frames"] is then the count at the END of the read."""
     L = lib()
     d = L.dvda_open(audio_ts.encode(), None)
     if not d:
@@ -125,7 +136,19 @@ def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0
                 "rate": L.dvda_sample_rate(r), "channels": ch, "mask": L.dvda_riff_wave_channel_mask(r),
                 "status": L.dvda_hip_reader_status(r), "frames": int(L.dvda_hip_reader_total_frames(r)),
                 "wav_only": bool(L.dvda_hip_reader_wav_only(r))}
-        if wav:
+        info["windowed"] = bool(L.dvda_hip_reader_windowed(r))
+        if wav and pieces:
+            got, sizes = [], []
+            while True:
+                p = ctypes.POINTER(ctypes.c_ubyte)()
+                n = L.dvda_hip_reader_wav_next(r, ctypes.byref(p))
+                if n == 0:
+                    break
+                got.append(bytes(ctypes.string_at(p, n)))
+                sizes.append(int(n))
+            info["payload"] = b"".join(got)
+            info["piece_sizes"] = sizes
+        elif wav:
             p = ctypes.POINTER(ctypes.c_ubyte)()
             n = L.dvda_hip_reader_wav_payload(r, ctypes.byref(p))
             info["payload"] = bytes(ctypes.string_at(p, n)) if n else b""
@@ -138,6 +161,11 @@ def read_track(audio_ts, titleset, title, track, chunk=4096, wav=False, device=0
                     break
                 parts.append(np.frombuffer(buf, dtype=np.int32, count=n * ch).reshape(n, ch).copy())
             info["pcm"] = np.concatenate(parts) if parts else np.zeros((0, ch), np.int32)
+        if info["windowed"]:
+            hp, dp = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+            L.dvda_hip_reader_memory(r, ctypes.byref(hp), ctypes.byref(dp))
+            info.update(host_peak=int(hp.value), device_peak=int(dp.value), frames=int(L.dvda_hip_reader_total_frames(r)),
+                        failed=bool(L.dvda_hip_reader_failed(r)), status=L.dvda_hip_reader_status(r))
         return info
     finally:
         if r:

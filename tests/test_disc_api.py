@@ -142,6 +142,69 @@ def test_mlp_tracks_decoded_straight_into_the_wav_payload(pkg, oracle):
         assert not again["wav_only"] and again["pcm"].shape[0] == again["frames"] > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["plain", "chained", "two_substreams"])
+def test_long_tracks_are_read_in_windows_of_bounded_memory(pkg, oracle, kind):
+    """A track of more sectors than a window (DVDA_WINDOW_SECTORS) is read, demultiplexed and decoded window by window
+    (csrc/dvda_disc.c, "MLP track, in windows"; reference: src/dvd-audio.c:751-795 streams a track of any length): the
+    windows are cut at major syncs, the bytes behind the cut and the FIR history at it (src/mlp.c:297-304: never cleared --
+    the chained title needs it at every cut) are all that crosses a cut.  dvda_read() and the payload pieces give the
+    oracle's PCM; what the reader holds does not grow with the track."""
+    syn, disc = pkg.synth, pkg.disc
+    feats = dict(plain={}, chained=dict(profile=1, features=syn.SF["CHAINED"] | syn.SF["FIRRAND"]),
+                 two_substreams=dict(n_substreams=2))[kind]
+    peaks = {}
+    old = os.environ.get("DVDA_WINDOW_SECTORS")
+    os.environ["DVDA_WINDOW_SECTORS"] = "128"                   # 256 KiB of sectors: a dozen windows and more
+    try:
+        for n_aus in (1600, 4800):
+            kw = dict(assignment=12, rate_code=1, n_substreams=1, n_aus=n_aus)
+            kw.update(feats)
+            b, f = syn.stream(syn.make_cfg(**kw), 77)
+            want, r, st = oracle.decode(b, 6, f)
+            assert st == 0 and r == f
+            secs = disc.mlp_track_sectors(b)
+            assert len(secs) > 4 * 128
+            with tempfile.TemporaryDirectory() as tmp:
+                # two tracks: the first one long (windows; its end is the end-of-track rule on its LAST window), the
+                # second short enough to be one batch -- together the whole stream
+                # (a chained title is one track: a second track would start on FIR taps with a fresh decoder, where the
+                #  reference reads out of its arrays -- src/mlp.c:1278-1290 -- and this library refuses)
+                if kind == "chained":
+                    ats = disc.write_disc_titles(tmp, [disc.split_tracks(secs, [], [f], 1)])
+                    a = pkg.discdec.read_track(ats, 1, 1, 1, chunk=3001)
+                    tail = np.zeros((0, 6), np.int32)
+                else:
+                    cutp = len(secs) - 40
+                    ats = disc.write_disc_titles(tmp, [disc.split_tracks(secs, [cutp], [f - 80, 80], 1)])
+                    a = pkg.discdec.read_track(ats, 1, 1, 1, chunk=3001)
+                    z = pkg.discdec.read_track(ats, 1, 1, 2)
+                    assert not z["windowed"]
+                    tail = z["pcm"]
+                assert a["windowed"] and not a["failed"]
+                assert a["status"] & ~pkg.hipdec.ST_BENIGN == 0
+                assert a["frames"] == len(a["pcm"]) and len(a["pcm"]) + len(tail) == f
+                assert np.array_equal(np.concatenate([a["pcm"], tail]).T, want)
+                # the payload, piece by piece: int32 windows packed on the host, and windows decoded straight into it
+                for fused in (False, True):
+                    w = pkg.discdec.read_track(ats, 1, 1, 1, wav=True, fused=fused, pieces=True)
+                    assert w["windowed"] and len(w["piece_sizes"]) >= 4 and not w["failed"]
+                    assert w["payload"] == oracle.wav_pack(a["pcm"].T, 24)
+                whole = pkg.discdec.read_track(ats, 1, 1, 1, wav=True, fused=True)       # the one-piece interface still works
+                assert whole["payload"] == oracle.wav_pack(a["pcm"].T, 24)
+                peaks[n_aus] = (a["host_peak"], a["device_peak"], len(a["pcm"]) * 6 * 4)
+        # three times the track, the same windows: what the reader held did not grow with it, and is a fraction of the PCM
+        (h1, d1, p1), (h2, d2, p2) = peaks[1600], peaks[4800]
+        assert p2 > 2.5 * p1
+        assert h2 <= 1.35 * h1 + (1 << 20) and d2 <= 1.35 * d1 + (8 << 20)
+        assert h2 < p2 / 2
+    finally:
+        if old is None:
+            del os.environ["DVDA_WINDOW_SECTORS"]
+        else:
+            os.environ["DVDA_WINDOW_SECTORS"] = old
+
+
 REF_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_ref")
 NATIVE_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_native")
 

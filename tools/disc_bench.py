@@ -68,6 +68,14 @@ def main():
                 r = subprocess.run(cmd, capture_output=True, text=True, env=env)
                 dt = time.time() - t0
                 assert r.returncode == 0, r.stderr[-2000:]
+            if name == "gpu":
+                import re
+                pk = re.findall(r"host peak ([0-9.]+) MB, device peak ([0-9.]+) MB, payload ([0-9.]+) MB", r.stdout)
+                if pk:
+                    res["windowed_tracks"] = len(pk)
+                    res["host_peak_mb_max"] = max(float(x[0]) for x in pk)
+                    res["device_peak_mb_max"] = max(float(x[1]) for x in pk)
+                    res["payload_mb_max"] = max(float(x[2]) for x in pk)
             res[name + "_seconds"] = round(dt, 3)
             res[name + "_msamples_per_s"] = round(samples / dt / 1e6, 1)
             outs[name] = digest(out)

@@ -75,14 +75,34 @@ static int extract(DVDA_Title *title, unsigned track_num, const char *dir, int d
     const unsigned channels = dvda_channel_count(r), bits = dvda_bits_per_sample(r), rate = dvda_sample_rate(r);
     printf("* Extracting %s track  %u channels  %u Hz  %u bps\n", dvda_codec(r) == DVDA_MLP ? "MLP" : "PCM",
            channels, rate, bits);
-    const unsigned long long frames = dvda_hip_reader_total_frames(r);
-    const unsigned char *payload = NULL;
-    const unsigned long long bytes = dvda_hip_reader_wav_payload(r, &payload);
+    /* the header first, as the reference does (utils/dvda2wav.c:316-343: a placeholder, the data chunk as it is read, the
+       finished header written over it) -- a long track comes window by window and knows its length at its end; a short
+       one hands out its whole payload as the one and only piece */
     uint8_t h[68];
-    wave_header(h, rate, channels, dvda_riff_wave_channel_mask(r), bits, (unsigned)frames);
-    int ok = fwrite(h, 1, sizeof(h), f) == sizeof(h) && (bytes == 0 || fwrite(payload, 1, bytes, f) == bytes);
+    const unsigned mask = dvda_riff_wave_channel_mask(r);
+    wave_header(h, rate, channels, mask, bits, 0);
+    int ok = fwrite(h, 1, sizeof(h), f) == sizeof(h);
+    unsigned long long bytes = 0, piece;
+    const unsigned char *payload = NULL;
+    while (ok && (piece = dvda_hip_reader_wav_next(r, &payload)) != 0) {
+        ok = fwrite(payload, 1, piece, f) == piece;
+        bytes += piece;
+    }
+    const unsigned long long frames = dvda_hip_reader_total_frames(r);
+    if (dvda_hip_reader_windowed(r)) {
+        /* a track read in windows: what it held at most (tools/disc_bench.py reads this line) */
+        unsigned long long hp = 0, dp = 0;
+        dvda_hip_reader_memory(r, &hp, &dp);
+        printf("* Read in windows: host peak %.1f MB, device peak %.1f MB, payload %.1f MB\n", hp / 1e6, dp / 1e6, bytes / 1e6);
+    }
+    if (ok) {
+        wave_header(h, rate, channels, mask, bits, (unsigned)frames);
+        ok = fseek(f, 0, SEEK_SET) == 0 && fwrite(h, 1, sizeof(h), f) == sizeof(h);
+    }
     ok = fclose(f) == 0 && ok;
-    if (ok && bytes == frames * channels * (bits / 8))
+    /* (a window that could not be read or decoded ends the pieces early: that is a failed track, not a short one) */
+    ok = ok && bytes == frames * channels * (bits / 8) && !dvda_hip_reader_failed(r);
+    if (ok)
         printf("* Wrote: \"%s\"\n", path);
     else
         fprintf(stderr, "*** Error: writing \"%s\"\n", path);
