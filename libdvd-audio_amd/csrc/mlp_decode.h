@@ -73,7 +73,7 @@ constexpr uint32_t YIELD_LONELY = 48;
 // the filter's coefficients one per register instead of int16 pairs (saves eight unpacks per sample, costs 24 registers
 // in the six-channel instance)
 #ifndef DVDA_CF_UNPACKED
-#define DVDA_CF_UNPACKED 0
+#define DVDA_CF_UNPACKED 1
 #endif
 // experiments of round 5 (tools/ab_build.py): the wave stores its PCM together / fills its rings together
 #ifndef DVDA_COOP_OUT
@@ -82,8 +82,27 @@ constexpr uint32_t YIELD_LONELY = 48;
 // the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
 // the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
 // the one LDS round trip per row they hide)
+// the synchronous ring fill as a call (rounds 1-4) or inlined where it is used (round 5: a call in the row loop's cold
+// branch made the register allocator keep the loop's state clear of the caller-saved registers by copying it -- sixty
+// moves per PCM frame on the hot path)
+#ifndef DVDA_FILL_CALL
+#define DVDA_FILL_CALL 0
+#endif
+#if DVDA_FILL_CALL
+#define DVDA_FILL_INLINE __attribute__((noinline))
+#else
+#define DVDA_FILL_INLINE __forceinline__
+#endif
 #ifndef DVDA_CARRY_WINDOW
 #define DVDA_CARRY_WINDOW 0
+#endif
+// the slot loop: 1 = one version, slots under the execution mask of the lanes that carry them; 0 = three versions
+// (all lanes NS slots / all lanes two / lanes that disagree: selects), picked per row
+#ifndef DVDA_MAT_UNPACKED
+#define DVDA_MAT_UNPACKED 1
+#endif
+#ifndef DVDA_SLOT_MODE
+#define DVDA_SLOT_MODE 1
 #endif
 #ifndef DVDA_UNI2
 #define DVDA_UNI2 1
@@ -398,7 +417,7 @@ __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, cons
 // Synchronous fill of one 64-byte chunk into a lane's ring slots (used after
 // seeks and inside long headers; the row loop prefetches instead).
 // dst: this lane's 16-byte slot in the chunk's first plane; planes are 64 slots apart.
-__device__ __attribute__((noinline)) void ring_fill_sync(const uint4 *src, uint32_t *dst, bool first_plane)
+__device__ DVDA_FILL_INLINE void ring_fill_sync(const uint4 *src, uint32_t *dst, bool first_plane)
 {
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     ring_store16(dst, a, b, c, d, first_plane);
@@ -879,9 +898,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     };
     // FIR coefficients, zero beyond the order: one register each where the filter runs (round 5: the row loop
     // unpacked eight int16 halves per sample); the chain parse pass only hands them on and keeps them packed
-    // (the four-slot instance of the two-wave layout has the registers: 5.52 -> 5.35 ms on the two-substream batch; the
-    //  six-slot instance does not: 3.64 -> 4.25 ms with the spills that buys)
-    constexpr bool CFU = (DVDA_CF_UNPACKED || NS <= 4) && !PARSE;
+    // (with three versions of the slot loop the six-slot instance had no registers for them -- 3.64 -> 4.25 ms with the
+    //  spills -- ; with the one masked version it runs in 215 registers and has: 3.65 -> 3.56 ms)
+    constexpr bool CFU = (DVDA_CF_UNPACKED || NS <= 4) && !PARSE && !GENERAL;     // (the sequential pass has no registers to spare)
     constexpr int CFW = CFU ? 8 : 4;
     int32_t cf[NS][CFW];
     uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
@@ -890,6 +909,16 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t mreg[2][4];              // channel coefficients of matrices 0 and 1 (int16 pairs), zero
                                       // beyond max_matrix_channel
     uint32_t mnoise[2] = {0, 0};      // their two noise coefficients (follow channel max_matrix_channel)
+    // (round 5) the one-lane fast pass keeps those two matrices one coefficient per register -- [0..5] the channels,
+    // [6], [7] the noise -- and does not unpack sixteen halves per PCM frame (the instances that hand the matrices to
+    // another lane or to a record keep the packed form: they have no registers to spare, or are not bound by this)
+    constexpr bool MU = DVDA_MAT_UNPACKED && !PAIRED && !GENERAL && !PARSE;
+    int32_t mu[2][MU ? 8 : 1];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int j = 0; j < (MU ? 8 : 1); j++)
+            mu[m][j] = 0;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
 #pragma unroll
@@ -984,10 +1013,41 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 ch[c] = keep;
             }
         };
+        // the same from coefficients held one per register
+        auto one_matrix_u = [&](const int32_t(&c8)[MU ? 8 : 1], uint32_t m, bool on) {
+            int64_t acc = (int64_t)n0 * (int64_t)c8[MU ? 6 : 0] + (int64_t)n1 * (int64_t)c8[MU ? 7 : 0];
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                acc += (int64_t)ch[c] * (int64_t)c8[MU ? c : 0];
+            const uint32_t oc = nib(outch_pack, m);
+            const int32_t nv = (int32_t)((uint32_t)mask_q((int32_t)(acc >> 14), nib(qss_A, oc)) +
+                                         ((bypass_bits >> m) & 1u));
+            uint32_t oce = on ? oc : 0xFFu;
+            asm volatile("" : "+v"(oce));
+            uint64_t hit[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                hit[c] = __builtin_amdgcn_ballot_w64((uint32_t)c == oce);
+                asm volatile("" : "+s"(hit[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                int32_t keep = ch[c];
+                asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(keep) : "v"(nv), "s"(hit[c]));
+                ch[c] = keep;
+            }
+        };
+        if constexpr (MU) {
+            if (__any(matrix_len > 0))
+                one_matrix_u(mu[0], 0, matrix_len > 0);
+            if (__any(matrix_len > 1))
+                one_matrix_u(mu[1], 1, matrix_len > 1);
+        } else {
         if (__any(matrix_len > 0))
             one_matrix(mreg[0], mnoise[0], 0, matrix_len > 0);
         if (__any(matrix_len > 1))
             one_matrix(mreg[1], mnoise[1], 1, matrix_len > 1);
+        }
         if (GENERAL && __builtin_expect(__any(matrix_len > 2), 0)) {   // (fast pass: such a segment is ST_COLD)
             for (uint32_t m = 2; m < matrix_len; m++) {    // cold: matrices 2.. live in the workspace
                 DVDA_COV(9);
@@ -1308,8 +1368,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                             for (int mm = 0; mm < 2; mm++)
 #pragma unroll
                                                 for (int jj = 0; jj < 4; jj++)
-                                                    if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1))
+                                                    if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1)) {
                                                         mreg[mm][jj] = word;
+                                                        if constexpr (MU) {
+                                                            if (jj < 3) {                           // ([6], [7] are the noise's)
+                                                                mu[mm][MU ? 2 * jj : 0] = lo16(word);
+                                                                mu[mm][MU ? 2 * jj + 1 : 0] = hi16(word);
+                                                            }
+                                                        }
+                                                    }
                                         }
                                     } else {
                                         pair = (uint32_t)vc & 0xFFFFu;
@@ -1320,6 +1387,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                     mnoise[0] = noise;
                                 if (m == 1)
                                     mnoise[1] = noise;
+                                if constexpr (MU) {
+#pragma unroll
+                                    for (int mm = 0; mm < 2; mm++)
+                                        if ((uint32_t)mm == m) {
+                                            mu[mm][MU ? 6 : 0] = lo16(noise);
+                                            mu[mm][MU ? 7 : 0] = hi16(noise);
+                                        }
+                                }
                             }
                         } else if (restart) {
                             matrix_len = 0;
@@ -1736,7 +1811,15 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             //  with a scalar count and a branch behind every slot the compiler moved the slot's whole history back into
             //  other registers at every join)
             constexpr int NU = decltype(uni_c)::value;
-            constexpr bool UNI = NU != 0;
+            constexpr bool UNI = NU > 0;
+            // NU < 0 (round 5, what the library runs): ONE version of the slot loop for every wave.  A slot's body -- symbol,
+            // filter, history shift -- runs under the execution mask of the lanes that carry the slot (the compiler's
+            // s_and_saveexec around an `if`), so nothing in it selects lane by lane; a slot no lane carries is skipped.
+            // With one version there is no place where several versions' register assignments meet: the three-version
+            // form paid ~60 register copies per PCM frame for that (SQ_INSTS_VALU 673 per wave-row against 619 in an
+            // instance with one version only; tools/probe/r05_fixpmc.sh).
+            constexpr bool MSK = NU < 0;
+            constexpr bool NOSEL = UNI || MSK;
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
             // all of the row's bypassed LSBs (at most one per matrix) are cut from the window at once
             // and dealt to their matrices in stream order -- straight-line, no per-bit read
@@ -1774,7 +1857,16 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
                 const bool in = UNI || (uint32_t)k < nslots;
                 uint64_t m_in = 0;
-                if constexpr (UNI) {
+                if constexpr (MSK) {
+                    // (the window the slot before asked for -- by hand, below -- is waited for HERE, whoever goes on:
+                    //  its registers must not be handed to anything else with the read still on its way)
+                    if (DVDA_EARLY_WINDOW && k > 0)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win));
+                    if constexpr (!WSPEC)
+                        val[k] = 0;
+                    if (k >= 2 && !__any(in))
+                        continue;
+                } else if constexpr (UNI) {
                     if (k >= NU) {
                         if constexpr (!WSPEC)
                             val[k] = 0;
@@ -1792,7 +1884,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     m_in = __builtin_amdgcn_ballot_w64(in);
                     asm volatile("" : "+s"(m_in));
                 }
-                const uint32_t pkk = UNI ? pk[k] : (in ? pk[k] : 0u);
+                if (!MSK || in) {
+                const uint32_t pkk = NOSEL ? pk[k] : (in ? pk[k] : 0u);
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
                 const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
@@ -1819,17 +1912,20 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 // symbol for LDS (tools/stamp_run.py) -- and waited for by hand at the next slot's top (the compiler does
                 // not count an asm's LDS read: its own waits can only come out longer; tools/hazard_check.py checks that
                 // nothing touches the pair in between).  The last slot asks for nothing.
-                uint64_t win_next = 0;
-                if constexpr (UNI && DVDA_EARLY_WINDOW) {
-                    if (k + 1 < NU)
-                        // (the slot's newest history pair and the window in hand ride through the asm: the filter and the
-                        //  cutting of the LSBs below start from them, so the scheduler cannot put either in front of the read)
-                        asm volatile("ds_read2st64_b32 %0, %3 offset1:1" : "=v"(win_next), "+v"(sp[k][0]), "+v"(win) : "v"(rd.window_lds()));
-                } else {
-                    win_next = rd.window();                       // (the last slot's read serves nobody: dropped by the compiler)
-                }
+                // (the LSBs are cut first: the read below lands in the window's own registers.  A second pair for it had
+                //  to be copied into `win` where the lanes that carry the slot meet those that do not -- a copy the
+                //  compiler placed, rightly by all it can know, in front of the wait: of registers whose data had not
+                //  arrived.  tests/test_gpu_parity.py::test_fuzz_fast_features found it.)
                 const uint32_t top2 = (uint32_t)((win << o2) >> 32);
                 const uint32_t lsbv = (top2 >> 1) >> (31u - lb);          // lb == 0 -> 0
+                if constexpr (NOSEL && DVDA_EARLY_WINDOW) {
+                    if (k + 1 < (MSK ? NS : NU))
+                        // (the slot's newest history pair rides through the asm: the filter below starts from it, so the
+                        //  scheduler cannot put the multiply-adds in front of the read)
+                        asm volatile("ds_read2st64_b32 %0, %2 offset1:1" : "+v"(win), "+v"(sp[k][0]) : "v"(rd.window_lds()));
+                } else {
+                    win = rd.window();                            // (the last slot's read serves nobody: dropped by the compiler)
+                }
                 const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
                 int32_t value;
                 if constexpr (PARSE) {
@@ -1864,27 +1960,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 const int32_t ssum = (int32_t)(acc >> shift);
                 value = mask_q((int32_t)((uint32_t)ssum + (uint32_t)residual), q);
-                if constexpr (UNI) {
-                    // the history moves up by one value: pair j takes the odd half of pair j - 1 and its own even half
-                    // (v_pk_mov_b32: low result = the half of source 0 that op_sel[0] names, high result = the half of
-                    //  source 1 that op_sel[1] names)
+                // the history moves up by one value: pair j takes the odd half of pair j - 1 and its own even half
+                // (v_pk_mov_b32: low result = the half of source 0 that op_sel[0] names, high result = the half of
+                //  source 1 that op_sel[1] names), pair 0 the new value and its own even half -- every pair in place.
+                // (Put together in C, pair 0 came out in fresh registers every row, and selected value by value, as the
+                //  lanes without the slot need it, the pairs were taken apart and rebuilt: either way the compiler moved
+                //  every slot's whole history back to where the loop keeps it, sixty moves per PCM frame.  The lanes that
+                //  do not carry the slot are masked out of the same four instructions instead.)
+                if (NOSEL || in) {
+                    const uint64_t vpair = (uint64_t)(uint32_t)value;
                     asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][3]) : "v"(sp[k][2]));
                     asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][2]) : "v"(sp[k][1]));
                     asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][1]) : "v"(sp[k][0]));
-                    sp[k][0] = (sp[k][0] << 32) | (uint32_t)value;
-                } else {
-                    // history moves only for channels this lane really carries
-                    uint32_t h[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        h[j] = (uint32_t)st_get(k, j);
-#pragma unroll
-                    for (int j = 7; j > 0; j--)
-                        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(h[j]) : "v"(h[j - 1]), "s"(m_in));
-                    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(h[0]) : "v"((uint32_t)value), "s"(m_in));
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        sp[k][j] = ((uint64_t)h[2 * j + 1] << 32) | h[2 * j];
+                    asm("v_pk_mov_b32 %0, %1, %0 op_sel:[0,0]" : "+v"(sp[k][0]) : "v"(vpair));
                 }
                 if (__builtin_expect(wave_iir, 0)) {
                     if (iir_on)
@@ -1896,9 +1984,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     if (in)
                         xw_mine[k * xstride] = value;     // straight into the tile
                 } else {
-                    val[k] = UNI ? value : (in ? value : 0);
+                    val[k] = NOSEL ? value : (in ? value : 0);
                 }
-                win = win_next;
+                }       // (the lanes that carry the slot)
             }
             if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {
                 status |= ST_HUFFMAN;
@@ -1915,6 +2003,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         auto row_head_any = [&]() {
             if constexpr (FIX) {
                 row_head(std::integral_constant<int, NS>{});
+                return;
+            }
+            if constexpr (DVDA_SLOT_MODE == 1) {
+                row_head(std::integral_constant<int, -1>{});
                 return;
             }
             const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)nslots);

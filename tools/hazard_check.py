@@ -82,6 +82,41 @@ def check(path):
                 if not (b < lo or a > hi):
                     viol.append((k, ws, p, t))
             ws += 1
+    # (round 5) the row loop's window read placed as inline asm (ds_read2st64_b32 into the window's own register pair)
+    # and waited for by an asm s_waitcnt at the next slot's top: the compiler does not know that the pair's data is
+    # still on its way in between, so NOTHING there may read or write the pair -- a register copy at the join of the
+    # lanes that carry a slot and those that do not did once (wrong PCM on fuzz streams).  Followed in layout order
+    # up to the next asm wait (labels and branches are passed through: the code in between is straight fall-through
+    # plus the exec-mask bookkeeping of the `if`).
+    i = 0
+    while i < len(L):
+        t = L[i].strip()
+        if t.startswith('ds_read2st64_b32') and 'ASMSTART' in L[i - 1]:
+            m = re.search(r'v\[(\d+):(\d+)\]', t)
+            lo, hi = int(m.group(1)), int(m.group(2))
+            checked += 1
+            k, found = i + 1, False
+            while k < len(L) and k < i + 400:
+                p = L[k].strip()
+                k += 1
+                if not p or p.startswith(';') or (p.startswith('.') and not p.endswith(':')) or p.endswith(':'):
+                    continue
+                if p.startswith('s_waitcnt') and 'lgkmcnt(0)' in p:
+                    found = True
+                    break
+                if p.startswith('s_endpgm') or p.startswith('s_setpc'):
+                    break
+                regs = set()
+                for mm in re.finditer(r'\bv\[(\d+):(\d+)\]', p):
+                    regs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+                for mm in re.finditer(r'\bv(\d+)\b', p):
+                    regs.add(int(mm.group(1)))
+                if any(lo <= r <= hi for r in regs):
+                    viol.append((k, 0, p, t))
+                    break
+            if not found and not (viol and viol[-1][3] == t):
+                unknown += 1
+        i += 1
     return checked, unknown, viol
 
 

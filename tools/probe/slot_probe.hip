@@ -11,6 +11,9 @@ template <int HUFF, int FILT, int LDSR, int SHIFT>
 __global__ __launch_bounds__(128, 2) void k_slot(uint32_t *out, uint32_t rows, uint32_t seed, unsigned long long *cyc)
 {
     __shared__ uint32_t s_ring[2][RING_DWORDS + 1][64];
+    __shared__ uint16_t s_huff[4 * 512];      // HUFF == 2: the code books as a table, [book][9-bit peek] -> value | length << 8
+    for (int i = threadIdx.x; i < 4 * 512; i += 128)
+        s_huff[i] = (i >> 9) ? huff_entry(i >> 9, i & 511) : 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t x = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
     for (int i = 0; i < RING_DWORDS + 1; i++) {
@@ -52,7 +55,11 @@ __global__ __launch_bounds__(128, 2) void k_slot(uint32_t *out, uint32_t rows, u
             const uint32_t ofs = pos & 31u;
             const uint32_t top = (uint32_t)((win << ofs) >> 32);
             uint32_t msb, len;
-            if (HUFF) {
+            if (HUFF == 2) {
+                const uint32_t e = s_huff[(cb << 9) | (top >> 23)];
+                msb = e & 0xFFu;
+                len = e >> 8;
+            } else if (HUFF) {
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);
                 asm volatile("" : "+s"(m_esc));
                 const uint32_t e = huff_decode_m(cb, top >> 23, m_esc, bmask);
@@ -130,6 +137,7 @@ int main()
     hipMalloc(&cyc, 8);
     for (int blocks : {256, 512, 1024}) {       // 2, 4, 8 waves per CU
         run<1, 1, 1, 1>("full slot", out, cyc, blocks);
+        run<2, 1, 1, 1>("code books from an LDS table", out, cyc, blocks);
         run<1, 0, 1, 1>("no filter", out, cyc, blocks);
         run<0, 1, 1, 1>("no code book", out, cyc, blocks);
         run<1, 1, 0, 1>("no window read", out, cyc, blocks);
