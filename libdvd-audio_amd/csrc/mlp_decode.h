@@ -912,7 +912,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // (round 5) the one-lane fast pass keeps those two matrices one coefficient per register -- [0..5] the channels,
     // [6], [7] the noise -- and does not unpack sixteen halves per PCM frame (the instances that hand the matrices to
     // another lane or to a record keep the packed form: they have no registers to spare, or are not bound by this)
-    constexpr bool MU = DVDA_MAT_UNPACKED && !PAIRED && !GENERAL && !PARSE;
+    // (frame-major instance only: 3.54 -> 3.41 ms on the headline batch; the planar instance ran its two-channel batch
+    //  3.6 % slower with them, 2.40 -> 2.49 ms, at the same 256 registers -- measured, not understood)
+    constexpr bool MU = DVDA_MAT_UNPACKED && ILV && !PAIRED && !GENERAL && !PARSE;
     int32_t mu[2][MU ? 8 : 1];
 #pragma unroll
     for (int m = 0; m < 2; m++)
