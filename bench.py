@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the full-size check")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (other shapes of the path)")
+    ap.add_argument("--chain-flight", type=int, default=0,
+                    help="diagnostic: also time sub.chained_two_substreams with this many decode contexts in flight")
     ap.add_argument("--only-sub", default="", help="comma-separated sub-record names: run only those (profiling)")
     ap.add_argument("--verify", type=int, default=8, help="titles checked against the oracle when the full check is off")
     ap.add_argument("--substreams", type=int, default=1, choices=(1, 2),
@@ -453,11 +455,11 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     syn, hip = pkg.synth, pkg.hipdec
     out = {}
 
-    def in_flight(depth, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign, k_steps, name):
+    def in_flight(depth, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign, k_steps, name, replicas=1):
         """the same small batch with `depth` decode contexts in flight (own HIP stream and PCM buffer each, the
         non-blocking decode call): a batch the cooperative kernel decodes leaves most of the device idle, a feeder
         with more than one such batch to decode overlaps them.  Every slot's PCM must be the same."""
-        bp = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, 1, layout, 0, nseg, depth=depth,
+        bp = Batch(pkg, torch, dev, local_rank, flat, offs, sizes, frames, nchs, replicas, layout, 0, nseg, depth=depth,
                    chained=chained)
         dtp, _, _ = bp.timed(k_steps, 2 * depth)
         bp.check_status(benign=benign)
@@ -514,7 +516,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
         torch.cuda.empty_cache()
         if flight > 1:
             rec["in_flight"] = in_flight(flight, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign,
-                                         max(steps, 30), name)
+                                         max(steps, 30), name, replicas=replicas)
         sys.stderr.write("bench: sub-record %s %.1f s\n" % (name, time.perf_counter() - t_run))
 
     rate = 1
@@ -616,7 +618,7 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
                         features=syn.SF["CHAINED"])
     flat, offs, sizes, frames = syn.batch(cfgd, 1, args.streams)
     run("chained_two_substreams", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg + args.streams * args.replicas * 2,
-        args.replicas, args.layout, 0, benign=hip.ST_BENIGN,
+        args.replicas, args.layout, 0, benign=hip.ST_BENIGN, flight=args.chain_flight, chained=True,
         note="the bench batch as a disc would hold it: every segment continues the FIR history of the one before it, "
              "two substreams per title; decoded by the chain passes (parse in lane pairs, filter, rematrix)")
     # ---- the shape a disc really has: chained, two substreams, EVERY block carries parameters (most channels re-send

@@ -98,6 +98,19 @@ constexpr uint32_t YIELD_LONELY = 48;
 #endif
 // the slot loop: 1 = one version, slots under the execution mask of the lanes that carry them; 0 = three versions
 // (all lanes NS slots / all lanes two / lanes that disagree: selects), picked per row
+// cache policy of the row loop's prefetch loads: 0 default, 1 nontemporal (nt)
+#ifndef DVDA_PF_POLICY
+#define DVDA_PF_POLICY 0
+#endif
+// 1: the wave prefetches together -- the lanes that need a chunk publish (chunk, lane) in LDS, and every four lanes
+// fetch one request's 64 bytes as four adjacent 16-byte pieces (one load instruction serves 16 chunks, each a whole
+// 64-byte segment, instead of four instructions that each touch 64 different lines)
+#ifndef DVDA_COOP_PF
+#define DVDA_COOP_PF 0
+#endif
+#ifndef DVDA_COOP_PF_GROUPS
+#define DVDA_COOP_PF_GROUPS 3
+#endif
 #ifndef DVDA_MAT_UNPACKED
 #define DVDA_MAT_UNPACKED 1
 #endif
@@ -662,6 +675,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     //  the staging column of the lane that flushes it -- 4 KB less, four workgroups per CU instead of three)
     constexpr bool XCH = SIDE && !PARSE;
     __shared__ int32_t s_xch[XCH ? WAVES : 1][MAXCH][XCH ? 64 : 1];
+#if DVDA_COOP_PF
+    __shared__ uint2 s_req[WAVES][64];              // cooperative prefetch: (chunk's dword index, lane | ring half << 6)
+#endif
     __shared__ uint32_t s_alive[2][WAVES];
     __shared__ uint32_t s_nchained[WAVES];          // fast pass: lanes of the wave that stopped on ST_CHAINED (or, two-wave
                                                     // layout, whose other substream's lane did)
@@ -1776,21 +1792,71 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // changes (a loop in the cold branch, one more CRC table) and went right again, each time, as soon as
         // these registers were defined.  The empty asm defines them -- some value, no instruction, nothing to
         // wait for -- which is all the code ever needed.
+#if !DVDA_COOP_PF
         uint4 p0, p1, p2, p3;
         asm volatile("" : "=v"(p0.x), "=v"(p0.y), "=v"(p0.z), "=v"(p0.w), "=v"(p1.x), "=v"(p1.y), "=v"(p1.z), "=v"(p1.w),
                           "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
+#endif
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
         const uint32_t frames_before = frames_done;      // (sequential pass: did this turn close an access unit?)
         uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
         uint64_t flush_row = 0;
+#if DVDA_COOP_PF
+        constexpr int PFG = DVDA_COOP_PF_GROUPS;
+        const uint64_t pf_mask = __ballot(pf);
+        const uint32_t pf_n = (uint32_t)__popcll(pf_mask);                    // (scalar)
+        const uint32_t pf_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pf_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pf_mask, 0u));
+        const bool pf_served = pf && pf_rank < 16u * PFG;                     // (the others ask again next row)
+        uint4 pq[PFG];
+        uint32_t pq_tag[PFG];
+        for (int g = 0; g < PFG; g++)
+            asm volatile("" : "=v"(pq[g].x), "=v"(pq[g].y), "=v"(pq[g].z), "=v"(pq[g].w), "=v"(pq_tag[g]));
+        if (pf_n) {
+            uint2 *const req = &s_req[wv][0];
+            if (pf_served) {
+                const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
+                req[pf_rank] = make_uint2(c, lane | ((rd.fillpos & (uint32_t)CHUNK_DWORDS) << 2));
+            }
+#pragma unroll
+            for (int g = 0; g < PFG; g++) {
+                if ((uint32_t)(16 * g) < pf_n) {                               // (scalar)
+                    const uint32_t r = (uint32_t)(16 * g) + (lane >> 2);
+                    if (r < pf_n) {
+                        const uint2 q = req[r];
+                        pq[g] = rd.gsrc[(q.x >> 2) + (lane & 3u)];
+                        pq_tag[g] = q.y;
+                    }
+                }
+            }
+        }
+#else
         if (pf) {
             const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
             const uint4 *src = rd.gsrc + (c >> 2);
+#if DVDA_PF_POLICY == 1
+            // (the stream's bytes pass once: nothing of them is asked for again through this CU's L1)
+            {
+                typedef unsigned dvda_v4u __attribute__((ext_vector_type(4)));
+                const dvda_v4u *nsrc = reinterpret_cast<const dvda_v4u *>(src);
+                const dvda_v4u n0v = __builtin_nontemporal_load(&nsrc[0]), n1v = __builtin_nontemporal_load(&nsrc[1]),
+                               n2v = __builtin_nontemporal_load(&nsrc[2]), n3v = __builtin_nontemporal_load(&nsrc[3]);
+                p0 = make_uint4(n0v.x, n0v.y, n0v.z, n0v.w);
+                p1 = make_uint4(n1v.x, n1v.y, n1v.z, n1v.w);
+                p2 = make_uint4(n2v.x, n2v.y, n2v.z, n2v.w);
+                p3 = make_uint4(n3v.x, n3v.y, n3v.z, n3v.w);
+            }
+#elif DVDA_PF_POLICY == 2
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
+                         : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(src) : "memory");
+#else
             p0 = src[0];
             p1 = src[1];
             p2 = src[2];
             p3 = src[3];
+#endif
         }
+#endif
         DVDA_STAMP(1);
 
         uint32_t bypass_bits = 0;
@@ -2310,10 +2376,36 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //  but for the PCM stores issued a few instructions earlier, a store's whole round trip every flush: 12 % of
         //  a wave's time, tools/stamp_run.py.  vmcnt(0), lgkmcnt / expcnt not waited for: 0x0F70)
         __builtin_amdgcn_s_waitcnt(0x0F70);
+#if DVDA_COOP_PF
+        if (pf_n) {
+            uint32_t *const ring_wave = rd.ring - lane;
+#pragma unroll
+            for (int g = 0; g < PFG; g++) {
+                if ((uint32_t)(16 * g) < pf_n) {
+                    const uint32_t r = (uint32_t)(16 * g) + (lane >> 2);
+                    if (r < pf_n) {
+                        // piece j of the chunk: ring dwords half * 16 + 4 j .. + 3, planes falling from 32 - that
+                        const uint32_t d0 = ((pq_tag[g] >> 2) & 16u) + ((lane & 3u) << 2);
+                        uint32_t *const dst = ring_wave + (pq_tag[g] & 63u) + ((uint32_t)RING_DWORDS - d0) * 64u;
+                        const uint32_t a0 = be32(pq[g].x);
+                        dst[0] = a0;
+                        dst[-64] = be32(pq[g].y);
+                        dst[-128] = be32(pq[g].z);
+                        dst[-192] = be32(pq[g].w);
+                        if (d0 == 0)
+                            dst[-RING_DWORDS * 64] = a0;
+                    }
+                }
+            }
+            if (pf_served)
+                rd.filled();
+        }
+#else
         if (pf) {
             ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3, (rd.fillpos & (RING_DWORDS - 1)) == 0);
             rd.filled();
         }
+#endif
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
         //      older memory operation, so stores issued before it would be waited for as well; issued
         //      here they have a whole row to drain before the next wait

@@ -92,7 +92,14 @@ for sub in subs:
                          "fetch_bytes": int(fb) if fb is not None else None, "write_bytes": int(wb) if wb is not None else None}
     if rec:
         # bytes of the sub-record's own step: every kernel of ITS dispatches, weighted by how often a step launches it
-        own = [k for k in per_kernel if any(t in k for t in ("k_chain", "false, true>", "k_coop<true>"))]
+        # (the chain passes: k_chain_*, the cooperative parse k_coop<true..>, and the PARSE instance of k_decode --
+        #  its fifth template argument; round 5 added a sixth and the match by the name's tail missed the parse pass)
+        def parse_instance(k):
+            if not k.startswith("k_decode<"):
+                return False
+            targs = [t.strip() for t in k[len("k_decode<"):].rstrip(">").split(",")]
+            return len(targs) >= 5 and targs[4] == "true"
+        own = [k for k in per_kernel if "k_chain" in k or k.startswith("k_coop<true") or parse_instance(k)]
         tb = sum((per_kernel[k]["fetch_bytes"] or 0) + (per_kernel[k]["write_bytes"] or 0) for k in own)
         res[sub] = {"samples_per_step": rec["samples_per_step"], "compressed_bytes": rec["compressed_bytes"],
                     "hbm_bytes_per_step": int(tb), "kernels_counted": own, "per_kernel": per_kernel,
