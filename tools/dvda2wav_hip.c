@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "dvd-audio-hip.h"
 
@@ -47,8 +49,18 @@ static void wave_header(uint8_t h[68], unsigned rate, unsigned channels, unsigne
     put32(h + 64, data);
 }
 
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
 static int extract(DVDA_Title *title, unsigned track_num, const char *dir, int device, int fused_wav)
 {
+    const int timing = getenv("DVDA_TOOL_TIMING") != NULL;       /* diagnostic: where a track's wall-clock time goes */
+    const double t_begin = now_s();
+    double t_write = 0;
     DVDA_Track *track = dvda_open_track(title, track_num);
     if (!track) {
         fprintf(stderr, "*** Error: unable to open track %u\n", track_num);
@@ -61,6 +73,7 @@ static int extract(DVDA_Title *title, unsigned track_num, const char *dir, int d
         dvda_close_track(track);
         return 0;
     }
+    const double t_opened = now_s();
     char path[4096];
     const size_t n = strlen(dir);
     snprintf(path, sizeof(path), "%s%strack-%2.2u-%2.2u.wav", dir, n && dir[n - 1] == '/' ? "" : "/",
@@ -85,9 +98,12 @@ static int extract(DVDA_Title *title, unsigned track_num, const char *dir, int d
     unsigned long long bytes = 0, piece;
     const unsigned char *payload = NULL;
     while (ok && (piece = dvda_hip_reader_wav_next(r, &payload)) != 0) {
+        const double tw = now_s();
         ok = fwrite(payload, 1, piece, f) == piece;
+        t_write += now_s() - tw;
         bytes += piece;
     }
+    const double t_pieces = now_s();
     const unsigned long long frames = dvda_hip_reader_total_frames(r);
     if (dvda_hip_reader_windowed(r)) {
         /* a track read in windows: what it held at most (tools/disc_bench.py reads this line) */
@@ -107,6 +123,10 @@ static int extract(DVDA_Title *title, unsigned track_num, const char *dir, int d
     else
         fprintf(stderr, "*** Error: writing \"%s\"\n", path);
     dvda_close_track_reader(r);
+    if (timing)
+        fprintf(stderr, "timing: track %u  open %.1f ms  pieces %.1f ms (of which fwrite %.1f)  finish %.1f ms  at %.1f ms\n", track_num,
+                (t_opened - t_begin) * 1e3, (t_pieces - t_opened) * 1e3, t_write * 1e3, (now_s() - t_pieces) * 1e3,
+                now_s() * 1e3);
     return ok;
 }
 
@@ -172,6 +192,8 @@ int main(int argc, char *argv[])
     unsigned titleset_num = 1, title_num = 0, track_num = 0;
     int devices[64], n_devices = 0, one_device = 0;
     int c;
+    if (getenv("DVDA_TOOL_TIMING"))
+        fprintf(stderr, "timing: main at %.1f ms\n", now_s() * 1e3);
     while ((c = getopt_long(argc, argv, "A:c:S:T:t:d:g:D:h", longopts, NULL)) != -1) {
         switch (c) {
         case 'A': audio_ts = optarg; break;
@@ -255,6 +277,13 @@ int main(int argc, char *argv[])
         fprintf(stderr, "*** Error: %u of %u tracks could not be extracted\n", atomic_load(&pool.failed), n_jobs);
         rc = 1;
     }
+    /* every file is written and closed.  What is left -- the titles' tables, and the HIP runtime's own teardown at exit
+       (some 60-80 ms, measured: tools/probe/r05_disc_time.sh) -- is the operating system's to reclaim: a command-line
+       tool that is done leaves */
+    fflush(stdout);
+    fflush(stderr);
+    if (!getenv("DVDA_TOOL_FULL_TEARDOWN"))
+        _exit(rc);
     for (unsigned i = 0; i < n_titles; i++)
         dvda_close_title(titles[i]);
     free(jobs);
