@@ -212,6 +212,9 @@ class Batch:
         self.samples = int((self.all_frames * self.all_nch).sum())
         # (offsets in int32 units; a packed WAV payload takes 3/4 of them, every stream starts on 16 bytes)
         words = (self.all_frames * self.all_nch * self.out_bytes + 15) // 16 * 4
+        # (diagnostic, DVDA_BENCH_OUT_PAD=bytes: this many bytes between one title's PCM and the next -- where the titles'
+        #  regions start is the caller's choice, d_out_off)
+        words = words + (int(os.environ.get("DVDA_BENCH_OUT_PAD", "0")) // 16) * 4
         self.out_off = np.zeros(self.n_streams, np.int64)
         self.out_off[1:] = np.cumsum(words[:-1])
         self.pcm_words = int(words.sum())

@@ -179,16 +179,20 @@ constexpr uint32_t HDR_GATE_TURNS = DVDA_HDR_GATE_TURNS, HDR_GATE_LANES = DVDA_H
 // store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
 // which doubles the store instructions and splits every half-sector write in two.
 typedef int dvda_v4i __attribute__((ext_vector_type(4)));
+// cache policy of the PCM stores (a string behind the instruction: "" default, " nt", " sc1", " sc0 sc1" ...)
+#ifndef DVDA_STORE_POLICY
+#define DVDA_STORE_POLICY ""
+#endif
 #define DVDA_STORE_V4(dst, a_, b_, c_, d_)                                                          \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v4_) : "memory");           \
+        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_POLICY ::"v"(dst), "v"(v4_) : "memory");           \
     } while (0)
 // ... followed by the two wait states a store of more than 64 bits needs before its data registers may be written
 #define DVDA_STORE_V4_PAD(dst, a_, b_, c_, d_)                                                      \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
+        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
     } while (0)
 // the same at a constant byte offset from one base address
 #if defined(DVDA_EXP_NOSTORE)      // (diagnostic: what the PCM stores cost -- the data is computed and read from the tile, not written)
@@ -201,7 +205,7 @@ typedef int dvda_v4i __attribute__((ext_vector_type(4)));
 #define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off offset:%2"                                   \
+        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" DVDA_STORE_POLICY                 \
                      ::"v"(dst), "v"(v4_), "n"(off_) : "memory");                                   \
     } while (0)
 #endif
