@@ -709,14 +709,22 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // two-substream ones -- so the even waves never rematrix, stage or store PCM
     const uint32_t ws_grp = (uint32_t)wv >> 1;
     const uint32_t ws_last = (uint32_t)wv & 1u;
-    const uint32_t gl0 = blockIdx.x * THREADS + threadIdx.x;
+    // (diagnostic, DVDA_EXP_WG_ORDER = k: workgroup p of the grid takes the lanes of workgroup (p mod k) * (G / k) + p / k --
+    //  k consecutive workgroups are one from each k-th of the lane order, which is by segment length)
+#if defined(DVDA_EXP_WG_ORDER)
+    const uint32_t wg_k = (!GENERAL && !PARSE && gridDim.x % DVDA_EXP_WG_ORDER == 0u) ? (uint32_t)DVDA_EXP_WG_ORDER : 1u;
+    const uint32_t wg_id = (blockIdx.x % wg_k) * (gridDim.x / wg_k) + blockIdx.x / wg_k;
+#else
+    const uint32_t wg_id = blockIdx.x;
+#endif
+    const uint32_t gl0 = wg_id * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
         n_seg = a.max_seg;
     // which segment: the fast pass covers the index in order; the sequential pass starts lane pair j at the
     // first segment of stream list[list_base + j]; the chain parse pass gives deferred segment
     // list[list_base + j] to lane (pair) j
-    const uint32_t item = WSPEC ? (blockIdx.x * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
+    const uint32_t item = WSPEC ? (wg_id * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
     uint32_t segi = item;
     bool active = segi < n_seg;
     if (!GENERAL && !PARSE && active && *a.hetero)

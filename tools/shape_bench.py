@@ -39,6 +39,15 @@ for w in which:
                                restart_interval=ri), 512) for a, rc, ri in shapes]
         flat, offs, sizes, frames, nchs, nseg = gen_mixed(syn, specs, 90000)
         run(w, flat, offs, sizes, frames, nchs, nseg * 4, 4)
+    elif w.startswith("fuzzone_"):
+        # fuzzone_K_R: only shape K of the fuzz batch's eight, 512 titles x R replicas (how long ONE segment shape takes
+        # with the chip to itself: 512 titles of shape 2 are 32 waves)
+        _, k, r = w.split("_")
+        a, rc, ri = shapes[int(k)]
+        feats = syn.SF_FAST & ~(SF["IIR"] | SF["MATRIXRAND"])
+        cfg = syn.make_cfg(assignment=a, rate_code=rc, n_substreams=1, n_aus=64, profile=1, features=feats, restart_interval=ri)
+        flat, offs, sizes, frames, nchs, nseg = gen_mixed(syn, [(cfg, 512)], 90000)
+        run(w, flat, offs, sizes, frames, nchs, nseg * int(r), int(r))
     elif w == "chained":
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=128, profile=1, features=SF["CHAINED"])
         flat, offs, sizes, frames = syn.batch(cfg, 1, 1024)
