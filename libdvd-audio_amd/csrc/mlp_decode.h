@@ -75,9 +75,14 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_CF_UNPACKED
 #define DVDA_CF_UNPACKED 1
 #endif
-// experiments of round 5 (tools/ab_build.py): the wave stores its PCM together / fills its rings together
+// Round 5: the wave stores its PCM together (frame-major int32, all 64 lanes flushing in the same turn: what lane
+// packing makes of a batch): ten whole 96-byte runs side by side per store instruction, written through (sc1).
+// Counter traffic of the bench batch 8.73 -> 6.38 GB per launch (reads 1.75 -> 1.07 x the input: the output's dirty
+// lines no longer push the input's out of L2; writes 1.27 -> 1.04 x), k_decode 3.41 -> 3.35 ms at two waves per SIMD;
+// at one wave per SIMD the extra instructions cost 7 %, so a batch of fewer than DecodeArgs::coop_min_seg segments
+// keeps the per-lane flush.  0: never.
 #ifndef DVDA_COOP_OUT
-#define DVDA_COOP_OUT 0
+#define DVDA_COOP_OUT 1
 #endif
 // the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
 // the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
@@ -187,6 +192,16 @@ typedef int dvda_v4i __attribute__((ext_vector_type(4)));
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
         asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_POLICY ::"v"(dst), "v"(v4_) : "memory");           \
+    } while (0)
+// the wave's cooperative flush (whole runs side by side in one instruction): its own cache policy -- written through,
+// the runs leave as whole 32- and 64-byte pieces and do not push the input's lines out of L2 (round 5, DESIGN A.5)
+#ifndef DVDA_COOP_STORE_POLICY
+#define DVDA_COOP_STORE_POLICY " sc1"
+#endif
+#define DVDA_STORE_V4_COOP(dst, a_, b_, c_, d_)                                                     \
+    do {                                                                                            \
+        dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
+        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_COOP_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
     } while (0)
 // ... followed by the two wait states a store of more than 64 bits needs before its data registers may be written
 #define DVDA_STORE_V4_PAD(dst, a_, b_, c_, d_)                                                      \
@@ -340,6 +355,8 @@ struct DecodeArgs {
     DecodeSummary *summary;        // what the fast pass leaves to the passes behind it (read by the host)
     uint32_t interleaved;          // PCM layout: 0 planar, 1 frame-major (see k_decode)
     uint32_t wav_bits;             // 0: int32 values; 16 / 24: frame-major packed little-endian WAV payload (write_signed)
+    uint32_t coop_min_seg;         // the wave flushes its PCM together when the batch has at least this many segments
+                                   // (more than one wave per SIMD: the flush costs instructions and saves traffic); 0: never
     const uint32_t *hetero;        // != 0: the batch mixes stream shapes and lane_seg[] deals the segments to the
     const uint32_t *lane_seg;      //       fast pass's lanes by shape (k_stream_rank / k_lane_perm, mlp_index.h)
     const uint32_t *cls;           // [2]: the batch holds streams with one / two substreams (set by the index)
@@ -2431,22 +2448,35 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //      or eleven runs whole.
         bool coop_out = false;
         if constexpr (ILV && !GENERAL && !PARSE) {
-            if (DVDA_COOP_OUT && ilv_direct && a.wav_bits == 0u)
+            if (DVDA_COOP_OUT && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
                 coop_out = __ballot(flush) == ~0ull;
         }
         if (coop_out) {
-            const int32_t *const dsrc = a.pcm + out_base + flush_row * 6u;
-            const uint32_t d_lo = (uint32_t)(uintptr_t)dsrc, d_hi = (uint32_t)((uintptr_t)dsrc >> 32);
+            // where the lane's own run starts, in int32 elements from a.pcm (one 32-bit word to hand round when the
+            // whole wave's fit: a PCM buffer of less than 16 GB; wave-uniform fall-back to two words otherwise)
+            const uint64_t doff = out_base + flush_row * 6u;
+            const bool off32 = !__any((doff >> 32) != 0);
+            const uint32_t d_lo = (uint32_t)doff, d_hi = (uint32_t)(doff >> 32);
             const int32_t *const T0 = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][0];
+            // lane l stores piece l mod 6 of the run of lane 10 i + l / 6 in the i-th of seven instructions (lanes 60..63
+            // rest): ten whole runs side by side per instruction, and the lane's part of the addresses -- l / 6, l mod 6 --
+            // is the same in every one of them
+            const uint32_t l6 = ((uint32_t)lane * 43691u) >> 18;             // lane / 6
+            const uint32_t pc = (uint32_t)lane - l6 * 6u;
+            const int32_t *const Tl6 = T0 + pc * (4 * 64) + l6;             // (the tile in output order: value v of a run in plane v)
+            const bool l60 = lane < 60;
 #pragma unroll
-            for (uint32_t it6 = 0; it6 < 6u; it6++) {
-                const uint32_t q = it6 * 64u + (uint32_t)lane;
-                const uint32_t o = (q * 43691u) >> 18;               // q / 6 for q < 384
-                const uint32_t pc = q - o * 6u;
-                const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64), b_hi = (uint32_t)__shfl((int)d_hi, (int)o, 64);
-                int32_t *const od = reinterpret_cast<int32_t *>(((uint64_t)b_hi << 32) | b_lo) + pc * 4u;
-                const int32_t *const Tp = T0 + pc * (4 * 64) + o;    // (the tile in output order: value v of a run in plane v)
-                DVDA_STORE_V4_PAD(od, Tp[0], Tp[64], Tp[128], Tp[192]);
+            for (uint32_t it7 = 0; it7 < 7u; it7++) {
+                const uint32_t o = l6 + 10u * it7;                           // whose run
+                const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64);
+                uint64_t eo = b_lo;
+                if (!off32)
+                    eo |= (uint64_t)(uint32_t)__shfl((int)d_hi, (int)o, 64) << 32;
+                if (l60 && (it7 < 6u || o < 64u)) {
+                    int32_t *const od = a.pcm + eo + pc * 4u;
+                    const int32_t *const Tp = Tl6 + 10u * it7;
+                    DVDA_STORE_V4_COOP(od, Tp[0], Tp[64], Tp[128], Tp[192]);
+                }
             }
         }
         if (!GENERAL && !PARSE && ILV && flush && !coop_out) {

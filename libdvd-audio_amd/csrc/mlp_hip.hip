@@ -58,6 +58,7 @@ static hipError_t ws_malloc(void **p, size_t bytes)
 
 struct dvda_mlp_hip_ctx {
     int device;
+    uint32_t coop_min_seg;     // DecodeArgs::coop_min_seg: 1.75 waves per SIMD of this device (measured: slower at 1.5, 4.5 % faster at 2) (DVDA_COOP_MIN_SEG overrides: diagnostic)
     uint32_t max_streams, max_segments;
     // index workspace
     uint8_t *d_masks;
@@ -237,6 +238,14 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     if (!c)
         return DVDA_HIP_ENOMEM;
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
+            cus = 256;
+        c->coop_min_seg = (uint32_t)cus * 4u * 64u * 7u / 4u;
+        if (const char *e = getenv("DVDA_COOP_MIN_SEG"))
+            c->coop_min_seg = (uint32_t)strtoul(e, nullptr, 10);
+    }
     c->max_streams = max_streams;
     c->max_segments = max_segments;
     c->masks_cap = 0;
@@ -771,6 +780,7 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     a.summary = c->d_summary;
     a.interleaved = c->pcm_layout != DVDA_PCM_PLANAR;
     a.wav_bits = c->pcm_layout == DVDA_PCM_WAV24 ? 24u : c->pcm_layout == DVDA_PCM_WAV16 ? 16u : 0u;
+    a.coop_min_seg = c->coop_min_seg;
     a.cls = c->d_cls;
     a.hetero = c->d_cls + 2;
     a.lane_seg = c->d_lane_seg;

@@ -545,6 +545,29 @@ def test_output_buffer_not_16_byte_aligned(pkg, oracle, assignment, lanes, layou
             ctx.close()
 
 
+@pytest.mark.parametrize("mix", ["alike", "ragged", "mixed_shapes"])
+def test_wave_flushes_its_pcm_together(pkg, oracle, monkeypatch, mix):
+    """Frame-major int32 output, every lane of a wave flushing in the same turn: the wave stores each other's 96-byte
+    runs (csrc/mlp_decode.h, DVDA_COOP_OUT) -- only in batches of more than a wave and a half per SIMD, which no other
+    test reaches: forced here for every batch (DVDA_COOP_MIN_SEG=1, read when a context is made).  Titles alike (whole
+    waves in lockstep, a part-filled last wave), of different lengths (lanes fall out of a wave one by one) and of
+    different shapes (waves whose lanes do not flush together take the per-lane flush)."""
+    monkeypatch.setenv("DVDA_COOP_MIN_SEG", "1")
+    syn = pkg.synth
+    cases = []
+    for i in range(44):
+        if mix == "alike":
+            cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=24, restart_interval=8)
+        elif mix == "ragged":
+            cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=9 + (i * 7) % 23, restart_interval=4)
+        else:
+            asg, rc = [(12, 1), (1, 1), (12, 2), (6, 0)][i % 4]
+            cfg = syn.make_cfg(assignment=asg, rate_code=rc, n_substreams=1, n_aus=16, profile=1, features=syn.SF_FAST & ~(
+                syn.SF["IIR"] | syn.SF["MATRIXRAND"]), restart_interval=4)
+        cases.append((cfg, 900 + i))
+    _check(pkg, oracle, cases, lanes=1)
+
+
 def test_pcm_layout_argument_is_checked(pkg):
     """dvda_mlp_hip_set_pcm_layout: the two layouts are accepted, anything else is DVDA_HIP_EINVAL (-3)
     and leaves the context as it was."""
