@@ -84,6 +84,12 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_COOP_OUT
 #define DVDA_COOP_OUT 1
 #endif
+// (its seven store instructions unrolled: 3.32 ms against 3.33 with two copies and 3.44 as a loop, one box; the unrolled
+//  form makes the compiler spill 47 registers of cold state in this instance -- 23 as a loop -- and the packed-WAV flush,
+//  which shares the instance, runs 3 % slower with any of them: 3.51 -> 3.62 ms)
+#ifndef DVDA_COOP_UNROLL
+#define DVDA_COOP_UNROLL 7
+#endif
 // the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
 // the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
 // the one LDS round trip per row they hide)
@@ -2447,7 +2453,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //      q mod 6 of lane q / 6's run, q = 64 i + l in the i-th of six instructions: an instruction covers ten
         //      or eleven runs whole.
         bool coop_out = false;
-        if constexpr (ILV && !GENERAL && !PARSE) {
+        // (not in the two-wave kernel: there the wave that flushes is the one that sets the pace, and the flush's extra
+        //  instructions cost it 7 %)
+        if constexpr (ILV && !GENERAL && !PARSE && !WSPEC) {
             if (DVDA_COOP_OUT && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
                 coop_out = __ballot(flush) == ~0ull;
         }
@@ -2465,7 +2473,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             const uint32_t pc = (uint32_t)lane - l6 * 6u;
             const int32_t *const Tl6 = T0 + pc * (4 * 64) + l6;             // (the tile in output order: value v of a run in plane v)
             const bool l60 = lane < 60;
-#pragma unroll
+#pragma unroll DVDA_COOP_UNROLL
             for (uint32_t it7 = 0; it7 < 7u; it7++) {
                 const uint32_t o = l6 + 10u * it7;                           // whose run
                 const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64);

@@ -5,6 +5,7 @@
 TAG=${1:-x}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
+rm -rf "$OUT"          # (a summary over an earlier run's files too would average two builds)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu --no-sub --verify 0 $*"
