@@ -568,6 +568,50 @@ def test_wave_flushes_its_pcm_together(pkg, oracle, monkeypatch, mix):
     _check(pkg, oracle, cases, lanes=1)
 
 
+def test_wave_flush_into_a_pcm_buffer_of_more_than_16_gb(pkg, oracle, monkeypatch):
+    """The cooperative flush hands a lane's output position round as ONE 32-bit element offset while every lane's fits,
+    as two words otherwise (wave-uniform): titles placed either side of element 2^32 of one PCM buffer."""
+    import torch
+    monkeypatch.setenv("DVDA_COOP_MIN_SEG", "1")
+    syn, hip = pkg.synth, pkg.hipdec
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 24 << 30:
+        pytest.skip("needs a 17 GB PCM buffer")
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=16, restart_interval=8)
+    n = 40                                          # 80 segments: one whole wave and a part-filled one
+    streams, frames = [], []
+    for i in range(n):
+        b, f = syn.stream(cfg, 7000 + i)
+        streams.append(b)
+        frames.append(f)
+    flat, offs, lens = hip.pack_streams(streams)
+    d_bytes = torch.from_numpy(flat).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int64)).to(dev)
+    stride = max(frames)
+    # titles 0..19 end just below element 2^32, titles 20..39 start just above it: both kinds of wave, and one that mixes them
+    base = (1 << 32) - 20 * stride * 6
+    out_off = np.array([base + i * stride * 6 + (64 if i >= 20 else 0) for i in range(n)], np.int64)
+    d_pcm = torch.empty(int(out_off[-1]) + stride * 6 + 64, dtype=torch.int32, device=dev)
+    ctx = hip.Context(0, n, 4096, 1, hip.PCM_INTERLEAVED)
+    try:
+        ctx.index(d_bytes.data_ptr(), len(flat) - 64, d_off.data_ptr(), d_len.data_ptr(), n, 0)
+        d_oo = torch.from_numpy(out_off).to(dev)
+        d_st = torch.full((n,), stride, dtype=torch.int64, device=dev)
+        ctx.decode(d_pcm.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), 0)
+        infos = ctx.stream_info()
+        for i in range(n):
+            want, r, st = oracle.decode(streams[i], 6, frames[i])
+            assert st == 0 and infos[i].status & ~hip.ST_BENIGN == 0 and infos[i].pcm_frames == frames[i]
+            got = d_pcm[int(out_off[i]):int(out_off[i]) + frames[i] * 6].cpu().numpy().reshape(frames[i], 6).T
+            assert np.array_equal(got, want), "title %d" % i
+    finally:
+        ctx.close()
+        del d_pcm
+        torch.cuda.empty_cache()
+
+
 def test_pcm_layout_argument_is_checked(pkg):
     """dvda_mlp_hip_set_pcm_layout: the two layouts are accepted, anything else is DVDA_HIP_EINVAL (-3)
     and leaves the context as it was."""
