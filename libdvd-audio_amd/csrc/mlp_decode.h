@@ -87,6 +87,10 @@ constexpr uint32_t YIELD_LONELY = 48;
 // (its seven store instructions unrolled: 3.32 ms against 3.33 with two copies and 3.44 as a loop, one box; the unrolled
 //  form makes the compiler spill 47 registers of cold state in this instance -- 23 as a loop -- and the packed-WAV flush,
 //  which shares the instance, runs 3 % slower with any of them: 3.51 -> 3.62 ms)
+// 1: the packed WAV payload has the frame-major instance k_decode<.., WAVO> to itself (the host launches it for those layouts)
+#ifndef DVDA_WAV_INSTANCE
+#define DVDA_WAV_INSTANCE 1
+#endif
 #ifndef DVDA_COOP_UNROLL
 #define DVDA_COOP_UNROLL 7
 #endif
@@ -660,7 +664,9 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 // register copies the compiler puts where those versions meet.  A lane that finds another count in a restart header
 // hands its segment to the chain passes (ST_COLD), as a lane of the two-wave kernel with too many channels does.  The
 // host launches both instances; the lanes of the one that is not meant leave at once.
-template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false, bool FIX = false>
+// WAVO (round 5): the frame-major instance for the packed WAV payload only (DVDA_PCM_WAV24 / WAV16) -- without the int32
+// flushes, the cooperative one among them, whose registers cost the payload's flush 3 % when they shared an instance.
+template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false, bool FIX = false, bool WAVO = false>
 __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     static_assert(!(GENERAL && PARSE), "one mode at a time");
@@ -2456,7 +2462,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // (not in the two-wave kernel: there the wave that flushes is the one that sets the pace, and the flush's extra
         //  instructions cost it 7 %)
         if constexpr (ILV && !GENERAL && !PARSE && !WSPEC) {
-            if (DVDA_COOP_OUT && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
+            if (DVDA_COOP_OUT && !WAVO && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
                 coop_out = __ballot(flush) == ~0ull;
         }
         if (coop_out) {
@@ -2491,7 +2497,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
             const int32_t *Tl = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
-            if (__builtin_expect(a.wav_bits != 0, 0)) {
+            // (the one-lane int32 frame-major instance has handed the payload to its WAVO twin; every other instance
+            //  -- two-wave, sequential -- still writes it itself)
+            constexpr bool WAV_ELSEWHERE = DVDA_WAV_INSTANCE && !PAIRED && !FIX && !WAVO;
+            if (WAVO || (!WAV_ELSEWHERE && __builtin_expect(a.wav_bits != 0, 0))) {
                 // ---- the WAV payload itself (SURVEY 8(f-3) fused into the decode): the OUT_ROWS frames are
                 //      OUT_ROWS * channels consecutive samples = `channels` groups of four; a group packs into
                 //      three dwords (24-bit) or two (16-bit); the lane's run is 12 (8) * channels contiguous bytes

@@ -820,7 +820,9 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     }
     if (run1) {
         a.only_S = force ? 0u : 1u;
-        if (a.interleaved)
+        if (a.interleaved && a.wav_bits && DVDA_WAV_INSTANCE)
+            hipLaunchKernelGGL((k_decode<6, false, false, true, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
+        else if (a.interleaved)
             hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
         else
             hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
