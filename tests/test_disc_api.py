@@ -205,6 +205,52 @@ def test_long_tracks_are_read_in_windows_of_bounded_memory(pkg, oracle, kind):
             os.environ["DVDA_WINDOW_SECTORS"] = old
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("damage", ["flipped_byte", "file_cut_short"])
+def test_windowed_reader_stops_at_a_damaged_window_and_says_so(pkg, oracle, damage):
+    """A long track whose bytes are damaged half way (a flipped payload byte: the substream's parity / CRC-8 or its
+    syntax fails; the AOB file shorter than the IFO says: the sectors end inside the track): the windows in front of the
+    damage are handed out and equal the oracle's PCM, the reader then ends, reports the failure
+    (dvda_hip_reader_failed) and never hangs -- producer thread and caller both come back.  The reference assert()s
+    on the first (src/mlp.c:700-708) and returns short reads on the second (src/dvd-audio.c:1151-1166)."""
+    syn, disc = pkg.synth, pkg.disc
+    old = os.environ.get("DVDA_WINDOW_SECTORS")
+    os.environ["DVDA_WINDOW_SECTORS"] = "128"
+    try:
+        b, f = syn.stream(syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=2400), 91)
+        want, r, st = oracle.decode(b, 6, f)
+        assert st == 0
+        secs = disc.mlp_track_sectors(b)
+        with tempfile.TemporaryDirectory() as tmp:
+            ats = disc.write_disc_titles(tmp, [disc.split_tracks(secs, [], [f], 1)])
+            aob = os.path.join(ats, "ATS_01_1.AOB")
+            size = os.path.getsize(aob)
+            mid = (size // 2048 // 2) * 2048
+            if damage == "flipped_byte":
+                with open(aob, "r+b") as fh:
+                    fh.seek(mid + 1200)                  # well inside a sector's MLP payload
+                    v = fh.read(1)
+                    fh.seek(mid + 1200)
+                    fh.write(bytes([v[0] ^ 0x5A]))
+            else:
+                with open(aob, "r+b") as fh:
+                    fh.truncate(mid)
+            a = pkg.discdec.read_track(ats, 1, 1, 1, chunk=4096)
+            assert a["windowed"] and a["failed"]
+            n = len(a["pcm"])
+            assert 0 < n < f and a["frames"] == n
+            assert np.array_equal(a["pcm"].T, want[:, :n])
+            # ... and the payload interface ends the same way
+            w = pkg.discdec.read_track(ats, 1, 1, 1, wav=True, fused=True, pieces=True)
+            assert w["failed"] and w["payload"] == oracle.wav_pack(want[:, :n], 24)
+    finally:
+        if old is None:
+            del os.environ["DVDA_WINDOW_SECTORS"]
+        else:
+            os.environ["DVDA_WINDOW_SECTORS"] = old
+
+
 REF_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_ref")
 NATIVE_INFO = os.path.join(ROOT, "oracle", "_ref", "debug_info_native")
 
