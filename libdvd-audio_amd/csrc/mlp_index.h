@@ -648,13 +648,18 @@ __global__ __launch_bounds__(256) void k_stream_rank(const uint32_t *__restrict_
                                                      uint32_t *__restrict__ rank, uint32_t *__restrict__ sorted_cnt,
                                                      const uint32_t *__restrict__ hetero)
 {
-    __shared__ uint32_t s_key[1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[1024];
     if (*hetero == 0)
         return;                                   // one shape (k_link looked): lanes keep the index order
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = s < n_streams;
     // streams without a segment sort last (key 0) and take no lanes
     const uint32_t mine = live && streams[s].first_seg != 0xFFFFFFFFu ? shape_key[s] : 0u;
+    // rank = streams with a larger key + streams with the same key and a smaller index.  n_streams^2 comparisons:
+    // round 5 made a comparison two instructions (it was five, and an LDS read per key: 0.45 ms for the fuzz batch's
+    // 16 384 streams) -- a tile of 1 024 streams that lies wholly below this block's streams counts ">= mine", one wholly
+    // above counts "> mine", only the tile the block sits in looks at the index; four keys per LDS read.
+    const uint32_t blk_lo = blockIdx.x * blockDim.x, blk_hi = blk_lo + blockDim.x;        // this block's streams [lo, hi)
     uint32_t before = 0;
     for (uint32_t t0 = 0; t0 < n_streams; t0 += 1024) {
         __syncthreads();
@@ -664,9 +669,23 @@ __global__ __launch_bounds__(256) void k_stream_rank(const uint32_t *__restrict_
         }
         __syncthreads();
         const uint32_t lim = n_streams - t0 < 1024u ? n_streams - t0 : 1024u;
-        for (uint32_t i = 0; i < lim; i++) {
-            const uint32_t k = s_key[i];
-            before += (k > mine || (k == mine && t0 + i < s)) ? 1u : 0u;
+        if (t0 + 1024u <= blk_lo || t0 >= blk_hi) {
+            // (no key is 0xFFFFFFFF -- bits 12..15 of a shape key are never set --: "k >= mine" is "k + 1 > mine")
+            const uint32_t bump = t0 + 1024u <= blk_lo ? 1u : 0u;
+            const uint4 *k4 = reinterpret_cast<const uint4 *>(s_key);
+            uint32_t i = 0;
+            for (; i + 4 <= lim; i += 4) {
+                const uint4 k = k4[i >> 2];
+                before += (k.x + bump > mine ? 1u : 0u) + (k.y + bump > mine ? 1u : 0u) + (k.z + bump > mine ? 1u : 0u) +
+                          (k.w + bump > mine ? 1u : 0u);
+            }
+            for (; i < lim; i++)
+                before += s_key[i] + bump > mine ? 1u : 0u;
+        } else {
+            for (uint32_t i = 0; i < lim; i++) {
+                const uint32_t k = s_key[i];
+                before += (k > mine || (k == mine && t0 + i < s)) ? 1u : 0u;
+            }
         }
     }
     if (!live)
