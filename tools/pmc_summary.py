@@ -16,13 +16,13 @@ for d in sorted(glob.glob(os.path.join(out, "*"))):
         acc = defaultdict(lambda: [0.0, 0])
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                k = (row["Kernel_Name"].split("(")[0][-60:].replace("void ", ""), row["Counter_Name"])
+                k = (row["Kernel_Name"].split("(")[0].replace("void ", "")[-64:], row["Counter_Name"])
                 acc[k][0] += float(row["Counter_Value"])
                 acc[k][1] += 1
         print("== %s" % name)
         for (kern, ctr), (s, n) in sorted(acc.items()):
             if "k_decode" in kern or "k_sync" in kern or "k_chase" in kern:
-                print("%-58s %-26s mean=%.6g n=%d" % (kern, ctr, s / n, n))
+                print("%-62s %-26s mean=%.6g n=%d" % (kern, ctr, s / n, n))
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         print("== %s kernel stats" % name)
         with open(f) as fh:
