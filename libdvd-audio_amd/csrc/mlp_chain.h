@@ -531,6 +531,9 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             ou++;
             if ((qu % (uint32_t)FU_OUT) != my_q)
                 continue;                           // the other output wave's
+#if defined(DVDA_EXP_NOOUT)         // (timing only: the output wave counts its units and does nothing with them)
+            continue;
+#endif
             const int32_t *const X = s_x[t][qu] + cl * FU_XS;
             int32_t ch[6];
 #pragma unroll
@@ -975,7 +978,9 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                     int32_t *const X = s_x[t][qu] + cl * FU_XS;
                     if (__all(plain_turn && (!filt || left >= 8u))) {
                         if (filt) {
+#if !defined(DVDA_EXP_NOFIR)        // (timing only: what the recursion itself costs the filter wave)
                             fir_step8(h, c, shift, qmask, xa, xb);
+#endif
                             left -= 8u;
                         }
                         reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
