@@ -791,6 +791,8 @@ struct mlp_windows {
     unsigned next;              /* next sector to read */
     unsigned window;
     int device, wav_bits;       /* wav_bits != 0: the decode writes the payload (DVDA_PCM_WAV24 / WAV16) */
+    int wav_request, wav_decided;   /* the opener asked for the payload; decided (from the first window's major sync:
+                                       only a 16- or 24-bit stream is decoded straight into it) */
     int started, finished, failed;
     uint8_t *carry;             /* host: bytes from the last cut on */
     size_t carry_len, carry_cap;
@@ -1069,6 +1071,13 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         uint64_t stride = ((info.mlp_frames * per_au + 3) & ~(uint64_t)3);
         if (stride == 0)
             stride = 4;
+        if (w->wav_request && !w->wav_decided) {
+            /* the bit depth is in the index's stream record: known before anything is decoded (round 5: the first
+               window was decoded twice, once as int32 to learn it) */
+            const unsigned b = bits_of(info.group0_bps);
+            w->wav_bits = (b == 16 || b == 24) ? (int)b : 0;
+            w->wav_decided = 1;
+        }
         const unsigned wbits = w->wav_bits;
         if (dvda_mlp_hip_set_pcm_layout(w->ctx, wbits == 24 ? DVDA_PCM_WAV24 : wbits == 16 ? DVDA_PCM_WAV16 : DVDA_PCM_INTERLEAVED) != DVDA_HIP_OK)
             return 0;
@@ -1207,10 +1216,10 @@ static DVDA_Track_Reader *open_mlp_windowed(const DVDA_Track *k)
     aob_open_all(&w->aobs, k->dir, k->titleset);
     if (w->aobs.n == 0)
         goto fail;
-    /* the first window in this thread: the stream's parameters are known when the reader is handed out.  (The output
-       layout is decided by them: a first pass as int32 tells the bit depth, and only a 16- or 24-bit stream can be
-       decoded straight into the payload -- so the first window is decoded once more when it is) */
+    /* the first window in this thread: the stream's parameters are known when the reader is handed out (and the output
+       layout with them: win_produce decides it from the first window's index) */
     w->wav_bits = 0;
+    w->wav_request = g_wav_output ? 1 : 0;
     {
         struct win_slot *out = &w->slot[0];
         for (;;) {
@@ -1221,22 +1230,6 @@ static DVDA_Track_Reader *open_mlp_windowed(const DVDA_Track *k)
         }
         if (!w->info.channels)
             goto fail;
-        const unsigned wbits = g_wav_output ? bits_of(w->info.group0_bps) : 0;
-        if (wbits == 16 || wbits == 24) {
-            /* again, as the payload: back to the track's first sector, nothing kept */
-            w->wav_bits = (int)wbits;
-            w->next = w->first;
-            w->started = w->finished = 0;
-            w->carry_len = 0;
-            w->have_fir = 0;
-            w->frames_total = 0;
-            for (;;) {
-                if (!win_produce(w, out))
-                    goto fail;
-                if (out->frames || w->finished)
-                    break;
-            }
-        }
         if (out->frames) {
             w->head = 1 % WIN_SLOTS;
             w->count = 1;
