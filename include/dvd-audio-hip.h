@@ -104,6 +104,10 @@ int dvda_hip_reader_failed(const DVDA_Track_Reader *reader);
  * windows), and of device memory in use beyond what was in use when it was opened (hipMemGetInfo, sampled after every
  * window); returns 0 on a reader that is not windowed */
 int dvda_hip_reader_memory(const DVDA_Track_Reader *reader, unsigned long long *host_peak, unsigned long long *device_peak);
+/* A windowed reader's decode context, device buffers and pinned buffers are kept, when it is closed, by the closing thread
+ * for the next windowed reader that thread opens on the same device (one set per thread).  This frees the calling
+ * thread's set; a thread that opens no more readers calls it before it ends. */
+void dvda_hip_release_cached_buffers(void);
 /* status word of the decode behind a reader: DVDA_ST_* bits of dvda_mlp_hip.h (0 = clean) */
 unsigned dvda_hip_reader_status(const DVDA_Track_Reader *reader);
 /* PCM frames the reader holds in total */

@@ -821,6 +821,7 @@ struct mlp_windows {
     uint8_t *whole;             /* dvda_hip_reader_wav_payload() on a windowed reader: every window appended (unbounded) */
     /* accounting */
     size_t host_now, host_peak, dev_free0, dev_peak;
+    size_t dev_base;            /* device memory the reader took over from the thread's cache (already allocated at dev_free0) */
 };
 
 static void win_host_add(struct mlp_windows *w, size_t now_more)
@@ -832,8 +833,8 @@ static void win_host_add(struct mlp_windows *w, size_t now_more)
 static void win_dev_sample(struct mlp_windows *w)
 {
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && w->dev_free0 > fr && w->dev_free0 - fr > w->dev_peak)
-        w->dev_peak = w->dev_free0 - fr;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && w->dev_free0 > fr && w->dev_base + (w->dev_free0 - fr) > w->dev_peak)
+        w->dev_peak = w->dev_base + (w->dev_free0 - fr);
 }
 static int win_grow_dev(void **p, size_t *cap, size_t need)
 {
@@ -849,6 +850,49 @@ static int win_grow_dev(void **p, size_t *cap, size_t need)
     return 1;
 }
 
+/* What a windowed reader allocated -- the decode context, the device buffers, the pinned sector buffer and window slots --
+ * kept by the thread that closes it for the next windowed reader the same thread opens on the same device (round 5: a
+ * worker of dvda2wav_hip extracts track after track; allocating and freeing all of it was 50 of a track's 90 ms,
+ * tools/probe/r05_disc_time.sh).  One set per thread; dvda_hip_release_cached_buffers() frees the caller's. */
+struct win_cache {
+    int valid, device;
+    dvda_mlp_hip_ctx *ctx;
+    uint32_t ctx_segs;
+    uint8_t *h_sec, *d_sec, *d_mlp, *d_stream, *carry;
+    uint32_t *d_work, *h_base;
+    uint64_t *d_meta;
+    int32_t *d_pcm, *d_fir;
+    size_t cap_sec, cap_stream, cap_pcm, carry_cap, host_bytes, dev_bytes;
+    struct win_slot slot[WIN_SLOTS];
+};
+static __thread struct win_cache t_win_cache;
+
+static void win_cache_free(struct win_cache *c)
+{
+    if (!c->valid)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->ctx)
+        dvda_mlp_hip_destroy(c->ctx);
+    for (int i = 0; i < WIN_SLOTS; i++)
+        if (c->slot[i].host)
+            (void)hipHostFree(c->slot[i].host);
+    if (c->h_sec)
+        (void)hipHostFree(c->h_sec);
+    free(c->h_base);
+    free(c->carry);
+    (void)hipFree(c->d_sec);
+    (void)hipFree(c->d_mlp);
+    (void)hipFree(c->d_stream);
+    (void)hipFree(c->d_work);
+    (void)hipFree(c->d_meta);
+    (void)hipFree(c->d_pcm);
+    (void)hipFree(c->d_fir);
+    memset(c, 0, sizeof(*c));
+}
+
+void dvda_hip_release_cached_buffers(void) { win_cache_free(&t_win_cache); }
+
 static void windows_free(struct mlp_windows *w)
 {
     if (!w)
@@ -860,24 +904,34 @@ static void windows_free(struct mlp_windows *w)
         pthread_mutex_unlock(&w->mu);
         pthread_join(w->th, NULL);
     }
-    (void)hipSetDevice(w->device);
-    if (w->ctx)
-        dvda_mlp_hip_destroy(w->ctx);
-    for (int i = 0; i < WIN_SLOTS; i++)
-        if (w->slot[i].host)
-            (void)hipHostFree(w->slot[i].host);
-    if (w->h_sec)
-        (void)hipHostFree(w->h_sec);
-    free(w->h_base);
-    free(w->carry);
+    /* the buffers go to this thread's cache (whatever it held before is freed: the newer set fits the newer tracks) */
+    struct win_cache *c = &t_win_cache;
+    win_cache_free(c);
+    c->valid = 1;
+    c->device = w->device;
+    c->ctx = w->ctx;
+    c->ctx_segs = w->ctx_segs;
+    c->h_sec = w->h_sec;
+    c->d_sec = w->d_sec;
+    c->d_mlp = w->d_mlp;
+    c->d_stream = w->d_stream;
+    c->carry = w->carry;
+    c->d_work = w->d_work;
+    c->h_base = w->h_base;
+    c->d_meta = w->d_meta;
+    c->d_pcm = w->d_pcm;
+    c->d_fir = w->d_fir;
+    c->cap_sec = w->cap_sec;
+    c->cap_stream = w->cap_stream;
+    c->cap_pcm = w->cap_pcm;
+    c->carry_cap = w->carry_cap;
+    c->host_bytes = w->host_now;
+    c->dev_bytes = w->dev_peak;
+    for (int i = 0; i < WIN_SLOTS; i++) {
+        c->slot[i] = w->slot[i];
+        c->slot[i].frames = 0;
+    }
     free(w->whole);
-    (void)hipFree(w->d_sec);
-    (void)hipFree(w->d_mlp);
-    (void)hipFree(w->d_stream);
-    (void)hipFree(w->d_work);
-    (void)hipFree(w->d_meta);
-    (void)hipFree(w->d_pcm);
-    (void)hipFree(w->d_fir);
     aob_close_all(&w->aobs);
     pthread_mutex_destroy(&w->mu);
     pthread_cond_destroy(&w->cv);
@@ -1212,6 +1266,36 @@ static DVDA_Track_Reader *open_mlp_windowed(const DVDA_Track *k)
     w->first = w->next = k->s.first;
     w->last = k->s.last >= k->s.first ? k->s.last : k->s.first;
     w->window = window_sectors();
+    {
+        /* what the last windowed reader of this thread left (same device): its context and buffers serve this track too */
+        struct win_cache *c = &t_win_cache;
+        if (c->valid && c->device != w->device)
+            win_cache_free(c);
+        if (c->valid) {
+            w->ctx = c->ctx;
+            w->ctx_segs = c->ctx_segs;
+            w->h_sec = c->h_sec;
+            w->d_sec = c->d_sec;
+            w->d_mlp = c->d_mlp;
+            w->d_stream = c->d_stream;
+            w->carry = c->carry;
+            w->d_work = c->d_work;
+            w->h_base = c->h_base;
+            w->d_meta = c->d_meta;
+            w->d_pcm = c->d_pcm;
+            w->d_fir = c->d_fir;
+            w->cap_sec = c->cap_sec;
+            w->cap_stream = c->cap_stream;
+            w->cap_pcm = c->cap_pcm;
+            w->carry_cap = c->carry_cap;
+            for (int i = 0; i < WIN_SLOTS; i++)
+                w->slot[i] = c->slot[i];
+            w->host_now = w->host_peak = c->host_bytes;
+            w->dev_base = c->dev_bytes;
+            w->dev_peak = c->dev_bytes;
+            memset(c, 0, sizeof(*c));
+        }
+    }
     (void)hipMemGetInfo(&w->dev_free0, &tot);
     aob_open_all(&w->aobs, k->dir, k->titleset);
     if (w->aobs.n == 0)

@@ -24,6 +24,7 @@ EXPORTS = [
     "dvda_hip_set_device", "dvda_hip_set_wav_output", "dvda_hip_reader_status", "dvda_hip_reader_total_frames",
     "dvda_hip_reader_wav_payload", "dvda_hip_open_track_reader_on", "dvda_hip_reader_wav_only",
     "dvda_hip_reader_wav_next", "dvda_hip_reader_windowed", "dvda_hip_reader_memory", "dvda_hip_reader_failed",
+    "dvda_hip_release_cached_buffers",
 ]
 
 _lib = None

@@ -161,6 +161,10 @@ static void *work(void *arg)
         if (!extract(w->pool->jobs[i].title, w->pool->jobs[i].track, w->pool->dir, w->device, w->pool->fused_wav))
             atomic_fetch_add(&w->pool->failed, 1);
     }
+    /* what this thread's last windowed reader left for a next one: freeing it is 30 ms a worker, and the process is
+       about to leave -- done only where main() tears everything down */
+    if (getenv("DVDA_TOOL_FULL_TEARDOWN"))
+        dvda_hip_release_cached_buffers();
     return NULL;
 }
 

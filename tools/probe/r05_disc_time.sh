@@ -13,7 +13,7 @@ import libdvd_audio_amd as pkg
 syn, disc = pkg.synth, pkg.disc
 tool = pkg._build.build_tool()
 with tempfile.TemporaryDirectory() as tmp:
-    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=16384)
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=int(os.environ.get("AUS", "16384")))
     tracks = []
     for t in range(8):
         b, f = syn.stream(cfg, 100 + t)
