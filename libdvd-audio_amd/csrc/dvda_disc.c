@@ -893,6 +893,20 @@ static void win_cache_free(struct win_cache *c)
 
 void dvda_hip_release_cached_buffers(void) { win_cache_free(&t_win_cache); }
 
+/* ... and a thread that ends without calling it does not keep them: a key whose destructor frees the thread's set */
+static pthread_key_t g_win_cache_key;
+static pthread_once_t g_win_cache_once = PTHREAD_ONCE_INIT;
+static void win_cache_at_thread_exit(void *p)
+{
+    win_cache_free((struct win_cache *)p);
+}
+static void win_cache_make_key(void) { (void)pthread_key_create(&g_win_cache_key, win_cache_at_thread_exit); }
+static void win_cache_arm(struct win_cache *c)
+{
+    (void)pthread_once(&g_win_cache_once, win_cache_make_key);
+    (void)pthread_setspecific(g_win_cache_key, c);
+}
+
 static void windows_free(struct mlp_windows *w)
 {
     if (!w)
@@ -908,6 +922,7 @@ static void windows_free(struct mlp_windows *w)
     struct win_cache *c = &t_win_cache;
     win_cache_free(c);
     c->valid = 1;
+    win_cache_arm(c);
     c->device = w->device;
     c->ctx = w->ctx;
     c->ctx_segs = w->ctx_segs;

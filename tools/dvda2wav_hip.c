@@ -142,7 +142,7 @@ struct job {
 struct pool {
     struct job *jobs;
     unsigned n_jobs;
-    atomic_uint next, failed;
+    atomic_uint next, failed, done;     /* done: workers through with the job list */
     const char *dir;
     int fused_wav;
 };
@@ -161,10 +161,9 @@ static void *work(void *arg)
         if (!extract(w->pool->jobs[i].title, w->pool->jobs[i].track, w->pool->dir, w->device, w->pool->fused_wav))
             atomic_fetch_add(&w->pool->failed, 1);
     }
-    /* what this thread's last windowed reader left for a next one: freeing it is 30 ms a worker, and the process is
-       about to leave -- done only where main() tears everything down */
-    if (getenv("DVDA_TOOL_FULL_TEARDOWN"))
-        dvda_hip_release_cached_buffers();
+    /* (what this thread's last windowed reader left for a next one is freed when the thread ends -- 30 ms a worker:
+       main() does not wait for that, it leaves as soon as every worker is through with the list) */
+    atomic_fetch_add(&w->pool->done, 1);
     return NULL;
 }
 
@@ -262,7 +261,7 @@ int main(int argc, char *argv[])
         for (unsigned i = 0; i < w; i++)
             devices[n_devices++] = one_device;
     }
-    struct pool pool = {jobs, n_jobs, 0, 0, dir, fused_wav};
+    struct pool pool = {jobs, n_jobs, 0, 0, 0, dir, fused_wav};
     struct worker workers[64];
     pthread_t th[64];
     int started[64];
@@ -273,9 +272,22 @@ int main(int argc, char *argv[])
         if (!started[i])
             work(&workers[i]);              /* one entry (or no thread to be had): here, in turn */
     }
-    for (int i = 0; i < n_devices; i++)
-        if (started[i])
-            pthread_join(th[i], NULL);
+    {
+        unsigned n_started = 0;
+        for (int i = 0; i < n_devices; i++)
+            n_started += started[i] ? 1u : 0u;
+        if (getenv("DVDA_TOOL_FULL_TEARDOWN")) {
+            for (int i = 0; i < n_devices; i++)
+                if (started[i])
+                    pthread_join(th[i], NULL);
+        } else {
+            /* every file is closed when a worker counts itself done; its buffers' release is not waited for */
+            while (atomic_load(&pool.done) < n_started) {
+                struct timespec ts = {0, 200000};
+                nanosleep(&ts, NULL);
+            }
+        }
+    }
     /* a track that could not be extracted (no such device, a read error, a decode the library reports) fails the run */
     if (atomic_load(&pool.failed)) {
         fprintf(stderr, "*** Error: %u of %u tracks could not be extracted\n", atomic_load(&pool.failed), n_jobs);
