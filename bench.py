@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the full-size check")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (other shapes of the path)")
+    ap.add_argument("--no-disc", action="store_true", help="skip sub.disc_tier (a synthetic disc extracted by build/dvda2wav_hip)")
     ap.add_argument("--chain-flight", type=int, default=0,
                     help="diagnostic: also time sub.chained_two_substreams with this many decode contexts in flight")
     ap.add_argument("--only-sub", default="", help="comma-separated sub-record names: run only those (profiling)")
@@ -405,6 +406,64 @@ def gen_mixed(syn, specs, seed0):
 
 
 # ----------------------------------------------------------------------------- sub-records (N = 1)
+def disc_tier(pkg, oracle_mod=None, tracks=8, aus=65536):
+    """The disc tier end to end, wall clock: a synthetic disc (IFO + one AOB file, `tracks` MLP tracks of `aus` access
+    units, 6-ch / 96 kHz / 24-bit) extracted by build/dvda2wav_hip -- process start, HIP runtime start, file read,
+    demux + index + decode in windows, WAV write.  The second of two runs (the first one warms the page cache), the
+    first track's WAV payload compared with the oracle's.  Never `value`: it is host I/O and a process's fixed cost as
+    much as the decode.  tools/disc_bench.py is the same with the reference's own tool beside it."""
+    import re
+    import tempfile
+    syn, disc = pkg.synth, pkg.disc
+    rec = {"unit": "Msamples/s", "tracks": tracks, "access_units_per_track": aus}
+    try:
+        tool = pkg._build.build_tool()
+        with tempfile.TemporaryDirectory() as tmp:          # (the default temporary directory, as tools/disc_bench.py)
+            cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=aus)
+            tr, samples, first = [], 0, None
+            for t in range(tracks):
+                b, f = syn.stream(cfg, 100 + t)
+                if t == 0:
+                    first = (b, f)
+                tr.append({"sectors": disc.mlp_track_sectors(b), "pcm_frames": f, "rate_code": 1})
+                samples += f * 6
+            ats = disc.write_disc_titles(tmp, [tr])
+            rec["aob_bytes"] = os.path.getsize(os.path.join(ats, "ATS_01_1.AOB"))
+            rec["samples"] = samples
+            env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "libdvd-audio_amd") + ":/opt/rocm/lib:" +
+                       os.environ.get("LD_LIBRARY_PATH", ""))
+            out = os.path.join(tmp, "out")
+            os.makedirs(out)
+            secs = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([tool, "-A", ats, "-d", out], capture_output=True, text=True, env=env)
+                secs.append(time.perf_counter() - t0)
+                if r.returncode != 0:
+                    raise RuntimeError("dvda2wav_hip: rc %d: %s" % (r.returncode, r.stderr[-300:]))
+            pk = re.findall(r"host peak ([0-9.]+) MB, device peak ([0-9.]+) MB", r.stdout)
+            if pk:
+                rec["host_peak_mb_max"] = max(float(x[0]) for x in pk)
+                rec["device_peak_mb_max"] = max(float(x[1]) for x in pk)
+            rec["seconds"] = round(secs[1], 3)
+            rec["seconds_first_run"] = round(secs[0], 3)
+            rec["value"] = round(samples / secs[1] / 1e6, 1)
+            if oracle_mod is not None:
+                want, got_frames, st = oracle_mod.decode(first[0], 6, first[1])
+                with open(os.path.join(out, "track-01-01.wav"), "rb") as fh:
+                    wav = fh.read()
+                rec["first_track_identical_to_oracle"] = bool(st == 0 and wav[68:] == oracle_mod.wav_pack(want, 24))
+                if not rec["first_track_identical_to_oracle"]:
+                    raise SystemExit("sub-record disc_tier: track 1's WAV payload differs from the oracle's")
+            rec["note"] = ("wall clock of build/dvda2wav_hip on a synthetic %d-track disc (%d MB of AOB), second run; four worker "
+                           "threads on one GPU, tracks read in windows of 8 192 sectors" % (tracks, rec["aob_bytes"] >> 20))
+    except SystemExit:
+        raise
+    except Exception as e:          # (no room for the files, no tool: the record says so, the bench line stays)
+        rec["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    return rec
+
+
 def streaming_tier(pkg, oracle_mod=None):
     """Tier B, the mlp.h mirror (dvda_hip_mlpdecoder_decode_packet): one 6-ch / 96 kHz title of 1 024 access units fed
     in PES-payload sized packets (2 011 bytes), the C entry point called directly; the PCM of every call collected and
@@ -1198,6 +1257,11 @@ def main():
             if not only or "streaming_tier" in only:
                 from tests import oracle_lib as _ol
                 out["sub"]["streaming_tier"] = streaming_tier(pkg, _ol.Oracle())
+            if (not only or "disc_tier" in only) and not args.no_disc:
+                from tests import oracle_lib as _ol
+                t_d = time.perf_counter()
+                out["sub"]["disc_tier"] = disc_tier(pkg, _ol.Oracle())
+                sys.stderr.write("bench: disc tier record %.1f s\n" % (time.perf_counter() - t_d))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
