@@ -202,7 +202,16 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
                 // are the only bytes read again; asked for HERE, with everything else of this unit: one memory round
                 // trip per access unit
                 const uint32_t bh = ss_lo & ~15u, bt = end_m & ~15u;
-                const uint4 v_edge = *reinterpret_cast<const uint4 *>(ubytes + (j == 1 ? bt : bh));
+                // (round 5, eight lanes per segment: a lane takes ONE dword of the two ragged chunks -- lanes 0..3 the
+                //  head's, 4..7 the tail's -- four look-ups each; two lanes hashing a whole masked chunk each were 100
+                //  of this kernel's 360 instructions per access unit, and it is bound by their number)
+                constexpr bool EDGE8 = CHK_GROUP == 8;
+                uint4 v_edge = make_uint4(0, 0, 0, 0);
+                uint32_t w_edge = 0;
+                if constexpr (EDGE8)
+                    w_edge = *reinterpret_cast<const uint32_t *>(ubytes + ((j & 4u) ? bt : bh) + 4u * (j & 3u));
+                else
+                    v_edge = *reinterpret_cast<const uint4 *>(ubytes + (j == 1 ? bt : bh));
                 // ---- whole chunks inside [ss_lo, end_m): their partial sums, CHK_RUN chunks per lane and pass
                 const uint32_t ci0 = (ss_lo + 15u) >> 4, ci1 = end_m >> 4;  // chunk indices [ci0, ci1) from ub on
                 uint32_t red = 0;                                           // crc | parity << 8 of this lane's share
@@ -238,6 +247,24 @@ __device__ __forceinline__ void au_check_group(uint32_t g, uint32_t j, const uin
                 {
                     const bool head = (ss_lo & 15u) != 0 && end_m > ss_lo;
                     const bool tail = (end_m & 15u) != 0 && end_m > ss_lo && !(head && bt == bh);
+                    if constexpr (EDGE8) {
+                        const bool mine_tail = (j & 4u) != 0;
+                        if (mine_tail ? tail : head) {
+                            const uint32_t B = mine_tail ? bt : bh;
+                            const int32_t k4 = 4 * (int32_t)(j & 3u);
+                            const int32_t lo = mine_tail ? 0 : (int32_t)(ss_lo - B);
+                            const int32_t hi = end_m - B < 16u ? (int32_t)(end_m - B) : 16;
+                            const uint32_t m = w_edge & chk_mask_lt(hi - k4) & ~chk_mask_lt(lo - k4);
+                            // byte i of the chunk carries x^(8 (16 - i)): table 15 - i (as chk_masked_chunk)
+                            const uint8_t *const tb = s_slice + (15 - k4) * 256;
+                            const uint32_t cc = (uint32_t)tb[m & 0xFFu] ^ tb[-256 + (int32_t)((m >> 8) & 0xFFu)] ^
+                                                tb[-512 + (int32_t)((m >> 16) & 0xFFu)] ^ tb[-768 + (int32_t)(m >> 24)];
+                            uint32_t px = m ^ (m >> 16);
+                            px = (px ^ (px >> 8)) & 0xFFu;
+                            const int32_t d = (int32_t)end_m - (int32_t)(B + 16u);
+                            red ^= shift(cc, (8u * (uint32_t)(d + 8160)) % 255u) | (px << 8);
+                        }
+                    } else
                     if ((j == 0 && head) || (j == 1 && tail)) {
                         const uint32_t B = j == 0 ? bh : bt;
                         const int32_t lo = j == 0 ? (int32_t)(ss_lo - B) : 0;
