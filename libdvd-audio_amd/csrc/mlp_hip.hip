@@ -93,6 +93,8 @@ struct dvda_mlp_hip_ctx {
     uint32_t *d_lane_seg;      // [max_segments]
     DecodeSummary *d_summary;
     DecodeSummary *h_summary;  // pinned
+    hipStream_t st_aux;        // the index's side branch: lane packing beside k_au_check (round 5)
+    hipEvent_t ev_fork, ev_join;
     uint32_t *d_seq_list;      // [max_streams]: streams for the sequential pass
     uint4 *d_plan;             // [max_segments + 1]
     uint4 *d_scan4_tmp;        // [max_segments / 1024 + 2]
@@ -202,6 +204,12 @@ static void free_ws(dvda_mlp_hip_ctx *c)
     (void)hipFree(c->d_summary);
     if (c->h_summary)
         (void)hipHostFree(c->h_summary);
+    if (c->st_aux)
+        (void)hipStreamDestroy(c->st_aux);
+    if (c->ev_fork)
+        (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join)
+        (void)hipEventDestroy(c->ev_join);
     (void)hipFree(c->d_seq_list);
     (void)hipFree(c->d_plan);
     (void)hipFree(c->d_scan4_tmp);
@@ -303,6 +311,12 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
     alloc((void **)&c->d_chain_hist, 2 * CHAIN_BUCKETS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&c->h_summary, sizeof(DecodeSummary), hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&c->st_aux, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipMemset(c->d_dbg, 0, 32 * sizeof(unsigned long long));
     if (e == hipSuccess)
@@ -556,18 +570,32 @@ static void enqueue_index(dvda_mlp_hip_ctx *c, hipStream_t st, const uint8_t *d_
     hipLaunchKernelGGL(k_link, dim3((ms + 255) / 256), dim3(256), 0, st, d_stream_off, d_stream_len,
                        c->d_n_cand, ms, c->d_seg, c->d_seg_fbase, c->d_streams, n_streams, c->d_shape_key,
                        c->d_cls + (pack ? 2 : 3));
-    // lane packing by stream shape (identity, and next to free, when the batch has one shape)
+    // lane packing by stream shape (identity, and next to free, when the batch has one shape) -- five or six small
+    // launches that nothing but the decode waits for: on a side stream, beside k_au_check (round 5: 25 us of the
+    // bench batch's index, 0.2 ms of a batch of 16 384 streams of mixed shapes).  Forked and joined by events, which a
+    // stream capture turns into the graph's edges.
+    hipStream_t sp = st;
+    bool forked = false;
+    if (pack && st != nullptr && c->st_aux && hipEventRecord(c->ev_fork, st) == hipSuccess &&
+        hipStreamWaitEvent(c->st_aux, c->ev_fork, 0) == hipSuccess) {
+        sp = c->st_aux;
+        forked = true;
+    }
     if (pack) {
-    hipLaunchKernelGGL(k_stream_rank, dim3((n_streams + 255) / 256), dim3(256), 0, st, c->d_shape_key, c->d_streams,
+    hipLaunchKernelGGL(k_stream_rank, dim3((n_streams + 255) / 256), dim3(256), 0, sp, c->d_shape_key, c->d_streams,
                        n_streams, c->d_rank, c->d_sorted_cnt, c->d_cls + 2);
-    exscan(c, st, c->d_sorted_cnt, c->d_sorted_base, n_streams, nullptr, n_streams);
-    (void)hipMemsetAsync(c->d_lane_seg, 0xFF, (size_t)ms * sizeof(uint32_t), st);     // lanes that are dealt nothing
-    hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, st, c->d_seg, c->d_streams, c->d_n_cand, ms,
+    exscan(c, sp, c->d_sorted_cnt, c->d_sorted_base, n_streams, nullptr, n_streams);
+    (void)hipMemsetAsync(c->d_lane_seg, 0xFF, (size_t)ms * sizeof(uint32_t), sp);     // lanes that are dealt nothing
+    hipLaunchKernelGGL(k_lane_perm, dim3((ms + 255) / 256), dim3(256), 0, sp, c->d_seg, c->d_streams, c->d_n_cand, ms,
                        c->d_rank, c->d_sorted_base, c->d_cls + 2, c->d_lane_seg);
     }
-    // parity / CRC-8 of every substream, byte-parallel (16 lanes per segment): the decode lanes only compare
+    // parity / CRC-8 of every substream, byte-parallel (8 lanes per segment): the decode lanes only compare
     hipLaunchKernelGGL(k_au_check, dim3((unsigned)(((uint64_t)ms * CHK_GROUP + CHK_THREADS - 1) / CHK_THREADS)),
                        dim3(CHK_THREADS), 0, st, d_bytes, c->d_parts, c->d_seg, c->d_n_cand, ms, c->d_streams, c->d_seg_check);
+    if (forked) {
+        (void)hipEventRecord(c->ev_join, sp);
+        (void)hipStreamWaitEvent(st, c->ev_join, 0);
+    }
 }
 
 extern "C" int dvda_mlp_hip_index(dvda_mlp_hip_ctx *c, const uint8_t *d_bytes, uint64_t total_bytes,
