@@ -17,7 +17,7 @@ STEPS = 4          # (replaced per sub-record by the number of its steps found i
 
 def short(n):
     n = n.replace("void ", "").replace("mlp::", "")
-    return n.split("(")[0][:44]
+    return n.split("(")[0][:52]
 
 
 res = {}
