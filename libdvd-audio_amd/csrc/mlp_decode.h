@@ -85,18 +85,16 @@ constexpr uint32_t YIELD_LONELY = 48;
 #define DVDA_COOP_OUT 1
 #endif
 // (its seven store instructions unrolled: 3.32 ms against 3.33 with two copies and 3.44 as a loop, one box; the unrolled
-//  form makes the compiler spill 47 registers of cold state in this instance -- 23 as a loop -- and the packed-WAV flush,
-//  which shares the instance, runs 3 % slower with any of them: 3.51 -> 3.62 ms)
-// 1: the packed WAV payload has the frame-major instance k_decode<.., WAVO> to itself (the host launches it for those layouts)
-#ifndef DVDA_WAV_INSTANCE
-#define DVDA_WAV_INSTANCE 1
-#endif
+//  form makes the compiler spill 47 registers of cold state in this instance -- 23 as a loop; none of them in the row path)
 #ifndef DVDA_COOP_UNROLL
 #define DVDA_COOP_UNROLL 7
 #endif
-// the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
-// the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
-// the one LDS round trip per row they hide)
+// 1: the packed WAV payload has the frame-major instance k_decode<.., WAVO> to itself (the host launches it for those
+// layouts): sharing one with the cooperative flush cost the payload's flush 3 % (3.51 -> 3.62 ms)
+#ifndef DVDA_WAV_INSTANCE
+#define DVDA_WAV_INSTANCE 1
+#endif
+// ---- round-5 experiments kept behind macros (tools/ab_build.py builds the variants; DESIGN.md A.5 has what each measured)
 // the synchronous ring fill as a call (rounds 1-4) or inlined where it is used (round 5: a call in the row loop's cold
 // branch made the register allocator keep the loop's state clear of the caller-saved registers by copying it -- sixty
 // moves per PCM frame on the hot path)
@@ -108,33 +106,40 @@ constexpr uint32_t YIELD_LONELY = 48;
 #else
 #define DVDA_FILL_INLINE __forceinline__
 #endif
+// the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
+// the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
+// the one LDS round trip per row they hide)
 #ifndef DVDA_CARRY_WINDOW
 #define DVDA_CARRY_WINDOW 0
 #endif
-// the slot loop: 1 = one version, slots under the execution mask of the lanes that carry them; 0 = three versions
-// (all lanes NS slots / all lanes two / lanes that disagree: selects), picked per row
-// cache policy of the row loop's prefetch loads: 0 default, 1 nontemporal (nt)
+// cache policy of the row loop's prefetch loads: 0 default, 1 nontemporal (nt), 2 sc1 (both slower: three of a chunk's
+// four loads hit the line the first one brought into L1)
 #ifndef DVDA_PF_POLICY
 #define DVDA_PF_POLICY 0
 #endif
 // 1: the wave prefetches together -- the lanes that need a chunk publish (chunk, lane) in LDS, and every four lanes
 // fetch one request's 64 bytes as four adjacent 16-byte pieces (one load instruction serves 16 chunks, each a whole
-// 64-byte segment, instead of four instructions that each touch 64 different lines)
+// 64-byte segment, instead of four instructions that each touch 64 different lines).  Parity-green, no faster.
 #ifndef DVDA_COOP_PF
 #define DVDA_COOP_PF 0
 #endif
 #ifndef DVDA_COOP_PF_GROUPS
 #define DVDA_COOP_PF_GROUPS 3
 #endif
+// the two register-resident matrices one coefficient per register (frame-major one-lane instance only)
 #ifndef DVDA_MAT_UNPACKED
 #define DVDA_MAT_UNPACKED 1
 #endif
+// the slot loop: 1 = one version, slots under the execution mask of the lanes that carry them; 0 = three versions
+// (all lanes NS slots / all lanes two / lanes that disagree: selects), picked per row
 #ifndef DVDA_SLOT_MODE
 #define DVDA_SLOT_MODE 1
 #endif
+// (of the three versions: the all-lanes-two one)
 #ifndef DVDA_UNI2
 #define DVDA_UNI2 1
 #endif
+// the next symbol's window read issued as soon as this symbol's length is known
 #ifndef DVDA_EARLY_WINDOW
 #define DVDA_EARLY_WINDOW 1
 #endif
@@ -142,6 +147,7 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_FIX_INSTANCE
 #define DVDA_FIX_INSTANCE 0
 #endif
+// ensure(n) wave-wide: if any lane is short of n resident dwords, the lanes at most a chunk ahead refill together
 #ifndef DVDA_WAVE_ENSURE
 #define DVDA_WAVE_ENSURE 1
 #endif
