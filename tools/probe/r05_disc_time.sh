@@ -13,7 +13,8 @@ import libdvd_audio_amd as pkg
 syn, disc = pkg.synth, pkg.disc
 tool = pkg._build.build_tool()
 with tempfile.TemporaryDirectory() as tmp:
-    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=int(os.environ.get("AUS", "16384")))
+    ch = bool(os.environ.get("CHAINED"))
+    cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=int(os.environ.get("AUS", "16384")), profile=1 if ch else 0, features=syn.SF["CHAINED"] if ch else 0)
     tracks = []
     for t in range(8):
         b, f = syn.stream(cfg, 100 + t)
