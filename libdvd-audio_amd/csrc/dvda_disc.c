@@ -808,8 +808,15 @@ struct mlp_windows {
     size_t cap_sec, cap_stream, cap_pcm;        /* sectors, bytes, bytes */
     /* what the stream is (first window) */
     dvda_mlp_stream_info info;
-    unsigned status;
+    unsigned status;            /* (with frames_total and `finished`: published under `mu`, win_commit()) */
     uint64_t frames_total;
+    /* what win_produce() found, private to the thread that runs it until win_commit() publishes it under `mu` -- in the
+       same critical section that queues the window (round 6: `finished` used to be set by win_produce itself, without
+       the lock, BEFORE the producer queued the last window: a consumer that looked in between saw "no window, finished"
+       and reported the end of the track with the last window still unqueued) */
+    int p_final;
+    unsigned p_status;
+    uint64_t p_frames;
     /* producer / consumer */
     pthread_t th;
     int th_started, stop;
@@ -954,13 +961,14 @@ static void windows_free(struct mlp_windows *w)
 }
 
 /* the last segment of the index (a live one: a sync pattern inside another segment's frames is not a cut) -> its number
- * and byte offset; 0 when the stream has no segment start behind its first byte */
+ * and byte offset; 0 when the stream has no segment start behind its first byte, -1 when the device call failed (that is
+ * not "no cut": taken as one, the carried bytes would grow window after window) */
 static int win_last_cut(struct mlp_windows *w, uint32_t n_seg, uint32_t *seg_out, uint64_t *off_out)
 {
     for (uint32_t s = n_seg; s-- > 0;) {
         dvda_mlp_segment_info si;
         if (dvda_mlp_hip_segment_info(w->ctx, s, &si, NULL) != DVDA_HIP_OK)
-            return 0;
+            return -1;
         if (si.status & DVDA_ST_FALSE_SYNC)
             continue;
         *seg_out = s;
@@ -997,8 +1005,9 @@ static int win_index(struct mlp_windows *w, uint64_t len, uint32_t *n_seg)
     return 0;
 }
 
-/* One window into `out`: 1 = out holds frames (possibly none), 0 = failure.  Sets w->finished behind the track's last
- * window.  Runs in the opener's thread for the first window, in the producer thread afterwards. */
+/* One window into `out`: 1 = out holds frames (possibly none), 0 = failure.  Leaves "this was the track's last window",
+ * the window's status bits and its frame count in w->p_*: the caller publishes them (win_commit, under w->mu once a
+ * consumer exists).  Runs in the opener's thread for the first window, in the producer thread afterwards. */
 static int win_produce(struct mlp_windows *w, struct win_slot *out)
 {
     out->frames = 0;
@@ -1087,7 +1096,7 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         w->next += final ? got : in_track;
         w->started = 1;
         if (len == 0) {
-            w->finished = final;
+            w->p_final = final;
             return final;                        /* an empty track does not open */
         }
         uint32_t n_seg = 0, cut_seg = 0;
@@ -1097,7 +1106,10 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         if (!win_index(w, len, &n_seg))
             return 0;
         if (!final) {
-            if (!win_last_cut(w, n_seg, &cut_seg, &cut)) {
+            const int have_cut = win_last_cut(w, n_seg, &cut_seg, &cut);
+            if (have_cut < 0)
+                return 0;
+            if (!have_cut) {
                 /* no segment starts inside this window: all of it waits for the next one */
                 cut = 0;
             }
@@ -1165,7 +1177,7 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
                 return 0;
             stride = (info.pcm_frames + 3) & ~(uint64_t)3;       /* access units longer than the standard length */
         }
-        w->status |= info.status;
+        w->p_status |= info.status;
         if (info.status & ~(uint32_t)DVDA_ST_BENIGN)
             return 0;                            /* the reference assert()s on such a stream */
         if (!w->info.channels)
@@ -1174,7 +1186,8 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         if (!final) {
             uint32_t last_seg = 0;
             uint64_t dummy = 0;
-            (void)win_last_cut(w, n_seg, &last_seg, &dummy);
+            if (win_last_cut(w, n_seg, &last_seg, &dummy) < 0)
+                return 0;
             if (dvda_mlp_hip_segment_fir(w->ctx, last_seg, w->fir, NULL) != DVDA_HIP_OK)
                 return 0;
             w->have_fir = 1;
@@ -1197,11 +1210,21 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         if (bytes && hipMemcpy(out->host, w->d_pcm, bytes, hipMemcpyDeviceToHost) != hipSuccess)
             return 0;
         out->frames = info.pcm_frames;
-        w->frames_total += info.pcm_frames;
+        w->p_frames += info.pcm_frames;
         win_dev_sample(w);
-        w->finished = final;
+        w->p_final = final;
         return 1;
     }
+}
+
+/* publishes what the last win_produce() left (the caller holds w->mu, or no consumer exists yet) */
+static void win_commit(struct mlp_windows *w)
+{
+    w->status |= w->p_status;
+    w->frames_total += w->p_frames;
+    w->p_frames = 0;
+    if (w->p_final)
+        w->finished = 1;
 }
 
 static void *win_thread(void *arg)
@@ -1226,6 +1249,7 @@ static void *win_thread(void *arg)
         pthread_mutex_unlock(&w->mu);
         const int ok = win_produce(w, out);
         pthread_mutex_lock(&w->mu);
+        win_commit(w);                          /* status, frames and "finished" together with the window itself */
         if (!ok)
             w->failed = 1;
         else if (out->frames) {
@@ -1322,7 +1346,9 @@ static DVDA_Track_Reader *open_mlp_windowed(const DVDA_Track *k)
     {
         struct win_slot *out = &w->slot[0];
         for (;;) {
-            if (!win_produce(w, out))
+            const int ok = win_produce(w, out);
+            win_commit(w);                      /* (no consumer yet: no lock needed) */
+            if (!ok)
                 goto fail;
             if (out->frames || w->finished)
                 break;
@@ -1514,11 +1540,24 @@ dvda_codec_t dvda_codec(const DVDA_Track_Reader *r) { return r->codec; }
 unsigned dvda_bits_per_sample(const DVDA_Track_Reader *r) { return bits_of(r->bps_code[0]); }
 unsigned dvda_sample_rate(const DVDA_Track_Reader *r) { return rate_of(r->rate_code[0]); }
 unsigned dvda_channel_count(const DVDA_Track_Reader *r) { return channels_of(r->assignment); }
-unsigned dvda_hip_reader_status(const DVDA_Track_Reader *r) { return r->win ? r->win->status : r->status; }
+unsigned dvda_hip_reader_status(const DVDA_Track_Reader *r)
+{
+    if (!r->win)
+        return r->status;
+    pthread_mutex_lock(&r->win->mu);
+    const unsigned st = r->win->status;
+    pthread_mutex_unlock(&r->win->mu);
+    return st;
+}
 /* (a track read in windows knows its length when its last window has been decoded: until then, the frames so far) */
 unsigned long long dvda_hip_reader_total_frames(const DVDA_Track_Reader *r)
 {
-    return r->win ? r->win->frames_total : r->frames;
+    if (!r->win)
+        return r->frames;
+    pthread_mutex_lock(&r->win->mu);
+    const unsigned long long n = r->win->frames_total;
+    pthread_mutex_unlock(&r->win->mu);
+    return n;
 }
 int dvda_hip_reader_windowed(const DVDA_Track_Reader *r) { return r && r->win != NULL; }
 int dvda_hip_reader_failed(const DVDA_Track_Reader *r)

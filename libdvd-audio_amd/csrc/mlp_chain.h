@@ -531,9 +531,6 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
             ou++;
             if ((qu % (uint32_t)FU_OUT) != my_q)
                 continue;                           // the other output wave's
-#if defined(DVDA_EXP_NOOUT)         // (timing only: the output wave counts its units and does nothing with them)
-            continue;
-#endif
             const int32_t *const X = s_x[t][qu] + cl * FU_XS;
             int32_t ch[6];
 #pragma unroll
@@ -941,13 +938,8 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
         const int4 *N = Q + (size_t)(w < nu ? w : nu - 1u) * 16u;
         // (piece 7 of a line is not used -- the bypassed LSBs ride in the seed word, piece 6 -- but its lanes ask all the
         //  same: masking them off costs the wave more than the 16 bytes cost the memory side, measured 7.96 -> 8.42 ms)
-#if defined(DVDA_EXP_NOUNITDMA)      // (timing only: no plane line is ever loaded)
-        (void)N;
-        (void)place;
-#else
         fu_dma16(N, fu_lds(&s_ring[place][0][0]));          // (no instruction offset: it would move the LDS address too)
         fu_dma16(N + 8, fu_lds(&s_ring[place][1][0]));
-#endif
     };
 
 #if defined(DVDA_EXP_STAMP)
@@ -983,17 +975,11 @@ __global__ __launch_bounds__(FU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
                     int32_t *const X = s_x[t][qu] + cl * FU_XS;
                     if (__all(plain_turn && (!filt || left >= 8u))) {
                         if (filt) {
-#if !defined(DVDA_EXP_NOFIR)        // (timing only: what the recursion itself costs the filter wave)
                             fir_step8(h, c, shift, qmask, xa, xb);
-#endif
                             left -= 8u;
                         }
-#if !defined(DVDA_EXP_NOTILE)        // (timing only: the filter wave's results never reach the exchange tile)
                         reinterpret_cast<int4 *>(X + p * 8)[0] = xa;
                         reinterpret_cast<int4 *>(X + p * 8)[1] = xb;
-#else
-                        asm volatile("" ::"v"(xa.x), "v"(xb.x), "v"(X));
-#endif
                     } else if (qu < cnt) {
                         filter_unit(xa, xb);
                         reinterpret_cast<int4 *>(X + p * 8)[0] = xa;

@@ -38,6 +38,13 @@
 // case is detected (DVDA_ST_MIDFRAME) and decoded frame-buffered by the general pass.
 #pragma once
 #include <hip/hip_runtime.h>
+// gfx950 only.  The row loop places s_waitcnt immediates by hand (0x0F70 = vmcnt(0) alone in the gfx9 encoding: vmcnt in
+// bits [3:0] and [15:14]) and gfx950 instructions as inline asm (v_pk_mov_b32, ds_read2st64_b32, global_store ... sc1):
+// on another target the same immediate means something else.  tools/hazard_check.py (run by tests/test_cabi.py on
+// every build) checks the asm contracts on the emitted ISA.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mlp_decode.h is written for gfx950 (MI355X): hand-placed s_waitcnt encodings and gfx950 inline asm"
+#endif
 #include <stdint.h>
 #include <type_traits>
 #include "mlp_bounds.h"
@@ -66,91 +73,8 @@ constexpr int OUT_ROWS = 4;                     // PCM frames staged per channel
 // still within its first two access units: the chain passes run anyway, and a wave kept alive by a few lanes holds
 // the whole fast pass (and everything that waits for it) for the time one segment takes, 2.6 ms.
 constexpr uint32_t YIELD_LONELY = 48;
-// header gate of the one-lane kernels (see the header phase of k_decode)
-#ifndef DVDA_HDR_GATE
-#define DVDA_HDR_GATE 1
-#endif
-// the filter's coefficients one per register instead of int16 pairs (saves eight unpacks per sample, costs 24 registers
-// in the six-channel instance)
-#ifndef DVDA_CF_UNPACKED
-#define DVDA_CF_UNPACKED 1
-#endif
-// Round 5: the wave stores its PCM together (frame-major int32, all 64 lanes flushing in the same turn: what lane
-// packing makes of a batch): ten whole 96-byte runs side by side per store instruction, written through (sc1).
-// Counter traffic of the bench batch 8.73 -> 6.38 GB per launch (reads 1.75 -> 1.07 x the input: the output's dirty
-// lines no longer push the input's out of L2; writes 1.27 -> 1.04 x), k_decode 3.41 -> 3.35 ms at two waves per SIMD;
-// at one wave per SIMD the extra instructions cost 7 %, so a batch of fewer than DecodeArgs::coop_min_seg segments
-// keeps the per-lane flush.  0: never.
-#ifndef DVDA_COOP_OUT
-#define DVDA_COOP_OUT 1
-#endif
-// (its seven store instructions unrolled: 3.32 ms against 3.33 with two copies and 3.44 as a loop, one box; the unrolled
-//  form makes the compiler spill 47 registers of cold state in this instance -- 23 as a loop; none of them in the row path)
-#ifndef DVDA_COOP_UNROLL
-#define DVDA_COOP_UNROLL 7
-#endif
-// 1: the packed WAV payload has the frame-major instance k_decode<.., WAVO> to itself (the host launches it for those
-// layouts): sharing one with the cooperative flush cost the payload's flush 3 % (3.51 -> 3.62 ms)
-#ifndef DVDA_WAV_INSTANCE
-#define DVDA_WAV_INSTANCE 1
-#endif
-// ---- round-5 experiments kept behind macros (tools/ab_build.py builds the variants; DESIGN.md A.5 has what each measured)
-// the synchronous ring fill as a call (rounds 1-4) or inlined where it is used (round 5: a call in the row loop's cold
-// branch made the register allocator keep the loop's state clear of the caller-saved registers by copying it -- sixty
-// moves per PCM frame on the hot path)
-#ifndef DVDA_FILL_CALL
-#define DVDA_FILL_CALL 0
-#endif
-#if DVDA_FILL_CALL
-#define DVDA_FILL_INLINE __attribute__((noinline))
-#else
-#define DVDA_FILL_INLINE __forceinline__
-#endif
-// the next row's first window asked for at the end of a row (measured, round 5: slower everywhere -- 2.59 against 2.44 ms on
-// the two-channel batch, 3.72 against 3.69 on the headline: three more registers through the whole loop cost more than
-// the one LDS round trip per row they hide)
-#ifndef DVDA_CARRY_WINDOW
-#define DVDA_CARRY_WINDOW 0
-#endif
-// cache policy of the row loop's prefetch loads: 0 default, 1 nontemporal (nt), 2 sc1 (both slower: three of a chunk's
-// four loads hit the line the first one brought into L1)
-#ifndef DVDA_PF_POLICY
-#define DVDA_PF_POLICY 0
-#endif
-// 1: the wave prefetches together -- the lanes that need a chunk publish (chunk, lane) in LDS, and every four lanes
-// fetch one request's 64 bytes as four adjacent 16-byte pieces (one load instruction serves 16 chunks, each a whole
-// 64-byte segment, instead of four instructions that each touch 64 different lines).  Parity-green, no faster.
-#ifndef DVDA_COOP_PF
-#define DVDA_COOP_PF 0
-#endif
-#ifndef DVDA_COOP_PF_GROUPS
-#define DVDA_COOP_PF_GROUPS 3
-#endif
-// the two register-resident matrices one coefficient per register (frame-major one-lane instance only)
-#ifndef DVDA_MAT_UNPACKED
-#define DVDA_MAT_UNPACKED 1
-#endif
-// the slot loop: 1 = one version, slots under the execution mask of the lanes that carry them; 0 = three versions
-// (all lanes NS slots / all lanes two / lanes that disagree: selects), picked per row
-#ifndef DVDA_SLOT_MODE
-#define DVDA_SLOT_MODE 1
-#endif
-// (of the three versions: the all-lanes-two one)
-#ifndef DVDA_UNI2
-#define DVDA_UNI2 1
-#endif
-// the next symbol's window read issued as soon as this symbol's length is known
-#ifndef DVDA_EARLY_WINDOW
-#define DVDA_EARLY_WINDOW 1
-#endif
-// the one-shape instance of the fast pass (k_decode<.., FIX>)
-#ifndef DVDA_FIX_INSTANCE
-#define DVDA_FIX_INSTANCE 0
-#endif
-// ensure(n) wave-wide: if any lane is short of n resident dwords, the lanes at most a chunk ahead refill together
-#ifndef DVDA_WAVE_ENSURE
-#define DVDA_WAVE_ENSURE 1
-#endif
+// Header gate of the one-lane kernels (see the header phase of k_decode): headers are parsed in company -- when every
+// active lane of the wave waits for one, when HDR_GATE_LANES of them do, or on every HDR_GATE_TURNS-th turn.
 // (round 4, tools/probe/sub_ab.sh: 4 turns / 16 lanes -> 32 / 32: fuzz_fast_features 26.0 -> 33.2 Gsamples/s,
 //  fuzz_all_features 10.3 -> 12.5, the header phase's share of a wave's time 62 -> 38 %; the headline -- lanes in
 //  lockstep, the phase runs when all of them wait -- and the heterogeneous batches do not move)
@@ -160,6 +84,10 @@ constexpr uint32_t YIELD_LONELY = 48;
 #ifndef DVDA_HDR_GATE_LANES
 #define DVDA_HDR_GATE_LANES 32
 #endif
+// What rounds 1-5 measured and dropped in this kernel (the filter's coefficients as int16 pairs, three versions of
+// the slot loop, a one-shape instance, the ring fill as a call, a window carried from row to row, cache policies of
+// the prefetch loads, a wave-cooperative prefetch, the cooperative flush as a loop) is in DESIGN.md's appendix
+// (docs/history.md) with its figures; the shipped path is what this file holds.
 constexpr uint32_t HDR_GATE_TURNS = DVDA_HDR_GATE_TURNS, HDR_GATE_LANES = DVDA_HDR_GATE_LANES;
 // The row-loop experiments of rounds 1 and 2 that lost (ring holding byte-swapped dwords, slot tests on a scalar
 // count, the second window step without its branch, split FIR accumulators, uniform slots, line-aware prefetch,
@@ -200,46 +128,32 @@ constexpr uint32_t HDR_GATE_TURNS = DVDA_HDR_GATE_TURNS, HDR_GATE_LANES = DVDA_H
 // store with the unaligned fall-back path next to it into a 12-byte plus a 4-byte store per lane,
 // which doubles the store instructions and splits every half-sector write in two.
 typedef int dvda_v4i __attribute__((ext_vector_type(4)));
-// cache policy of the PCM stores (a string behind the instruction: "" default, " nt", " sc1", " sc0 sc1" ...)
-#ifndef DVDA_STORE_POLICY
-#define DVDA_STORE_POLICY ""
-#endif
 #define DVDA_STORE_V4(dst, a_, b_, c_, d_)                                                          \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_POLICY ::"v"(dst), "v"(v4_) : "memory");           \
+        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v4_) : "memory");           \
     } while (0)
-// the wave's cooperative flush (whole runs side by side in one instruction): its own cache policy -- written through,
-// the runs leave as whole 32- and 64-byte pieces and do not push the input's lines out of L2 (round 5, DESIGN A.5)
-#ifndef DVDA_COOP_STORE_POLICY
-#define DVDA_COOP_STORE_POLICY " sc1"
-#endif
+// the wave's cooperative flush (whole runs side by side in one instruction): written through (sc1) -- the runs
+// leave as whole 32- and 64-byte pieces and do not push the input's lines out of L2 (round 5, docs/history.md A.5) --
+// and followed by the two wait states a store of more than 64 bits needs before its data registers may be written
 #define DVDA_STORE_V4_COOP(dst, a_, b_, c_, d_)                                                     \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_COOP_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
     } while (0)
-// ... followed by the two wait states a store of more than 64 bits needs before its data registers may be written
+// default policy, followed by the same two wait states
 #define DVDA_STORE_V4_PAD(dst, a_, b_, c_, d_)                                                      \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off" DVDA_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v4_) : "memory"); \
     } while (0)
 // the same at a constant byte offset from one base address
-#if defined(DVDA_EXP_NOSTORE)      // (diagnostic: what the PCM stores cost -- the data is computed and read from the tile, not written)
 #define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
     do {                                                                                            \
         dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("" ::"v"(dst), "v"(v4_) : "memory");                                           \
-    } while (0)
-#else
-#define DVDA_STORE_V4_AT(dst, off_, a_, b_, c_, d_)                                                 \
-    do {                                                                                            \
-        dvda_v4i v4_ = {(a_), (b_), (c_), (d_)};                                                    \
-        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" DVDA_STORE_POLICY                 \
+        asm volatile("global_store_dwordx4 %0, %1, off offset:%2"                                   \
                      ::"v"(dst), "v"(v4_), "n"(off_) : "memory");                                   \
     } while (0)
-#endif
 
 // (8-byte store at a constant byte offset: the tail of a 72-byte run of packed 24-bit samples)
 typedef int dvda_v2i __attribute__((ext_vector_type(2)));
@@ -467,7 +381,7 @@ __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, cons
 // Synchronous fill of one 64-byte chunk into a lane's ring slots (used after
 // seeks and inside long headers; the row loop prefetches instead).
 // dst: this lane's 16-byte slot in the chunk's first plane; planes are 64 slots apart.
-__device__ DVDA_FILL_INLINE void ring_fill_sync(const uint4 *src, uint32_t *dst, bool first_plane)
+__device__ __forceinline__ void ring_fill_sync(const uint4 *src, uint32_t *dst, bool first_plane)
 {
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     ring_store16(dst, a, b, c, d, first_plane);
@@ -552,15 +466,10 @@ struct BitReader {
     //  per read_signed" in round 4's stamps.  Filled together the lanes stay together: three or four.)
     __device__ __forceinline__ void ensure(uint32_t n)
     {
-#if DVDA_WAVE_ENSURE
         while (__builtin_expect(__any(ahead() < (int32_t)n), 0)) {
             if (ahead() <= (int32_t)(RING_DWORDS - CHUNK_DWORDS))
                 fill_sync();
         }
-#else
-        while (__builtin_expect(ahead() < (int32_t)n, 0))
-            fill_sync();
-#endif
     }
     // repositions the reader
     __device__ __forceinline__ void seek_byte(uint64_t byte_pos)
@@ -664,19 +573,13 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
 // (src/dvd-audio.c:781-792) -- instead of planar pcm[off + wave_channel * stride + frame], the order
 // decode_packet appends to `samples` (src/mlp.c:527-533).  A lane's flush is then ONE contiguous
 // run of 16 * channels bytes (whole 32-byte sectors) instead of six 16-byte pieces in six places.
-// FIX (fast pass, one lane per segment; round 5): the instance for batches of ONE stream shape whose streams carry NS
-// channels in one substream -- what the headline batch is, and any batch of titles of one kind.  Its row loop has the
-// one slot count and nothing else: no second and third version of the slot loop for lanes that disagree, none of the
-// register copies the compiler puts where those versions meet.  A lane that finds another count in a restart header
-// hands its segment to the chain passes (ST_COLD), as a lane of the two-wave kernel with too many channels does.  The
-// host launches both instances; the lanes of the one that is not meant leave at once.
 // WAVO (round 5): the frame-major instance for the packed WAV payload only (DVDA_PCM_WAV24 / WAV16) -- without the int32
 // flushes, the cooperative one among them, whose registers cost the payload's flush 3 % when they shared an instance.
-template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false, bool FIX = false, bool WAVO = false>
+template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false, bool DUO = false, bool WAVO = false>
 __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     static_assert(!(GENERAL && PARSE), "one mode at a time");
-    static_assert(!FIX || (!PAIRED && !GENERAL && !PARSE), "the one-shape instance is a fast-pass instance");
+    static_assert(!DUO, "not built yet");
     static_assert(!GENERAL || PAIRED, "the sequential pass always runs as lane pairs");
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     // fast pass: the batch holds no stream of this kernel's class (set by the index): whole grid exits
@@ -714,9 +617,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     //  the staging column of the lane that flushes it -- 4 KB less, four workgroups per CU instead of three)
     constexpr bool XCH = SIDE && !PARSE;
     __shared__ int32_t s_xch[XCH ? WAVES : 1][MAXCH][XCH ? 64 : 1];
-#if DVDA_COOP_PF
-    __shared__ uint2 s_req[WAVES][64];              // cooperative prefetch: (chunk's dword index, lane | ring half << 6)
-#endif
     __shared__ uint32_t s_alive[2][WAVES];
     __shared__ uint32_t s_nchained[WAVES];          // fast pass: lanes of the wave that stopped on ST_CHAINED (or, two-wave
                                                     // layout, whose other substream's lane did)
@@ -744,14 +644,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // two-substream ones -- so the even waves never rematrix, stage or store PCM
     const uint32_t ws_grp = (uint32_t)wv >> 1;
     const uint32_t ws_last = (uint32_t)wv & 1u;
-    // (diagnostic, DVDA_EXP_WG_ORDER = k: workgroup p of the grid takes the lanes of workgroup (p mod k) * (G / k) + p / k --
-    //  k consecutive workgroups are one from each k-th of the lane order, which is by segment length)
-#if defined(DVDA_EXP_WG_ORDER)
-    const uint32_t wg_k = (!GENERAL && !PARSE && gridDim.x % DVDA_EXP_WG_ORDER == 0u) ? (uint32_t)DVDA_EXP_WG_ORDER : 1u;
-    const uint32_t wg_id = (blockIdx.x % wg_k) * (gridDim.x / wg_k) + blockIdx.x / wg_k;
-#else
     const uint32_t wg_id = blockIdx.x;
-#endif
     const uint32_t gl0 = wg_id * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
     if (n_seg > a.max_seg)
@@ -821,13 +714,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     if (active && (sub >= S || sr.nframes == 0))
         active = false;
     bool mine = GENERAL || !a.only_S || S == a.only_S;          // else: the other kernel's stream, hands off
-    if (!PAIRED && !GENERAL && !PARSE && DVDA_FIX_INSTANCE) {
-        // one stream shape in the batch (k_link looked) and it is this instance's: the one-shape instance's lane, else
-        // the general instance's
-        const bool one_shape = *a.hetero == 0u && S == 1u && nch_out == (uint32_t)NS && a.only_S == 1u;
-        if (one_shape != FIX)
-            mine = false;
-    }
     if (!mine)
         active = false;
     if (active && S > L) {
@@ -963,7 +849,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // unpacked eight int16 halves per sample); the chain parse pass only hands them on and keeps them packed
     // (with three versions of the slot loop the six-slot instance had no registers for them -- 3.64 -> 4.25 ms with the
     //  spills -- ; with the one masked version it runs in 215 registers and has: 3.65 -> 3.56 ms)
-    constexpr bool CFU = (DVDA_CF_UNPACKED || NS <= 4) && !PARSE && !GENERAL;     // (the sequential pass has no registers to spare)
+    constexpr bool CFU = !PARSE && !GENERAL;     // (the sequential pass has no registers to spare)
     constexpr int CFW = CFU ? 8 : 4;
     int32_t cf[NS][CFW];
     uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
@@ -977,7 +863,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // another lane or to a record keep the packed form: they have no registers to spare, or are not bound by this)
     // (frame-major instance only: 3.54 -> 3.41 ms on the headline batch; the planar instance ran its two-channel batch
     //  3.6 % slower with them, 2.40 -> 2.49 ms, at the same 256 registers -- measured, not understood)
-    constexpr bool MU = DVDA_MAT_UNPACKED && ILV && !PAIRED && !GENERAL && !PARSE;
+    constexpr bool MU = ILV && !PAIRED && !GENERAL && !PARSE;
     int32_t mu[2][MU ? 8 : 1];
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -1017,7 +903,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t par_phase = 0;               // ... and the phase + 1 the last one was written in
     uint32_t it = 0;                      // two-wave layout: loop turn (wave-uniform); phase = it / OUT_ROWS
     uint32_t gate_turn = 0;               // loop turn for the header gate (wave-uniform)
-    constexpr bool HDR_GATE = DVDA_HDR_GATE && !PAIRED && !GENERAL;
+    constexpr bool HDR_GATE = !PAIRED && !GENERAL;
     const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
     uint32_t nslots = 0;
     bool have_restart = false;
@@ -1037,8 +923,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     int32_t pq_s[OUT_ROWS] = {0, 0, 0, 0};   // chain parse pass (see TP): per staged row, noise seed (its 23 bits) | bypassed LSBs << 23
     uint32_t au_idx = 0;              // chain parse pass: PCM-yielding access units of the segment so far
     uint32_t drops_seen = 0;          // frames dropped so far (major sync with other stream parameters)
-    uint64_t carry_win = 0;           // the window asked for at the end of a row for the next row's first symbol ...
-    uint32_t carry_pos = 0xFFFFFFFFu; // ... and the reading position it belongs to
 
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
     //      ch[0..7] in MLP channel order, shifted in place
@@ -1363,8 +1247,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                             // history before it is decided there -- and the segment goes to the chain passes
                             if (NS < 6 && nslots > (uint32_t)NS)
                                 too_wide = true;
-                            if (FIX && nslots != (uint32_t)NS)
-                                too_wide = true;            // (not the count this instance's row loop is made for)
                             have_restart = true;
                         }
                         if (blocks_in_frame)
@@ -1839,71 +1721,21 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // changes (a loop in the cold branch, one more CRC table) and went right again, each time, as soon as
         // these registers were defined.  The empty asm defines them -- some value, no instruction, nothing to
         // wait for -- which is all the code ever needed.
-#if !DVDA_COOP_PF
         uint4 p0, p1, p2, p3;
         asm volatile("" : "=v"(p0.x), "=v"(p0.y), "=v"(p0.z), "=v"(p0.w), "=v"(p1.x), "=v"(p1.y), "=v"(p1.z), "=v"(p1.w),
                           "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
-#endif
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
         const uint32_t frames_before = frames_done;      // (sequential pass: did this turn close an access unit?)
         uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
         uint64_t flush_row = 0;
-#if DVDA_COOP_PF
-        constexpr int PFG = DVDA_COOP_PF_GROUPS;
-        const uint64_t pf_mask = __ballot(pf);
-        const uint32_t pf_n = (uint32_t)__popcll(pf_mask);                    // (scalar)
-        const uint32_t pf_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pf_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pf_mask, 0u));
-        const bool pf_served = pf && pf_rank < 16u * PFG;                     // (the others ask again next row)
-        uint4 pq[PFG];
-        uint32_t pq_tag[PFG];
-        for (int g = 0; g < PFG; g++)
-            asm volatile("" : "=v"(pq[g].x), "=v"(pq[g].y), "=v"(pq[g].z), "=v"(pq[g].w), "=v"(pq_tag[g]));
-        if (pf_n) {
-            uint2 *const req = &s_req[wv][0];
-            if (pf_served) {
-                const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
-                req[pf_rank] = make_uint2(c, lane | ((rd.fillpos & (uint32_t)CHUNK_DWORDS) << 2));
-            }
-#pragma unroll
-            for (int g = 0; g < PFG; g++) {
-                if ((uint32_t)(16 * g) < pf_n) {                               // (scalar)
-                    const uint32_t r = (uint32_t)(16 * g) + (lane >> 2);
-                    if (r < pf_n) {
-                        const uint2 q = req[r];
-                        pq[g] = rd.gsrc[(q.x >> 2) + (lane & 3u)];
-                        pq_tag[g] = q.y;
-                    }
-                }
-            }
-        }
-#else
         if (pf) {
             const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
             const uint4 *src = rd.gsrc + (c >> 2);
-#if DVDA_PF_POLICY == 1
-            // (the stream's bytes pass once: nothing of them is asked for again through this CU's L1)
-            {
-                typedef unsigned dvda_v4u __attribute__((ext_vector_type(4)));
-                const dvda_v4u *nsrc = reinterpret_cast<const dvda_v4u *>(src);
-                const dvda_v4u n0v = __builtin_nontemporal_load(&nsrc[0]), n1v = __builtin_nontemporal_load(&nsrc[1]),
-                               n2v = __builtin_nontemporal_load(&nsrc[2]), n3v = __builtin_nontemporal_load(&nsrc[3]);
-                p0 = make_uint4(n0v.x, n0v.y, n0v.z, n0v.w);
-                p1 = make_uint4(n1v.x, n1v.y, n1v.z, n1v.w);
-                p2 = make_uint4(n2v.x, n2v.y, n2v.z, n2v.w);
-                p3 = make_uint4(n3v.x, n3v.y, n3v.z, n3v.w);
-            }
-#elif DVDA_PF_POLICY == 2
-            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
-                         : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(src) : "memory");
-#else
             p0 = src[0];
             p1 = src[1];
             p2 = src[2];
             p3 = src[3];
-#endif
         }
-#endif
         DVDA_STAMP(1);
 
         uint32_t bypass_bits = 0;
@@ -1916,25 +1748,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         const uint32_t xstride = (ILV && ilv_direct) ? 64u : (uint32_t)OUT_ROWS * 64u;       // channel to channel
         int32_t *const xrow = xtile + ((ILV && ilv_direct) ? xslot * (6u * 64u) : xslot * 64u);
         int32_t *const xw_mine = xrow + min_ch * xstride;
-        // UNI: every lane of the wave that decodes a row this turn carries the same number of channels, nu of them
-        // (all the lanes of a wave of one stream shape -- what lane packing makes of any batch): the slot loop then runs
-        // on a scalar count, and nothing in it is selected by "does this lane have the slot": a slot's parameters, its
-        // history (shifted by register pairs) and its value are the lane's own in every lane.  Otherwise slots beyond
-        // a lane's channel count read 0 bits and keep their state, select by select (rounds 1-4: always).
-        auto row_head = [&](auto uni_c) {
-            // (NU != 0: the wave's count, a compile-time constant -- straight-line code from the first slot to the last;
-            //  with a scalar count and a branch behind every slot the compiler moved the slot's whole history back into
-            //  other registers at every join)
-            constexpr int NU = decltype(uni_c)::value;
-            constexpr bool UNI = NU > 0;
-            // NU < 0 (round 5, what the library runs): ONE version of the slot loop for every wave.  A slot's body -- symbol,
-            // filter, history shift -- runs under the execution mask of the lanes that carry the slot (the compiler's
-            // s_and_saveexec around an `if`), so nothing in it selects lane by lane; a slot no lane carries is skipped.
-            // With one version there is no place where several versions' register assignments meet: the three-version
-            // form paid ~60 register copies per PCM frame for that (SQ_INSTS_VALU 673 per wave-row against 619 in an
-            // instance with one version only; tools/probe/r05_fixpmc.sh).
-            constexpr bool MSK = NU < 0;
-            constexpr bool NOSEL = UNI || MSK;
+        // ONE version of the slot loop for every wave (round 5).  A slot's body -- symbol, filter, history shift -- runs under
+        // the execution mask of the lanes that carry the slot (the compiler's s_and_saveexec around an `if`), so nothing in
+        // it selects lane by lane; a slot no lane carries is skipped.  (Rounds 1-4 ran every slot for every lane and
+        // selected field by field; three versions by wave -- all lanes six slots / all two / mixed -- paid ~60 register
+        // copies per PCM frame where the versions' register assignments met: docs/history.md A.5.)
+        // (called by the lanes that decode a row this turn)
+        auto row_head_any = [&]() {
             // ---- bypassed LSBs + residuals for one PCM frame (src/mlp.c:1194-1238)
             // all of the row's bypassed LSBs (at most one per matrix) are cut from the window at once
             // and dealt to their matrices in stream order -- straight-line, no per-bit read
@@ -1956,60 +1776,31 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                 }
             }
-            // the row's first window: the one the row before asked for when it was through with its last symbol, if the
-            // reading position is still the one it was asked for (a header parse or the row's bypassed LSBs moved it:
-            // then it is read here, and waited for -- which is what every row did before this: a fifth of a two-channel
-            // row's time, tools/shape_bench.py stereo)
-            uint64_t win = carry_win;
-            if (!DVDA_CARRY_WINDOW || __any(rd.pos != carry_pos))
-                win = rd.window();
+            // the row's first window (read here and waited for; a window carried over from the row before was measured
+            // and dropped: three more registers through the whole loop cost more than the one LDS round trip they hide)
+            uint64_t win = rd.window();
             uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
             // IIR taps anywhere in the wave (sequential pass only: in the fast pass such a segment is ST_COLD)
             const bool wave_iir = GENERAL && __any(iir_any != 0);
 #pragma unroll
             for (int k = 0; k < NS; k++) {
-                // branch-free symbol decode: slots beyond the lane's channel count read 0 bits;
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
-                const bool in = UNI || (uint32_t)k < nslots;
-                uint64_t m_in = 0;
-                if constexpr (MSK) {
-                    // (the window the slot before asked for -- by hand, below -- is waited for HERE, whoever goes on:
-                    //  its registers must not be handed to anything else with the read still on its way)
-                    if (DVDA_EARLY_WINDOW && k > 0)
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win));
-                    if constexpr (!WSPEC)
-                        val[k] = 0;
-                    if (k >= 2 && !__any(in))
-                        continue;
-                } else if constexpr (UNI) {
-                    if (k >= NU) {
-                        if constexpr (!WSPEC)
-                            val[k] = 0;
-                        continue;
-                    }
-                } else {
-                    if (k >= 2 && !__any(in)) {
-                        if constexpr (!WSPEC)
-                            val[k] = 0;
-                        continue;
-                    }
-                    // (the selects below take this mask from an SGPR pair, as inline asm: left to the compiler they become
-                    //  runs of v_cndmask_b32_e32 on vcc, which issue at a tenth of the rate -- profiles/r05_valu_issue_rates.txt;
-                    //  the mask is made here, a slot's length ahead of its first use: tools/hazard_check.py)
-                    m_in = __builtin_amdgcn_ballot_w64(in);
-                    asm volatile("" : "+s"(m_in));
-                }
-                if (!MSK || in) {
-                const uint32_t pkk = NOSEL ? pk[k] : (in ? pk[k] : 0u);
+                const bool in = (uint32_t)k < nslots;
+                // (the window the slot before asked for -- by hand, below -- is waited for HERE, whoever goes on:
+                //  its registers must not be handed to anything else with the read still on its way)
+                if (k > 0)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win));
+                if constexpr (!WSPEC)
+                    val[k] = 0;
+                if (k >= 2 && !__any(in))
+                    continue;
+                if (in) {
+                const uint32_t pkk = pk[k];
                 const uint32_t cb = pkk & 3u, lb = (pkk >> 2) & 31u, q = (pkk >> 7) & 15u,
                                shift = (pkk >> 11) & 15u;
                 const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
                 // the symbol is cut from the 64 bits at the reading position (a code of at most 9 bits and at most 24
                 // LSBs behind an offset of at most 31)
-                if constexpr (UNI && DVDA_EARLY_WINDOW) {
-                    if (k > 0)
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win));      // (the read placed by hand in the slot before)
-                }
                 const uint32_t ofs = rd.pos & 31u;
                 const uint32_t top = (uint32_t)((win << ofs) >> 32);
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);      // bit 8 of the 9-bit peek
@@ -2021,10 +1812,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 const uint32_t o2 = ofs + len;
                 rd.pos += len + lb;
                 // ... and the next symbol's window is asked for at once: the read is in flight while this symbol's
-                // LSBs are cut and its value goes through the filter.  With the lanes' slot count a compile-time constant
-                // the read is placed by hand, as early as the position is known -- left to the compiler it sank into the
-                // filter's multiply-adds, a dozen instructions in front of its use, and a lone wave waited 140 cycles per
-                // symbol for LDS (tools/stamp_run.py) -- and waited for by hand at the next slot's top (the compiler does
+                // LSBs are cut and its value goes through the filter.  The read is placed by hand, as early as the
+                // position is known -- left to the compiler it sank into the filter's multiply-adds, a dozen
+                // instructions in front of its use, and a lone wave waited 140 cycles per symbol for LDS
+                // (tools/stamp_run.py) -- and waited for by hand at the next slot's top (the compiler does
                 // not count an asm's LDS read: its own waits can only come out longer; tools/hazard_check.py checks that
                 // nothing touches the pair in between).  The last slot asks for nothing.
                 // (the LSBs are cut first: the read below lands in the window's own registers.  A second pair for it had
@@ -2033,14 +1824,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 //  arrived.  tests/test_gpu_parity.py::test_fuzz_fast_features found it.)
                 const uint32_t top2 = (uint32_t)((win << o2) >> 32);
                 const uint32_t lsbv = (top2 >> 1) >> (31u - lb);          // lb == 0 -> 0
-                if constexpr (NOSEL && DVDA_EARLY_WINDOW) {
-                    if (k + 1 < (MSK ? NS : NU))
-                        // (the slot's newest history pair rides through the asm: the filter below starts from it, so the
-                        //  scheduler cannot put the multiply-adds in front of the read)
-                        asm volatile("ds_read2st64_b32 %0, %2 offset1:1" : "+v"(win), "+v"(sp[k][0]) : "v"(rd.window_lds()));
-                } else {
-                    win = rd.window();                            // (the last slot's read serves nobody: dropped by the compiler)
-                }
+                if (k + 1 < NS)
+                    // (the slot's newest history pair rides through the asm: the filter below starts from it, so the
+                    //  scheduler cannot put the multiply-adds in front of the read)
+                    asm volatile("ds_read2st64_b32 %0, %2 offset1:1" : "+v"(win), "+v"(sp[k][0]) : "v"(rd.window_lds()));
                 const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
                 int32_t value;
                 if constexpr (PARSE) {
@@ -2082,7 +1869,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 //  lanes without the slot need it, the pairs were taken apart and rebuilt: either way the compiler moved
                 //  every slot's whole history back to where the loop keeps it, sixty moves per PCM frame.  The lanes that
                 //  do not carry the slot are masked out of the same four instructions instead.)
-                if (NOSEL || in) {
+                {
                     const uint64_t vpair = (uint64_t)(uint32_t)value;
                     asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][3]) : "v"(sp[k][2]));
                     asm("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]" : "+v"(sp[k][2]) : "v"(sp[k][1]));
@@ -2096,10 +1883,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 }
                 if constexpr (WSPEC) {
-                    if (in)
-                        xw_mine[k * xstride] = value;     // straight into the tile
+                    xw_mine[k * xstride] = value;     // straight into the tile
                 } else {
-                    val[k] = NOSEL ? value : (in ? value : 0);
+                    val[k] = value;
                 }
                 }       // (the lanes that carry the slot)
             }
@@ -2107,31 +1893,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 status |= ST_HUFFMAN;
                 active = false;
             }
-            if (DVDA_CARRY_WINDOW) {
-                // the next row's first window, in flight through the rematrix, the ring commit and the stores
-                carry_win = rd.window();
-                carry_pos = rd.pos;
-            }
             DVDA_STAMP(2);
-        };
-        // (called by the lanes that decode a row this turn)
-        auto row_head_any = [&]() {
-            if constexpr (FIX) {
-                row_head(std::integral_constant<int, NS>{});
-                return;
-            }
-            if constexpr (DVDA_SLOT_MODE == 1) {
-                row_head(std::integral_constant<int, -1>{});
-                return;
-            }
-            const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)nslots);
-            const bool uni = __all(nslots == nu);
-            if (uni && nu == (uint32_t)NS)
-                row_head(std::integral_constant<int, NS>{});
-            else if (DVDA_UNI2 && NS > 2 && uni && nu == 2u)
-                row_head(std::integral_constant<int, (NS > 2 ? 2 : 0)>{});
-            else
-                row_head(std::integral_constant<int, 0>{});
         };
         auto row_tail = [&](int32_t (&ch)[MAXCH]) {
             if (owner && (!adopt || active)) {
@@ -2423,36 +2185,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //  but for the PCM stores issued a few instructions earlier, a store's whole round trip every flush: 12 % of
         //  a wave's time, tools/stamp_run.py.  vmcnt(0), lgkmcnt / expcnt not waited for: 0x0F70)
         __builtin_amdgcn_s_waitcnt(0x0F70);
-#if DVDA_COOP_PF
-        if (pf_n) {
-            uint32_t *const ring_wave = rd.ring - lane;
-#pragma unroll
-            for (int g = 0; g < PFG; g++) {
-                if ((uint32_t)(16 * g) < pf_n) {
-                    const uint32_t r = (uint32_t)(16 * g) + (lane >> 2);
-                    if (r < pf_n) {
-                        // piece j of the chunk: ring dwords half * 16 + 4 j .. + 3, planes falling from 32 - that
-                        const uint32_t d0 = ((pq_tag[g] >> 2) & 16u) + ((lane & 3u) << 2);
-                        uint32_t *const dst = ring_wave + (pq_tag[g] & 63u) + ((uint32_t)RING_DWORDS - d0) * 64u;
-                        const uint32_t a0 = be32(pq[g].x);
-                        dst[0] = a0;
-                        dst[-64] = be32(pq[g].y);
-                        dst[-128] = be32(pq[g].z);
-                        dst[-192] = be32(pq[g].w);
-                        if (d0 == 0)
-                            dst[-RING_DWORDS * 64] = a0;
-                    }
-                }
-            }
-            if (pf_served)
-                rd.filled();
-        }
-#else
         if (pf) {
             ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3, (rd.fillpos & (RING_DWORDS - 1)) == 0);
             rd.filled();
         }
-#endif
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
         //      older memory operation, so stores issued before it would be waited for as well; issued
         //      here they have a whole row to drain before the next wait
@@ -2468,7 +2204,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // (not in the two-wave kernel: there the wave that flushes is the one that sets the pace, and the flush's extra
         //  instructions cost it 7 %)
         if constexpr (ILV && !GENERAL && !PARSE && !WSPEC) {
-            if (DVDA_COOP_OUT && !WAVO && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
+            if (!WAVO && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
                 coop_out = __ballot(flush) == ~0ull;
         }
         if (coop_out) {
@@ -2485,7 +2221,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             const uint32_t pc = (uint32_t)lane - l6 * 6u;
             const int32_t *const Tl6 = T0 + pc * (4 * 64) + l6;             // (the tile in output order: value v of a run in plane v)
             const bool l60 = lane < 60;
-#pragma unroll DVDA_COOP_UNROLL
+#pragma unroll
             for (uint32_t it7 = 0; it7 < 7u; it7++) {
                 const uint32_t o = l6 + 10u * it7;                           // whose run
                 const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64);
@@ -2505,7 +2241,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
             // (the one-lane int32 frame-major instance has handed the payload to its WAVO twin; every other instance
             //  -- two-wave, sequential -- still writes it itself)
-            constexpr bool WAV_ELSEWHERE = DVDA_WAV_INSTANCE && !PAIRED && !FIX && !WAVO;
+            constexpr bool WAV_ELSEWHERE = !PAIRED && !WAVO;
             if (WAVO || (!WAV_ELSEWHERE && __builtin_expect(a.wav_bits != 0, 0))) {
                 // ---- the WAV payload itself (SURVEY 8(f-3) fused into the decode): the OUT_ROWS frames are
                 //      OUT_ROWS * channels consecutive samples = `channels` groups of four; a group packs into

@@ -848,21 +848,12 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     }
     if (run1) {
         a.only_S = force ? 0u : 1u;
-        if (a.interleaved && a.wav_bits && DVDA_WAV_INSTANCE)
+        if (a.interleaved && a.wav_bits)
             hipLaunchKernelGGL((k_decode<6, false, false, true, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
         else if (a.interleaved)
             hipLaunchKernelGGL((k_decode<6, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
         else
             hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
-#if DVDA_FIX_INSTANCE
-        // ... and the instance for a batch of one six-channel shape (the lanes of whichever is not meant leave at once)
-        if (!force) {
-            if (a.interleaved)
-                hipLaunchKernelGGL((k_decode<6, false, false, true, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
-            else
-                hipLaunchKernelGGL((k_decode<6, false, false, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
-        }
-#endif
     }
     if (run2) {
         a.only_S = force ? 0u : 2u;
