@@ -256,7 +256,10 @@ class Batch:
             # slot's INDEX -- bound by HBM -- with that decode -- bound by instruction issue
             # (a small batch -- one the cooperative kernel decodes, a few workgroups per compute unit -- leaves most
             #  of the device idle: there the slots' decodes run side by side as well)
-            if self._turn > 1 and not self.small:
+            # (diagnostic, DVDA_BENCH_FREE_OVERLAP=1: no such edge -- the slots' decodes are left to the hardware's own
+            #  scheduling, which is how the parse pass of one batch and the fused chain pass of another were measured
+            #  side by side in round 6; tools/probe/r06_overlap.sh)
+            if self._turn > 1 and not self.small and os.environ.get("DVDA_BENCH_FREE_OVERLAP", "0") != "1":
                 self._tstreams[k].wait_event(self._done[(k - 1) % self.depth])
             ctx.decode_async(self.d_pcms[k].data_ptr(), self.d_out_off.data_ptr(), self.d_stride.data_ptr(), st)
             self._done[k].record(self._tstreams[k])

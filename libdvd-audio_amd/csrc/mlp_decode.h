@@ -362,6 +362,7 @@ __device__ __forceinline__ int32_t huff_center(uint32_t codebook, uint32_t lb)
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
 // (round 5: the ring holds the stream's dwords in big-endian value order -- swapped here, once per dword, instead of
 //  by every reader: the row loop cuts each symbol from a 64-bit window it reads from the ring, two dwords per symbol)
+template <int RD = RING_DWORDS>
 __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, const uint4 &b, const uint4 &c,
                                              const uint4 &d, bool first_plane)
 {
@@ -370,11 +371,24 @@ __device__ __forceinline__ void ring_store16(uint32_t *dst, const uint4 &a, cons
     const uint32_t a0 = be32(a.x);
     uint32_t *const e = dst - 15 * 64;                  // the chunk's last dword
     if (first_plane)
-        dst[-RING_DWORDS * 64] = a0;                    // plane 32 -> its mirror, plane 0
+        dst[-RD * 64] = a0;                             // plane RD -> its mirror, plane 0
     e[15 * 64] = a0;         e[14 * 64] = be32(a.y); e[13 * 64] = be32(a.z); e[12 * 64] = be32(a.w);
     e[11 * 64] = be32(b.x);  e[10 * 64] = be32(b.y); e[9 * 64] = be32(b.z);  e[8 * 64] = be32(b.w);
     e[7 * 64] = be32(c.x);   e[6 * 64] = be32(c.y);  e[5 * 64] = be32(c.z);  e[4 * 64] = be32(c.w);
     e[3 * 64] = be32(d.x);   e[2 * 64] = be32(d.y);  e[1 * 64] = be32(d.z);  e[0 * 64] = be32(d.w);
+}
+
+// a 16-byte granule (four dwords, 4-dword aligned) the same way: the small rings of the two-substream lane
+template <int RD>
+__device__ __forceinline__ void ring_store4(uint32_t *dst, const uint4 &a, bool first_plane)
+{
+    const uint32_t a0 = be32(a.x);
+    if (first_plane)
+        dst[-RD * 64] = a0;
+    dst[0] = a0;
+    dst[-1 * 64] = be32(a.y);
+    dst[-2 * 64] = be32(a.z);
+    dst[-3 * 64] = be32(a.w);
 }
 
 // ---------------------------------------------------------------- cold helpers
@@ -416,29 +430,33 @@ __device__ __attribute__((noinline)) void iir_push(int32_t *ws, uint32_t stride,
 // in flight while this symbol's value goes through the filter.  Absolute 64-bit positions are rebuilt by the cold
 // code from a nearby reference (tell_near); dword indices are 32-bit: a batch buffer is limited to 16 GiB
 // (checked by dvda_mlp_hip_index).
-struct BitReader {
+// RD: dwords the ring holds (a power of two; planes 1 .. RD and the mirror, plane 0); G: dwords a fill brings (16: a
+// 64-byte chunk, four loads -- the one-substream kernels; 4: one 16-byte load -- the two small rings of a lane that reads
+// both substreams of its segment, DUO)
+template <int RD, int G>
+struct BitReaderT {
     const uint4 *gsrc;      // global bytes as 16-byte units
     uint32_t *ring;         // this lane's column: wave ring + lane
     uint32_t max_chunk;     // last loadable chunk (dword index, multiple of 16)
     uint32_t pos;           // bit position of the next unread bit (absolute, modulo 2^32)
-    uint32_t fillpos;       // ring holds dwords [lo_valid, fillpos); fillpos is a multiple of 16
+    uint32_t fillpos;       // ring holds dwords [lo_valid, fillpos); fillpos is a multiple of G
     uint32_t lo_valid;
 
     __device__ __forceinline__ uint32_t *slot(uint32_t d) const
     {
-        return ring + ((RING_DWORDS - (d & (RING_DWORDS - 1))) << 6);
+        return ring + ((RD - (d & (RD - 1))) << 6);
     }
     // the stream's 64 bits from the dword of the next unread bit on (big-endian value order): dword d + 1 is one
     // plane below dword d (the mirror plane below dword 31's)
     __device__ __forceinline__ uint64_t window() const
     {
-        const uint32_t *p = ring + ((~(pos >> 5) & (RING_DWORDS - 1)) << 6);
+        const uint32_t *p = ring + ((~(pos >> 5) & (RD - 1)) << 6);
         return ((uint64_t)p[64] << 32) | p[0];
     }
     // LDS byte address of that window's low half (for the row loop's own read instruction)
     __device__ __forceinline__ uint32_t window_lds() const
     {
-        return (uint32_t)(uintptr_t)ring + ((~(pos >> 5) & (RING_DWORDS - 1)) << 8);
+        return (uint32_t)(uintptr_t)ring + ((~(pos >> 5) & (RD - 1)) << 8);
     }
     // dwords resident at / after the dword of the next unread bit
     __device__ __forceinline__ int32_t ahead() const
@@ -447,15 +465,51 @@ struct BitReader {
     }
     __device__ __forceinline__ void filled()
     {
-        fillpos += CHUNK_DWORDS;
-        if (fillpos - lo_valid > (uint32_t)RING_DWORDS)
-            lo_valid = fillpos - RING_DWORDS;                   // the oldest chunk was overwritten
+        fillpos += G;
+        if (fillpos - lo_valid > (uint32_t)RD)
+            lo_valid = fillpos - RD;                            // the oldest chunk was overwritten
     }
+    // where a fill's bytes come from: past the buffer's end, from its last granule (the spare bytes)
+    __device__ __forceinline__ uint32_t fill_src() const
+    {
+        const uint32_t last = max_chunk + (uint32_t)(CHUNK_DWORDS - G);
+        return fillpos < last ? fillpos : last;
+    }
+    __device__ __forceinline__ bool room() const { return ahead() <= (int32_t)(RD - G); }
     __device__ __forceinline__ void fill_sync()
     {
-        const uint32_t c = fillpos < max_chunk ? fillpos : max_chunk;
-        ring_fill_sync(gsrc + (c >> 2), slot(fillpos), (fillpos & (RING_DWORDS - 1)) == 0);
-        filled();
+        if constexpr (G == CHUNK_DWORDS) {
+            ring_fill_sync(gsrc + (fill_src() >> 2), slot(fillpos), (fillpos & (RD - 1)) == 0);
+            filled();
+        } else {
+            uint4 q[4];
+            const int32_t n = fill_issue(q);
+            fill_commit(q, n);
+        }
+    }
+    // small ring: everything there is room for at once -- after a seek that is the whole ring, one memory round trip
+    // instead of one per granule.  Issue and commit apart, so that a lane with two rings has both rings' loads in
+    // flight together.  -> granules asked for (0: no room)
+    __device__ __forceinline__ int32_t fill_issue(uint4 (&q)[4]) const
+    {
+        static_assert(G == CHUNK_DWORDS || (G == 4 && RD == 16), "the small ring is 16 dwords filled by 16-byte granules");
+        const int32_t n = room() ? (RD - ahead()) >> 2 : 0;     // 0 .. 4 granules
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if (g < n) {
+                const uint32_t f = fillpos + 4u * g, last = max_chunk + (uint32_t)(CHUNK_DWORDS - G);
+                q[g] = gsrc[(f < last ? f : last) >> 2];
+            }
+        return n;
+    }
+    __device__ __forceinline__ void fill_commit(const uint4 (&q)[4], int32_t n)
+    {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if (g < n) {
+                ring_store4<RD>(slot(fillpos), q[g], (fillpos & (RD - 1)) == 0);
+                filled();
+            }
     }
     // n <= 16 dwords resident from the dword of the next unread bit on (a fill overwrites the dwords 32 below its
     // own: with n <= 16 never one at or after the reading position)
@@ -467,7 +521,7 @@ struct BitReader {
     __device__ __forceinline__ void ensure(uint32_t n)
     {
         while (__builtin_expect(__any(ahead() < (int32_t)n), 0)) {
-            if (ahead() <= (int32_t)(RING_DWORDS - CHUNK_DWORDS))
+            if (room())
                 fill_sync();
         }
     }
@@ -476,7 +530,7 @@ struct BitReader {
     {
         const uint32_t t = (uint32_t)(byte_pos >> 2);
         if (!((int32_t)(t - lo_valid) >= 0 && (int32_t)(fillpos - t) > 0)) {
-            fillpos = t & ~(uint32_t)(CHUNK_DWORDS - 1);        // outside the ring: restart it
+            fillpos = t & ~(uint32_t)(G - 1);                   // outside the ring: restart it
             lo_valid = fillpos;
         }
         pos = (uint32_t)byte_pos << 3;
@@ -525,6 +579,11 @@ struct BitReader {
     }
 };
 
+using BitReader = BitReaderT<RING_DWORDS, CHUNK_DWORDS>;
+// the two-substream lane's rings: 16 dwords each, filled 16 bytes at a time (2 x 17 planes = 8.5 KB per wave where
+// the one 32-dword ring is 8.25)
+constexpr int DUO_RING = 16, DUO_GRAN = 4;
+
 // Arithmetic, branch-free decode of the three code books (mlp_tables.h: huff_entry) from a 9-bit
 // peek t: returns value | length << 8, value 0xFF for the two invalid codes of a book, and 0 (no
 // bits, value 0) for "book" 0 = no code.  Checked exhaustively against the table by
@@ -558,6 +617,15 @@ __device__ __forceinline__ uint32_t huff_decode(uint32_t cb, uint32_t t)
     return huff_decode_m(cb, t, m_esc, cb ? 0xFFFFFFFFu : 0u);
 }
 
+// DUO lanes: what the header parser and the block bookkeeping keep per substream, for the substream that is not the
+// lane's working one (k_decode: the working variables are substream 1's; these are substream 0's between its headers)
+struct SubPark {
+    uint32_t flags, block_size, min_ch, max_ch, max_mat_ch, noise_shift, seed, matrix_len, bypass_mask, outch_pack,
+             oshift_pack, qss_pack, nslots, iir_any, ss_end_bit, rows_left, blocks_in_frame, chk, gl, seg_lane;
+    bool have_restart, seg_iir;
+    uint32_t *brec, *brec_end, *brec_base;
+};
+
 // ----------------------------------------------------------------------------
 // GENERAL = false: the fast pass.  One lane per (segment, substream); conditions it cannot
 //   decode exactly are reported per segment (ST_DEFERRED) and the lane stops or goes on as noted.
@@ -579,7 +647,12 @@ template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = fals
 __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     static_assert(!(GENERAL && PARSE), "one mode at a time");
-    static_assert(!DUO, "not built yet");
+    // DUO (round 6): ONE lane decodes BOTH substreams of its segment, row by row -- the channels of substream 0, then the
+    // channels of substream 1, from two small rings -- and rematrixes with substream 1's parameters (src/mlp.c:540-582).
+    // The lane's working state is substream 1's (what the rematrix, the output and the records of the last substream
+    // use); substream 0's header / block state is parked (`P0`) and swapped in for its block headers.  Channel c of the
+    // segment lives in register slot c whichever substream carries it.
+    static_assert(!DUO || (!PAIRED && !GENERAL && NS == 6), "the two-substream lane is a one-lane fast-pass / parse instance");
     static_assert(!GENERAL || PAIRED, "the sequential pass always runs as lane pairs");
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     // fast pass: the batch holds no stream of this kernel's class (set by the index): whole grid exits
@@ -608,7 +681,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     constexpr int TP = 6;                                         // staged planes: the channels (the chain parse pass keeps
                                                                   // a row's bypassed LSBs and noise seed in registers: with two
                                                                   // more planes its workgroup was 34 KB of LDS and only three fit a CU)
-    __shared__ uint32_t s_ring[WAVES][RING_DWORDS + 1][64];     // + the mirror of plane 0
+    constexpr int RD = DUO ? DUO_RING : RING_DWORDS;            // dwords a ring holds
+    constexpr int RG = DUO ? DUO_GRAN : CHUNK_DWORDS;           // dwords a fill brings
+    using Reader = BitReaderT<RD, RG>;
+    __shared__ uint32_t s_ring[WAVES][DUO ? 2 : 1][RD + 1][64];     // + the mirror of plane 0 (DUO: a ring per substream)
     __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS * 2 : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
     // two-wave layout, per row of a tile: "the odd wave's channels are there" | version of the rematrix
     // parameters the row goes with << 8 | its bypassed LSBs
@@ -700,8 +776,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
     // substream handled by this lane; workspace lane = segment * 2 + substream in every layout and pass
     // (an even-wave lane of a single-substream stream is idle and names the stream's absent substream 1)
-    const uint32_t sub = WSPEC ? (ws_last == (S == 2 ? 1u : 0u) ? 1u : 0u) : gl0 - item * L;
-    const uint32_t gl = segi * 2u + sub;
+    // (DUO: the lane's working substream is the last one, 1; substream 0's state is parked)
+    const uint32_t sub = DUO ? 1u : WSPEC ? (ws_last == (S == 2 ? 1u : 0u) ? 1u : 0u) : gl0 - item * L;
+    uint32_t gl = segi * 2u + sub;          // (DUO: swapped with the parked substream's for its block headers)
     uint32_t seg_lane = gl;                 // lane index that owns segment `segi` in the workspaces
     const uint32_t assignment = (stream_sync >> 16) & 0x1F;
     const uint32_t rpa = rows_per_au((stream_sync >> 8) & 0xF);
@@ -716,10 +793,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     bool mine = GENERAL || !a.only_S || S == a.only_S;          // else: the other kernel's stream, hands off
     if (!mine)
         active = false;
-    if (active && S > L) {
+    if (active && S > (DUO ? 2u : L)) {
         status |= ST_ENVELOPE;                                  // 2-substream stream in a forced 1-lane launch
         active = false;
     }
+    if (DUO && S != 2u)
+        active = false;                                         // (the one-substream kernel's stream)
     if (active && (rpa == 0 || nch_out == 0)) {
         status |= ST_ENVELOPE;
         active = false;
@@ -821,9 +900,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     }
     const bool ilv_direct = ILV && !GENERAL && !PARSE && __all(dir_ok);
 
-    BitReader rd;
+    Reader rd;
     rd.gsrc = reinterpret_cast<const uint4 *>(a.bytes);
-    rd.ring = &s_ring[wv][0][lane];
+    rd.ring = &s_ring[wv][DUO ? 1 : 0][0][lane];
     rd.max_chunk = (uint32_t)(((a.total_bytes + 63) >> 6) << 4);  // the chunk holding the spare bytes
     rd.pos = 0;
     rd.fillpos = 0;
@@ -831,6 +910,35 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // parity / CRC-8 of the segment's substreams: checked byte-parallel by k_au_check (mlp_check.h) before this
     // kernel runs; what is left here is one compare per access unit -- the first unit that fails | which check
     uint32_t chk = active ? DVDA_AT(a.seg_check, (size_t)segi * 2u + sub, 2ull * a.caps.max_seg, BT_CHECK) : 0xFFFFFFFFu;
+    // DUO: substream 0's reader (its own ring) and its parked state
+    Reader rx;
+    rx.gsrc = rd.gsrc;
+    rx.ring = &s_ring[wv][0][0][lane];
+    rx.max_chunk = rd.max_chunk;
+    rx.pos = 0;
+    rx.fillpos = 0;
+    rx.lo_valid = 0;
+    SubPark P0;
+    P0.flags = 0xFF;
+    P0.block_size = 8;
+    P0.min_ch = P0.max_ch = P0.max_mat_ch = P0.noise_shift = P0.seed = P0.matrix_len = P0.bypass_mask = P0.outch_pack = 0;
+    P0.oshift_pack = P0.qss_pack = P0.nslots = P0.iir_any = P0.ss_end_bit = P0.rows_left = P0.blocks_in_frame = 0;
+    P0.have_restart = false;
+    P0.seg_iir = false;
+    P0.gl = segi * 2u;
+    P0.seg_lane = P0.gl;
+    P0.chk = (DUO && active) ? DVDA_AT(a.seg_check, (size_t)segi * 2u, 2ull * a.caps.max_seg, BT_CHECK) : 0xFFFFFFFFu;
+    P0.brec = P0.brec_end = P0.brec_base = nullptr;
+    if (DUO && PARSE && active) {
+        const uint4 pl = DVDA_AT(a.plan, segi, a.caps.max_seg + 1u, BT_PLAN);
+        P0.brec = a.brec + brec_offset(pl.x, pl.y, 0u, seg_R);
+        P0.brec_base = P0.brec;
+        P0.brec_end = P0.brec + brec_capacity(seg_R);
+        if (!DVDA_RANGE_OK(brec_offset(pl.x, pl.y, 0u, seg_R), brec_capacity(seg_R), a.caps.brec, BT_BREC)) {
+            status |= ST_CAPACITY;
+            active = false;
+        }
+    }
 
     // ---- per-lane decoder state (reference struct substream, src/mlp.c:103-115), in VGPRs
     // FIR history, st(k, 0) = most recent output, two values per 64-bit register pair (the even one in the low
@@ -849,7 +957,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // unpacked eight int16 halves per sample); the chain parse pass only hands them on and keeps them packed
     // (with three versions of the slot loop the six-slot instance had no registers for them -- 3.64 -> 4.25 ms with the
     //  spills -- ; with the one masked version it runs in 215 registers and has: 3.65 -> 3.56 ms)
-    constexpr bool CFU = !PARSE && !GENERAL;     // (the sequential pass has no registers to spare)
+    constexpr bool CFU = !PARSE && !GENERAL && !DUO;                  // (nor has the two-substream lane: its parked substream takes them)     // (the sequential pass has no registers to spare)
     constexpr int CFW = CFU ? 8 : 4;
     int32_t cf[NS][CFW];
     uint32_t pk[NS];                  // codebook | lsb_bits<<2 | qss<<7 | shift<<11 | iir_order<<15 |
@@ -863,7 +971,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // another lane or to a record keep the packed form: they have no registers to spare, or are not bound by this)
     // (frame-major instance only: 3.54 -> 3.41 ms on the headline batch; the planar instance ran its two-channel batch
     //  3.6 % slower with them, 2.40 -> 2.49 ms, at the same 256 registers -- measured, not understood)
-    constexpr bool MU = ILV && !PAIRED && !GENERAL && !PARSE;
+    constexpr bool MU = ILV && !PAIRED && !GENERAL && !PARSE && !DUO;
     int32_t mu[2][MU ? 8 : 1];
 #pragma unroll
     for (int m = 0; m < 2; m++)
@@ -923,6 +1031,44 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     int32_t pq_s[OUT_ROWS] = {0, 0, 0, 0};   // chain parse pass (see TP): per staged row, noise seed (its 23 bits) | bypassed LSBs << 23
     uint32_t au_idx = 0;              // chain parse pass: PCM-yielding access units of the segment so far
     uint32_t drops_seen = 0;          // frames dropped so far (major sync with other stream parameters)
+    // DUO: the lane's working substream <-> the parked one (for the lanes that call it: a block header of substream 0 is
+    // parsed between two swaps).  The register slots of the channels are not swapped: slot = channel.
+    uint32_t dsub = sub;              // which substream the working variables are (DUO: 1 between header parses)
+    auto swap_sub = [&]() {
+        auto sw = [](uint32_t &x, uint32_t &y) { const uint32_t t = x; x = y; y = t; };
+        auto swb = [](bool &x, bool &y) { const bool t = x; x = y; y = t; };
+        auto swp = [](uint32_t *&x, uint32_t *&y) { uint32_t *const t = x; x = y; y = t; };
+        sw(rd.pos, rx.pos);
+        sw(rd.fillpos, rx.fillpos);
+        sw(rd.lo_valid, rx.lo_valid);
+        swp(rd.ring, rx.ring);
+        sw(flags, P0.flags);
+        sw(block_size, P0.block_size);
+        sw(min_ch, P0.min_ch);
+        sw(max_ch, P0.max_ch);
+        sw(max_mat_ch, P0.max_mat_ch);
+        sw(noise_shift, P0.noise_shift);
+        sw(seed, P0.seed);
+        sw(matrix_len, P0.matrix_len);
+        sw(bypass_mask, P0.bypass_mask);
+        sw(outch_pack, P0.outch_pack);
+        sw(oshift_pack, P0.oshift_pack);
+        sw(qss_pack, P0.qss_pack);
+        sw(nslots, P0.nslots);
+        sw(iir_any, P0.iir_any);
+        sw(ss_end_bit, P0.ss_end_bit);
+        sw(rows_left, P0.rows_left);
+        sw(blocks_in_frame, P0.blocks_in_frame);
+        sw(chk, P0.chk);
+        sw(gl, P0.gl);
+        sw(seg_lane, P0.seg_lane);
+        swb(have_restart, P0.have_restart);
+        swb(seg_iir, P0.seg_iir);
+        swp(brec, P0.brec);
+        swp(brec_end, P0.brec_end);
+        swp(brec_base, P0.brec_base);
+        dsub ^= 1u;
+    };
 
     // ---- noise + rematrix + output shift of one PCM frame (src/mlp.c:1327-1355, 515-525);
     //      ch[0..7] in MLP channel order, shifted in place
@@ -1034,7 +1180,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // HDR_GATE_LANES of them do, or on every HDR_GATE_TURNS-th turn -- a lane waits some turns, rowless, and
         // the wave pays the parser that much less often.  (Not in the two-wave layout -- its waves exchange rows by
         // turn count -- nor in the sequential pass, whose lane pairs end access units together.)
-        bool hdr_now = active && rows_left == 0;
+        bool hdr_now = active && (rows_left == 0 || (DUO && P0.rows_left == 0));
         if (HDR_GATE && __builtin_expect(__any(hdr_now), 0)) {
             const uint64_t m_need = __ballot(hdr_now), m_act = __ballot(active);
             const bool go = m_need == m_act || (uint32_t)__popcll(m_need) >= HDR_GATE_LANES ||
@@ -1064,6 +1210,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #pragma unroll
                         for (int kk = 0; kk < 6; kk++)
                             brec[BREC_SLOT * kk] = 0xFFFFFFFFu;  // end of this (segment, substream)'s records
+                    }
+                    if constexpr (DUO && PARSE) {               // ... and the same for substream 0
+                        a.seg_meta[P0.seg_lane] = P0.min_ch | (P0.max_ch << 4) | (1u << 8) | (P0.seg_iir ? 1u << 9 : 0u);
+                        if (P0.brec) {
+#pragma unroll
+                            for (int kk = 0; kk < 6; kk++)
+                                P0.brec[BREC_SLOT * kk] = 0xFFFFFFFFu;
+                        }
                     }
                     bool go_on = false;
                     if (GENERAL) {
@@ -1123,14 +1277,17 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                     // ---- substream info "1u 1u 1u 1p 12u" (+16p) (src/mlp.c:463-468, 660-667)
                     uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0;
+                    uint32_t end0 = 0;                         // DUO: where substream 0 ends (it starts at data0)
                     bool bad = false;
                     for (uint32_t s = 0; s < S; s++) {
                         const uint32_t info = rd.read(16);
                         const uint32_t end = (info & 0xFFFu) * 2u;
                         if (info & 0x8000u)
                             rd.read(16);
-                        if (s == 0)
+                        if (s == 0) {
                             check0 = (info >> 13) & 1u;
+                            end0 = end;
+                        }
                         if (end < end_prev)
                             bad = true;
                         if (s == sub) {
@@ -1142,13 +1299,19 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     const uint64_t data0 = rd.tell_near(cur * 8u) >> 3;   // first substream byte
                     const uint64_t ss_lo = data0 + my_start;
                     const uint64_t ss_hi = data0 + my_end;
-                    if (bad || data0 + end_prev > frame_end || (check0 && my_end - my_start < 2)) {
+                    if (bad || data0 + end_prev > frame_end || (check0 && my_end - my_start < 2) ||
+                        (DUO && check0 && end0 < 2)) {
                         status |= ST_EOF;
                         active = false;
                     } else {
                         const uint64_t data_hi = check0 ? ss_hi - 2 : ss_hi;
                         ss_end_bit = (uint32_t)data_hi << 3;
                         rd.seek_byte(ss_lo);
+                        if constexpr (DUO) {
+                            P0.ss_end_bit = (uint32_t)(data0 + end0 - (check0 ? 2u : 0u)) << 3;
+                            rx.seek_byte(data0);
+                            P0.blocks_in_frame = 0;
+                        }
                         // (parity + CRC-8 over [ss_lo, ss_hi - 2), src/mlp.c:675-706: k_au_check's verdict is
                         //  looked at when the access unit ends)
                         in_frame = true;
@@ -1169,8 +1332,31 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 status |= ST_YIELD;
                 active = false;
             }
-            if (active) {
+            // (the working substream's.  A DUO lane parses substream 0's block header first, between two swaps, then
+            //  substream 1's: the order the reference reads them in, src/mlp.c:471-512, 540-573 -- ONE copy of the parser,
+            //  the loop is not unrolled; every other instance runs the loop's body once)
+            // (DUO fast pass: substream 0's FIRST block may hand the segment to the chain passes -- cold state, or a history
+            //  it continues.  Substream 1's first header is parsed all the same, and the lane stops behind it: whether the
+            //  segment continues a history is decided per substream, and the chain passes plan by that bit)
+            bool probe = false;
+#pragma nounroll
+            for (uint32_t pass = DUO ? 0u : 1u; pass < 2u; pass++) {
+                bool me = active;
+                bool first0 = false;
+                if constexpr (DUO) {
+                    me = active && (pass == 0u ? P0.rows_left == 0u : rows_left == 0u);
+                    if (!__any(me))
+                        continue;
+                    if (pass == 0u && me) {
+                        swap_sub();
+                        first0 = frames_done == 0u && blocks_in_frame == 0u;
+                    }
+                }
+            if (me) {
                 // ---- block header (src/mlp.c:748-771)
+                // (DUO, substream 0: its matrices are parsed -- their bypass flags size its rows -- and never applied: the
+                //  frame is rematrixed with substream 1's, src/mlp.c:575-582; the registers keep substream 1's)
+                const bool mat_mine = !(DUO && dsub == 0u);
                 bool ok = true;
                 uint32_t err = ST_PARAMS;
                 bool matrix_class_change = false;
@@ -1227,7 +1413,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         if (h0 != (0x18F5u << 1) || max_ch < min_ch || max_mat_ch < max_ch) {
                             ok = false;
                             err = ST_RESTART;
-                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= 6u || (!PAIRED && min_ch != 0)) {
+                        } else if (max_mat_ch >= 6u || max_ch - min_ch >= 6u || (!PAIRED && !DUO && min_ch != 0)) {
                             ok = false;
                             // DVD-Audio layouts stop at 6 channels (src/mlp.c:416-438 has 6 columns,
                             // src/dvd-audio.c:1459-1496 counts at most 6); matrix channels 6 and 7 are
@@ -1315,7 +1501,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                             for (int mm = 0; mm < 2; mm++)
 #pragma unroll
                                                 for (int jj = 0; jj < 4; jj++)
-                                                    if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1)) {
+                                                    if ((uint32_t)mm == m && (uint32_t)jj == (c >> 1) && mat_mine) {
                                                         mreg[mm][jj] = word;
                                                         if constexpr (MU) {
                                                             if (jj < 3) {                           // ([6], [7] are the noise's)
@@ -1330,14 +1516,14 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                     }
                                 }
                                 a.mat_ws[(size_t)(m * 5 + 4) * a.total_lanes + gl] = noise;
-                                if (m == 0)
+                                if (m == 0 && mat_mine)
                                     mnoise[0] = noise;
-                                if (m == 1)
+                                if (m == 1 && mat_mine)
                                     mnoise[1] = noise;
                                 if constexpr (MU) {
 #pragma unroll
                                     for (int mm = 0; mm < 2; mm++)
-                                        if ((uint32_t)mm == m) {
+                                        if ((uint32_t)mm == m && mat_mine) {
                                             mu[mm][MU ? 6 : 0] = lo16(noise);
                                             mu[mm][MU ? 7 : 0] = hi16(noise);
                                         }
@@ -1377,12 +1563,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         for (uint32_t k = 0; k < nslots && ok; k++) {
                             rd.ensure(HDR_FIR);
                             const uint32_t c = min_ch + k;
+                            const uint32_t kr = DUO ? c : k;        // the slot's registers (DUO: slot = channel)
                             uint32_t pk_old = 0;
                             int32_t sho_old = 0;
                             uint32_t cf_old[4] = {0, 0, 0, 0};
 #pragma unroll
                             for (int kk = 0; kk < NS; kk++)
-                                if ((uint32_t)kk == k) {
+                                if ((uint32_t)kk == kr) {
                                     pk_old = pk[kk];
                                     sho_old = sho[kk];
                                     if (PARSE) {
@@ -1535,7 +1722,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                                          (codebook ? 1u << 31 : 0u);
 #pragma unroll
                                     for (int kk = 0; kk < NS; kk++)
-                                        if ((uint32_t)kk == k) {
+                                        if ((uint32_t)kk == kr) {
                                             pk[kk] = npk;
                                             sho[kk] = nsho;
                                             if (new_fir) {
@@ -1610,7 +1797,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     status |= ST_SEQ;
                     active = false;
                 }
-                if (!adopt) {
+                if (!adopt && mat_mine) {
                     qss_A = qss_pack;
                     mmc_A = max_mat_ch;
                 }
@@ -1671,7 +1858,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (!GENERAL && !PARSE && (status & ST_CHAINED)) {
                     active = false;            // left to the chain passes (needs the previous history)
-                    atomicAdd(&s_nchained[wv], 1u);
+                    if (!(DUO && probe))
+                        atomicAdd(&s_nchained[wv], 1u);
                     // ... which start one segment earlier if that segment's lane hears of it in time: it is
                     // decoding a whole segment on its own (one lane of many per title) only to hand over its
                     // last eight values, and the parse pass would then wait for it
@@ -1692,6 +1880,26 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                 }
             }
+                if constexpr (DUO) {
+                    if (pass == 0u && me)
+                        swap_sub();
+                    if (!PARSE && pass == 0u && me && !active && first0 && !(status & ~ST_INFO)) {
+                        probe = true;
+                        active = true;
+                    }
+                    if (pass == 1u && probe)
+                        active = false;
+                }
+            }
+            if constexpr (DUO) {
+                // the lane's register slots are the segment's channels: substream 0 carries channels 0 .. n0 - 1 and
+                // substream 1 the ones right behind them.  Anything else (a gap: the reference leaves a channel empty;
+                // an overlap: it appends to one channel twice, src/mlp.c:598-603) is not this lane's to decode
+                if (active && have_restart && P0.have_restart && (P0.min_ch != 0u || min_ch != P0.max_ch + 1u)) {
+                    status |= PARSE ? ST_SEQ : ST_COLD;
+                    active = false;
+                }
+            }
         }
         if (hdr_now)
             DVDA_HSTAMP(4);
@@ -1703,16 +1911,30 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // A row needs at most 8 x 33 + 6 bits = 34 bytes.  Keep 12 dwords resident past `next`
         // (cold top-up), hash what the parser has passed, and fetch the next 64-byte chunk now
         // so that it lands in the ring while this row is being decoded.
+        // (DUO: a substream of a two-substream stream has at most five channels: 5 x 33 + 6 bits behind an offset of at
+        //  most 31 are seven dwords and one more for the last window -- eight resident in each of the two rings; both
+        //  rings' top-ups in flight together)
         if (active) {
+            if constexpr (DUO) {
+                while (__builtin_expect(__any(rd.ahead() < 8 || rx.ahead() < 8), 0)) {
+                    DVDA_COV(14);
+                    uint4 q0[4], q1[4];
+                    const int32_t n0 = rx.fill_issue(q0), n1 = rd.fill_issue(q1);
+                    rx.fill_commit(q0, n0);
+                    rd.fill_commit(q1, n1);
+                }
+            } else {
             if (rd.ahead() < 12)
                 DVDA_COV(14);                // synchronous ring top-up inside the row loop
             rd.ensure(12);
+            }
         }
         DVDA_STAMP(7);
         // both 64-byte halves of a 128-byte line are requested in consecutive rows, while the line
         // is still in L2 (one HBM fetch per line); a new line is started when half the ring is free
-        const int32_t ahead_now = rd.ahead();
-        const bool pf = active && ahead_now <= (RING_DWORDS - CHUNK_DWORDS);
+        // (DUO: sixteen bytes per ring and row, whenever the ring has room for them)
+        const bool pf = active && rd.room();
+        const bool pfx = DUO && active && rx.room();
         // Four registers each, written by the loads below and read under the same `pf`.  They must hold a DEFINED
         // value on the lanes that do not load.  Zero-filling them with instructions made the compiler wait for
         // every outstanding memory operation -- the previous row's PCM stores included -- before it could
@@ -1728,6 +1950,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         const uint32_t frames_before = frames_done;      // (sequential pass: did this turn close an access unit?)
         uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
         uint64_t flush_row = 0;
+        if constexpr (DUO) {
+            if (pfx)
+                p0 = rx.gsrc[rx.fill_src() >> 2];
+            if (pf)
+                p1 = rd.gsrc[rd.fill_src() >> 2];
+        } else {
         if (pf) {
             const uint32_t c = rd.fillpos < rd.max_chunk ? rd.fillpos : rd.max_chunk;
             const uint4 *src = rd.gsrc + (c >> 2);
@@ -1735,6 +1963,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             p1 = src[1];
             p2 = src[2];
             p3 = src[3];
+        }
         }
         DVDA_STAMP(1);
 
@@ -1776,20 +2005,44 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     }
                 }
             }
+            // (DUO: substream 0's bypassed LSBs -- at most one per matrix of ITS -- are read and dropped: the frame is
+            //  rematrixed with substream 1's matrices and substream 1's bits, src/mlp.c:484-486, 575-582)
+            if constexpr (DUO)
+                rx.pos += (uint32_t)__popc(P0.bypass_mask);
+            // the reading position and ring the slots cut their symbols from: the lane's one reader -- or, DUO, substream
+            // 0's until the slot where the lane's substream 1 begins (its channel count is the lane's own: the switch is
+            // a masked block at every slot where some lane of the wave has it)
+            uint32_t cpos = DUO ? rx.pos : rd.pos;
+            uint32_t cbase = (uint32_t)(uintptr_t)(DUO ? rx.ring : rd.ring);
+            auto cur_window_lds = [&]() -> uint32_t { return cbase + ((~(cpos >> 5) & (uint32_t)(RD - 1)) << 8); };
             // the row's first window (read here and waited for; a window carried over from the row before was measured
             // and dropped: three more registers through the whole loop cost more than the one LDS round trip they hide)
-            uint64_t win = rd.window();
+            uint64_t win = DUO ? rx.window() : rd.window();
+            const uint32_t n_sub0 = DUO ? P0.max_ch + 1u : 0u;       // DUO: the slot the lane's substream 1 starts at
             uint32_t msb_or = 0;                      // an invalid code decodes to 0xFF: bit 7 of the OR
             // IIR taps anywhere in the wave (sequential pass only: in the fast pass such a segment is ST_COLD)
             const bool wave_iir = GENERAL && __any(iir_any != 0);
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 // a slot no lane of the wave uses (2-channel titles: slots 2..5) is skipped outright
-                const bool in = (uint32_t)k < nslots;
+                const bool in = DUO ? (uint32_t)k <= max_ch : (uint32_t)k < nslots;
                 // (the window the slot before asked for -- by hand, below -- is waited for HERE, whoever goes on:
                 //  its registers must not be handed to anything else with the read still on its way)
                 if (k > 0)
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(win));
+                if constexpr (DUO) {
+                    if (k > 0) {
+                        const bool sw = (uint32_t)k == n_sub0;
+                        if (__any(sw)) {
+                            if (sw) {
+                                rx.pos = cpos;                  // substream 0's row is read
+                                cpos = rd.pos;
+                                cbase = (uint32_t)(uintptr_t)rd.ring;
+                                win = rd.window();
+                            }
+                        }
+                    }
+                }
                 if constexpr (!WSPEC)
                     val[k] = 0;
                 if (k >= 2 && !__any(in))
@@ -1801,7 +2054,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 const uint32_t bmask = (uint32_t)((int32_t)pkk >> 31);     // bit 31: the slot has a code book
                 // the symbol is cut from the 64 bits at the reading position (a code of at most 9 bits and at most 24
                 // LSBs behind an offset of at most 31)
-                const uint32_t ofs = rd.pos & 31u;
+                const uint32_t ofs = cpos & 31u;
                 const uint32_t top = (uint32_t)((win << ofs) >> 32);
                 uint64_t m_esc = __builtin_amdgcn_ballot_w64((int32_t)top < 0);      // bit 8 of the 9-bit peek
                 asm volatile("" : "+s"(m_esc));
@@ -1810,7 +2063,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 const uint32_t len = e >> 8;
                 msb_or |= msb;                            // valid values are < 0x20
                 const uint32_t o2 = ofs + len;
-                rd.pos += len + lb;
+                cpos += len + lb;
                 // ... and the next symbol's window is asked for at once: the read is in flight while this symbol's
                 // LSBs are cut and its value goes through the filter.  The read is placed by hand, as early as the
                 // position is known -- left to the compiler it sank into the filter's multiply-adds, a dozen
@@ -1827,7 +2080,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 if (k + 1 < NS)
                     // (the slot's newest history pair rides through the asm: the filter below starts from it, so the
                     //  scheduler cannot put the multiply-adds in front of the read)
-                    asm volatile("ds_read2st64_b32 %0, %2 offset1:1" : "+v"(win), "+v"(sp[k][0]) : "v"(rd.window_lds()));
+                    asm volatile("ds_read2st64_b32 %0, %2 offset1:1" : "+v"(win), "+v"(sp[k][0]) : "v"(cur_window_lds()));
                 const int32_t residual = (int32_t)(((msb << lb) + lsbv + (uint32_t)sho[k]) << q);
                 int32_t value;
                 if constexpr (PARSE) {
@@ -1889,6 +2142,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
                 }       // (the lanes that carry the slot)
             }
+            rd.pos = cpos;
             if (__builtin_expect((msb_or & 0x80u) != 0, 0)) {
                 status |= ST_HUFFMAN;
                 active = false;
@@ -1980,6 +2234,66 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
             frame_rows++;
             rows_left--;
+            if constexpr (DUO) {
+                // ---- both substreams' blocks: "last block" bits (src/mlp.c:729), ends of data, parity / CRC-8 verdicts.
+                //      The two substreams of an access unit end it at the same PCM frame, the standard one, or the stream
+                //      is the sequential pass's (ST_TIMING)
+                P0.rows_left--;
+                if (__builtin_expect(active && (rows_left == 0 || P0.rows_left == 0), 0)) {
+                    bool last0 = false, last1 = false;
+                    if (P0.rows_left == 0) {
+                        last0 = rx.read(1) != 0;
+                        if (rx.past(P0.ss_end_bit)) {
+                            status |= ST_EOF;
+                            active = false;
+                        }
+                        if (active && last0 && (P0.chk >> 2) == frames_done) {
+                            status |= (P0.chk & 1u) ? ST_PARITY : ST_CRC;
+                            active = false;
+                        }
+                    }
+                    if (active && rows_left == 0) {
+                        last1 = rd.read(1) != 0;
+                        if (rd.past(ss_end_bit)) {
+                            status |= ST_EOF;
+                            active = false;
+                        }
+                        if (active && last1 && (chk >> 2) == frames_done) {
+                            status |= (chk & 1u) ? ST_PARITY : ST_CRC;
+                            active = false;
+                        }
+                    }
+                    if (active && (last0 || last1) && (!(last0 && last1) || frame_rows != rpa)) {
+                        status |= ST_TIMING;
+                        active = false;
+                    }
+                    if (last0 && last1) {
+                        if (PARSE && active) {
+                            // ---- what this access unit is rematrixed with: the parameters substream 1's last block leaves
+                            uint32_t *F = frec + (size_t)au_idx * FREC_WORDS;
+                            if (!DVDA_RANGE_OK((size_t)(F - a.frec), FREC_WORDS, a.caps.frec, BT_FREC))
+                                F = a.frec;
+                            F[0] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
+                            F[1] = outch_pack;
+                            F[2] = qss_pack;
+                            F[3] = oshift_pack;
+#pragma unroll
+                            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                    F[4 + m * 5 + j] = mreg[m][j];
+                                F[4 + m * 5 + 4] = mnoise[m];
+                            }
+                            for (uint32_t m = 2; m < matrix_len; m++)
+                                for (uint32_t j = 0; j < 5; j++)
+                                    F[4 + m * 5 + j] = a.mat_ws[(size_t)(m * 5 + j) * a.total_lanes + gl];
+                        }
+                        au_idx++;
+                        in_frame = false;
+                        frames_done++;
+                    }
+                }
+            } else
             if (__builtin_expect(active && rows_left == 0, 0)) {
                 // ---- "last block" bit (src/mlp.c:729); the substream tail is padding
                 if (rd.read(1)) {
@@ -2068,7 +2382,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // ---- the frame's channels 0..7 come together for the rematrix
         int32_t ch[MAXCH];
         // (two-wave layout: the lane that rematrixes starts OUT_ROWS turns late, for good)
-        const bool in_row = active && (!HDR_GATE || rows_left != 0) && (!adopt || it >= (uint32_t)OUT_ROWS);
+        const bool in_row = active && (!HDR_GATE || (rows_left != 0 && (!DUO || P0.rows_left != 0))) && (!adopt || it >= (uint32_t)OUT_ROWS);
         if constexpr (WSPEC) {
             if (in_row)
                 row_head_any();
@@ -2185,9 +2499,20 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //  but for the PCM stores issued a few instructions earlier, a store's whole round trip every flush: 12 % of
         //  a wave's time, tools/stamp_run.py.  vmcnt(0), lgkmcnt / expcnt not waited for: 0x0F70)
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        if constexpr (DUO) {
+            if (pfx) {
+                ring_store4<RD>(rx.slot(rx.fillpos), p0, (rx.fillpos & (RD - 1)) == 0);
+                rx.filled();
+            }
+            if (pf) {
+                ring_store4<RD>(rd.slot(rd.fillpos), p1, (rd.fillpos & (RD - 1)) == 0);
+                rd.filled();
+            }
+        } else {
         if (pf) {
             ring_store16(rd.slot(rd.fillpos), p0, p1, p2, p3, (rd.fillpos & (RING_DWORDS - 1)) == 0);
             rd.filled();
+        }
         }
         // ---- ... and only then the staged PCM leaves: the wait for the chunk above counts every
         //      older memory operation, so stores issued before it would be waited for as well; issued
@@ -2241,7 +2566,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
             // (the one-lane int32 frame-major instance has handed the payload to its WAVO twin; every other instance
             //  -- two-wave, sequential -- still writes it itself)
-            constexpr bool WAV_ELSEWHERE = !PAIRED && !WAVO;
+            constexpr bool WAV_ELSEWHERE = !PAIRED && !WAVO && !DUO;
             if (WAVO || (!WAV_ELSEWHERE && __builtin_expect(a.wav_bits != 0, 0))) {
                 // ---- the WAV payload itself (SURVEY 8(f-3) fused into the decode): the OUT_ROWS frames are
                 //      OUT_ROWS * channels consecutive samples = `channels` groups of four; a group packs into
@@ -2429,12 +2754,29 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 #endif
     if (!GENERAL && !PARSE && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
         // FIR history at the segment's end, for a following segment that depends on it
+        if constexpr (DUO) {
+            // (slot c = channel c: substream 0's slots 0 .. n0 - 1, substream 1's behind them, each into its own
+            //  workspace lane under its slot number within the substream)
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const uint32_t s1 = (uint32_t)k >= min_ch ? 1u : 0u;
+                const uint32_t kk = (uint32_t)k - (s1 ? min_ch : 0u);
+                if ((uint32_t)k <= max_ch) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        a.fir_ws[(size_t)(kk * 8 + j) * a.total_lanes + segi * 2u + s1] = st_get(k, j);
+                }
+            }
+            a.seg_meta[segi * 2u] = P0.min_ch | (P0.max_ch << 4) | (1u << 8);
+            a.seg_meta[segi * 2u + 1u] = min_ch | (max_ch << 4) | (1u << 8);
+        } else {
 #pragma unroll
         for (int k = 0; k < NS; k++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 a.fir_ws[(size_t)(k * 8 + j) * a.total_lanes + gl] = st_get(k, j);
         a.seg_meta[gl] = min_ch | (max_ch << 4) | (1u << 8);
+        }
     }
     // ---- what the passes behind the fast pass will have to do (the host reads the summary): summed over the
     //      wave first -- every lane of a chained batch reports here, and 10^5 atomics on one address are

@@ -58,6 +58,9 @@ static hipError_t ws_malloc(void **p, size_t bytes)
 
 struct dvda_mlp_hip_ctx {
     int device;
+    bool duo_parse;            // (DVDA_DUO=1: the fast pass only, =2: the parse pass only -- diagnostic)
+    bool duo;                  // two-substream streams: one lane reads both substreams (k_decode<.., DUO>); false (DVDA_DUO=0,
+                               // diagnostic): the round 1-5 layouts -- a wave per substream in the fast pass, lane pairs in the parse pass
     uint32_t coop_min_seg;     // DecodeArgs::coop_min_seg: 1.75 waves per SIMD of this device (measured: slower at 1.5, 4.5 % faster at 2) (DVDA_COOP_MIN_SEG overrides: diagnostic)
     uint32_t max_streams, max_segments;
     // index workspace
@@ -253,6 +256,9 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
         c->coop_min_seg = (uint32_t)cus * 4u * 64u * 7u / 4u;
         if (const char *e = getenv("DVDA_COOP_MIN_SEG"))
             c->coop_min_seg = (uint32_t)strtoul(e, nullptr, 10);
+        const int duo_env = getenv("DVDA_DUO") ? atoi(getenv("DVDA_DUO")) : 3;
+        c->duo = (duo_env & 1) != 0;
+        c->duo_parse = (duo_env & 2) != 0;
     }
     c->max_streams = max_streams;
     c->max_segments = max_segments;
@@ -832,7 +838,8 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     const bool coop_only = c->lanes_per_seg == 64 || (c->lanes_per_seg == 0 && c->small_input);
     const bool lanes_only = c->lanes_per_seg == 3;
     const uint32_t force = (coop_only || lanes_only) ? 0u : c->lanes_per_seg;
-    const bool run1 = force != 2 && !coop_only, run2 = force != 1 && !coop_only;
+    // (DUO: the two-substream kernel decodes two-substream streams only, so "2" runs both lane kernels, each on its class)
+    const bool run1 = (force != 2 || c->duo) && !coop_only, run2 = force != 1 && !coop_only;
     a.coop = coop_only ? 64u : lanes_only ? 3u : force;
     const uint64_t ms = c->max_segments;
     const unsigned blocks1 = (unsigned)((ms + DEC_THREADS - 1) / DEC_THREADS);            // one lane per segment
@@ -847,7 +854,7 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         hipLaunchKernelGGL(k_coop<false>, dim3(cblocks), dim3(COOP_THREADS), 0, st, a);
     }
     if (run1) {
-        a.only_S = force ? 0u : 1u;
+        a.only_S = (force == 1) ? 0u : 1u;
         if (a.interleaved && a.wav_bits)
             hipLaunchKernelGGL((k_decode<6, false, false, true, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
         else if (a.interleaved)
@@ -855,7 +862,13 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         else
             hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
     }
-    if (run2) {
+    if (run2 && c->duo) {
+        a.only_S = 2u;
+        if (a.interleaved)
+            hipLaunchKernelGGL((k_decode<6, false, false, true, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_decode<6, false, false, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
+    } else if (run2) {
         a.only_S = force ? 0u : 2u;
         if (a.interleaved)
             hipLaunchKernelGGL((k_decode<WS_SLOTS, true, false, true>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
@@ -943,12 +956,16 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         if (coop_parse) {
             hipLaunchKernelGGL(k_coop<true>, dim3(segs), dim3(COOP_THREADS), 0, st, a);
         } else {
-            if (force != 2) {
-                a.only_S = force ? 0u : 1u;
+            if (force != 2 || c->duo_parse) {
+                a.only_S = (force == 1) ? 0u : 1u;
                 hipLaunchKernelGGL((k_decode<6, false, false, false, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
                                    dim3(DEC_THREADS), 0, st, a);
             }
-            if (force != 1) {
+            if (force != 1 && c->duo_parse) {
+                a.only_S = 2u;
+                hipLaunchKernelGGL((k_decode<6, false, false, false, true, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
+                                   dim3(DEC_THREADS), 0, st, a);
+            } else if (force != 1) {
                 a.only_S = force ? 0u : 2u;
                 hipLaunchKernelGGL((k_decode<6, true, false, false, true>), dim3((2 * segs + DEC_THREADS - 1) / DEC_THREADS),
                                    dim3(DEC_THREADS), 0, st, a);

@@ -792,9 +792,11 @@ def test_mixed_batch_picks_the_kernels_itself(pkg, oracle):
 
 @pytest.mark.parametrize("ss0", [1, 2, 3, 4, 5])
 def test_two_substreams_of_any_split(pkg, oracle, ss0):
-    """The two-wave kernel keeps four channels per substream in registers (two + four is what discs carry).  Any
-    other split of six channels -- one + five, five + one -- must still come out exact: the wide substream's
-    segments are handed to the chain passes (DVDA_ST_COLD, an information bit)."""
+    """Any split of six channels over two substreams -- one + five, two + four (what discs carry) ... five + one -- comes
+    out exact from the fast pass itself: since round 6 one lane reads both substreams of its segment and a channel's
+    register slot is its channel number, so no split is "too wide" (rounds 1-5: the two-wave kernel kept four channels
+    per substream and handed wider ones to the chain passes, DVDA_ST_COLD).  Forced to the lane kernels: a batch this
+    small would otherwise get the cooperative one."""
     syn, hip = pkg.synth, pkg.hipdec
     cfgs = [syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0),
             syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0, profile=1,
@@ -802,15 +804,13 @@ def test_two_substreams_of_any_split(pkg, oracle, ss0):
             syn.make_cfg(assignment=12, rate_code=1, n_substreams=2, n_aus=24, ss0_channels=ss0, profile=1,
                          features=syn.SF["CHAINED"] | syn.SF["FIRRAND"], restart_interval=4)]
     streams = [syn.stream(c, 9300 + 10 * ss0 + i) for i, c in enumerate(cfgs)]
-    pcm, infos = _both(hip, [b for b, _ in streams], lanes_per_segment=2)      # (the two-wave kernel; a batch this small
-    wide = ss0 < 2 or ss0 > 4                                                    #  would otherwise get the cooperative one)
+    pcm, infos = _both(hip, [b for b, _ in streams], lanes_per_segment=2)
     for i, ((b, f), got, inf) in enumerate(zip(streams, pcm, infos)):
         want, r, st = oracle.decode(b, 6, f)
         assert st == 0 and r == f
         assert inf.status & ~hip.ST_BENIGN == 0 and inf.substreams == 2
-        assert bool(inf.status & hip.ST["COLD"]) or not wide
         if i == 0:
-            assert inf.status == (hip.ST["COLD"] | hip.ST["GENERAL"] if wide else 0), hex(inf.status)
+            assert inf.status == 0, hex(inf.status)         # (the plain recipe: nothing is deferred)
         assert np.array_equal(got, want)
 
 
