@@ -258,12 +258,10 @@ int dvda_mlp_hip_decode_multi(dvda_mlp_hip_multi *multi, const uint8_t *const *s
 int dvda_mlp_hip_bounds_violations(unsigned long long *out4);
 
 /* Which fast-pass kernels run.  0 (default): chosen per batch from the substream counts the index
- * found -- streams with one substream take the one-lane-per-segment kernel, streams with two the
- * two-wave kernel, a mixed batch both (a kernel whose class is absent exits at once).  1 / 2 force one
- * kernel for the whole batch (1: a two-substream stream is then reported as DVDA_ST_ENVELOPE; 2: the
- * two-wave kernel keeps four channels per substream in registers -- what discs carry is 2 + 4 -- and a
- * substream with five or six channels is decoded by the passes behind it, DVDA_ST_COLD | DVDA_ST_GENERAL
- * set, PCM identical).
+ * found -- streams with one substream take the one-lane-per-segment kernel, streams with two the kernel
+ * whose lane reads both substreams of its segment (round 6; any split of the channels over the two), a
+ * mixed batch both (a kernel whose class is absent exits at once).  1 forces the one-substream kernel for
+ * the whole batch (a two-substream stream is then reported as DVDA_ST_ENVELOPE); 2 = 3.
  * Under 0 a SMALL batch -- at most 4 096 segments and 32 768 access units, counted on the device by the index --
  * is decoded by the wave-cooperative kernel instead (csrc/mlp_coop.h: one wave per (segment, substream), the
  * bit-serial symbol scan in scalar registers, residuals / filter / rematrix at the width they have): BASELINE

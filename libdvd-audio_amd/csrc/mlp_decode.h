@@ -21,9 +21,8 @@
 //   * PCM leaves as 16-byte stores, staged four frames at a time in an LDS tile and issued after
 //     the ring commit so that no s_waitcnt counts them: planar layout = one store per channel into six
 //     places, frame-major layout = one contiguous run per lane (template parameter ILV)
-//   * two-substream streams: one wave per substream in the fast pass; the wave that rematrixes runs four
-//     rows behind the other, the rows cross through the doubled staging tile, one workgroup barrier per
-//     four rows (WSPEC)
+//   * two-substream streams: ONE lane reads both substreams of its segment, from two small rings (DUO, round 6;
+//     rounds 1-5 gave each substream a wave of its own and crossed the rows through a doubled staging tile)
 //   * Huffman codes are decoded arithmetically (the three books share one
 //     structure, mlp_tables.h) -- no table, no LDS latency on the parse chain
 //
@@ -55,9 +54,6 @@ namespace mlp {
 
 constexpr int DEC_THREADS = 128;
 constexpr int DEC_WAVES = DEC_THREADS / 64;
-// fast pass over two-substream streams: one wave per (64 segments, substream); see k_decode
-constexpr int WS_THREADS = 256;
-constexpr int WS_SLOTS = 4;   // channels per substream the two-wave kernel keeps in registers (more: ST_COLD)
 constexpr int MAXCH = 8;    // reference MAX_MLP_CHANNELS (src/mlp.c:30)
 constexpr int MAXMAT = 6;   // reference MAX_MLP_MATRICES (src/mlp.c:27)
 constexpr int RING_PLANES = 8;                  // planes x 16 B per lane (8 = 128-byte ring)
@@ -644,7 +640,7 @@ struct SubPark {
 // WAVO (round 5): the frame-major instance for the packed WAV payload only (DVDA_PCM_WAV24 / WAV16) -- without the int32
 // flushes, the cooperative one among them, whose registers cost the payload's flush 3 % when they shared an instance.
 template <int NS, bool PAIRED, bool GENERAL, bool ILV = false, bool PARSE = false, bool DUO = false, bool WAVO = false>
-__global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_THREADS, 2) void k_decode(DecodeArgs a)
+__global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
 {
     static_assert(!(GENERAL && PARSE), "one mode at a time");
     // DUO (round 6): ONE lane decodes BOTH substreams of its segment, row by row -- the channels of substream 0, then the
@@ -652,8 +648,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // The lane's working state is substream 1's (what the rematrix, the output and the records of the last substream
     // use); substream 0's header / block state is parked (`P0`) and swapped in for its block headers.  Channel c of the
     // segment lives in register slot c whichever substream carries it.
+    // (Rounds 1-5: a wave per substream in the fast pass, the rows crossing through a doubled staging tile with one
+    //  workgroup barrier per four rows, and lane pairs in the parse pass -- both waves / lanes paid the row loop's fixed
+    //  part: 5.2 ms for the two-substream bench batch against this layout's 4.1, parse 5.2 against 4.0.  docs/history.md.)
     static_assert(!DUO || (!PAIRED && !GENERAL && NS == 6), "the two-substream lane is a one-lane fast-pass / parse instance");
-    static_assert(!GENERAL || PAIRED, "the sequential pass always runs as lane pairs");
+    // PAIRED: the two substreams of a segment in two lanes side by side -- the sequential pass only
+    static_assert(GENERAL == PAIRED, "lane pairs are the sequential pass's layout, and its only one");
     constexpr uint32_t L = PAIRED ? 2u : 1u;                      // lanes per segment
     // fast pass: the batch holds no stream of this kernel's class (set by the index): whole grid exits
     if (!GENERAL && a.only_S && a.cls[a.only_S - 1u] == 0)
@@ -661,23 +661,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // ... or the batch is small enough for the wave-cooperative kernel, which then decodes it (mlp_coop.h)
     if (!GENERAL && !PARSE && coop_takes(a))
         return;
-    // fast pass over two-substream streams: a wave carries ONE substream of 64 segments.  The odd
-    // wave of a group has each segment's last substream (the only one of a single-substream stream):
-    // it gathers the row's channels, rematrixes, stages and stores.  The even wave has the first
-    // substream of the two-substream streams: its own (typically two) slots and nothing else.
-    // (Round 1 measured this against the lane-pair layout, which ran every wave through the long
-    //  substream's slots and the rematrix; 2-, 4- and 8-wave blocks were tried.)
-    // Round 2: the pair no longer meets at a barrier every row.  The staging tile is doubled and doubles
-    // as the exchange: the odd wave writes the rows of phase p (OUT_ROWS loop turns) into tile p & 1
-    // while the even wave -- which rematrixes, see WS_BAL -- runs OUT_ROWS rows behind it: it reads the
-    // rows of phase p - 1 from the other tile, adds its own channels, rematrixes in place and flushes
-    // the tile at the phase's last row.  One block barrier per OUT_ROWS rows, and neither wave waits
-    // for the other's row, only for its last four.
-    constexpr bool WSPEC = PAIRED && !GENERAL && !PARSE;
-    constexpr bool SIDE = PAIRED && !WSPEC;                       // the two lanes of a segment side by side
-    constexpr int THREADS = WSPEC ? WS_THREADS : DEC_THREADS;
+    constexpr int THREADS = DEC_THREADS;
     constexpr int WAVES = THREADS / 64;
-    constexpr int GROUPS = WSPEC ? WAVES / 2 : 1;
     constexpr int TP = 6;                                         // staged planes: the channels (the chain parse pass keeps
                                                                   // a row's bypassed LSBs and noise seed in registers: with two
                                                                   // more planes its workgroup was 34 KB of LDS and only three fit a CU)
@@ -685,41 +670,18 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     constexpr int RG = DUO ? DUO_GRAN : CHUNK_DWORDS;           // dwords a fill brings
     using Reader = BitReaderT<RD, RG>;
     __shared__ uint32_t s_ring[WAVES][DUO ? 2 : 1][RD + 1][64];     // + the mirror of plane 0 (DUO: a ring per substream)
-    __shared__ int32_t s_out[GENERAL ? 1 : (WSPEC ? GROUPS * 2 : WAVES)][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
-    // two-wave layout, per row of a tile: "the odd wave's channels are there" | version of the rematrix
-    // parameters the row goes with << 8 | its bypassed LSBs
-    __shared__ uint32_t s_tag[WSPEC ? GROUPS : 1][2][OUT_ROWS][WSPEC ? 64 : 1];
-    // (the chain parse pass needs no exchange tile: both lanes of a segment put their residuals straight into
-    //  the staging column of the lane that flushes it -- 4 KB less, four workgroups per CU instead of three)
-    constexpr bool XCH = SIDE && !PARSE;
+    __shared__ int32_t s_out[GENERAL ? 1 : WAVES][TP][OUT_ROWS][GENERAL ? 1 : 64];   // PCM staging
+    // sequential pass: the two lanes of a segment exchange their channels here
+    constexpr bool XCH = PAIRED;
     __shared__ int32_t s_xch[XCH ? WAVES : 1][MAXCH][XCH ? 64 : 1];
-    __shared__ uint32_t s_alive[2][WAVES];
-    __shared__ uint32_t s_nchained[WAVES];          // fast pass: lanes of the wave that stopped on ST_CHAINED (or, two-wave
-                                                    // layout, whose other substream's lane did)
-    // WS_BAL: the rematrix parameters of a two-substream segment, published by the lane that parses them
-    // (last substream, odd wave) for the lane that applies them (first substream, even wave)
-    constexpr bool WS_BAL = WSPEC;
-    // (two copies, by version parity.  Versions are at least 8 rows apart -- a block has 8 rows or more --
-    //  so at most one is written per phase, and the reader, one phase behind, has taken version v - 1 before
-    //  the phase in which v + 1 overwrites it.  Word 0: a restart header set the noise seed in word 1.)
-    constexpr int SPL = 64;
-    __shared__ uint32_t s_par[WS_BAL ? GROUPS : 1][2][16][WS_BAL ? SPL : 1];
+    __shared__ uint32_t s_nchained[WAVES];          // fast pass: lanes of the wave that stopped on ST_CHAINED
 
     if (threadIdx.x < WAVES)
         s_nchained[threadIdx.x] = 0;
-    if (WSPEC) {
-        for (int i = threadIdx.x; i < GROUPS * 2 * OUT_ROWS * 64; i += THREADS)     // "no row there"
-            (&s_tag[0][0][0][0])[WSPEC ? i : 0] = 0;
-    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    // two-wave layout: the odd wave of a group carries the LAST substream of each of its 64 segments
-    // (the only one of a single-substream stream), the even wave the first substream of the
-    // two-substream ones -- so the even waves never rematrix, stage or store PCM
-    const uint32_t ws_grp = (uint32_t)wv >> 1;
-    const uint32_t ws_last = (uint32_t)wv & 1u;
     const uint32_t wg_id = blockIdx.x;
     const uint32_t gl0 = wg_id * THREADS + threadIdx.x;
     uint32_t n_seg = *a.n_seg_ptr;
@@ -728,7 +690,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // which segment: the fast pass covers the index in order; the sequential pass starts lane pair j at the
     // first segment of stream list[list_base + j]; the chain parse pass gives deferred segment
     // list[list_base + j] to lane (pair) j
-    const uint32_t item = WSPEC ? (wg_id * GROUPS + ws_grp) * 64u + (uint32_t)lane : gl0 / L;
+    const uint32_t item = gl0 / L;
     uint32_t segi = item;
     bool active = segi < n_seg;
     if (!GENERAL && !PARSE && active && *a.hetero)
@@ -775,9 +737,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     }
     const uint32_t S = (stream_sync >> 24) & 0xF;             // latched substream count
     // substream handled by this lane; workspace lane = segment * 2 + substream in every layout and pass
-    // (an even-wave lane of a single-substream stream is idle and names the stream's absent substream 1)
     // (DUO: the lane's working substream is the last one, 1; substream 0's state is parked)
-    const uint32_t sub = DUO ? 1u : WSPEC ? (ws_last == (S == 2 ? 1u : 0u) ? 1u : 0u) : gl0 - item * L;
+    const uint32_t sub = DUO ? 1u : gl0 - item * L;
     uint32_t gl = segi * 2u + sub;          // (DUO: swapped with the parked substream's for its block headers)
     uint32_t seg_lane = gl;                 // lane index that owns segment `segi` in the workspaces
     const uint32_t assignment = (stream_sync >> 16) & 0x1F;
@@ -804,12 +765,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         active = false;
     }
     const bool is_last_sub = (sub + 1 == S);
-    // who turns the segment's channels into PCM: the lane of the last substream -- except in the two-wave
-    // layout, where the (short) first substream's lane of a two-substream segment takes that over from the
-    // (long) last one: it reads the matrices the other lane parses and the pair's work is even
-    const bool adopt = WS_BAL && S == 2u && sub == 0u;
-    const bool lends = WS_BAL && S == 2u && sub == 1u;
-    const bool owner = WS_BAL ? (adopt || (is_last_sub && !lends)) : is_last_sub;
+    // who turns the segment's channels into PCM: the lane of the last substream
+    const bool owner = is_last_sub;
 
     uint64_t out_base = 0, out_stride = 0;
     if (active && !PARSE) {
@@ -887,11 +844,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     // frame-major, and every segment of this wave is 6 channels in identity RIFF order (all 6-channel
     // assignments but 0x14) into an aligned buffer: the tile is staged frame-major too -- [frame][channel]
     // instead of [channel][frame] -- and a flush reads it front to back.  Decided once per wave.
-    // (Judged by the SEGMENT a lane names, not by whether the lane has work: in the two-wave layout the staging
-    //  tile is also the exchange between the two waves of a group, so both have to decide alike -- and the idle
-    //  lane of a single-substream segment, whose output offset was never loaded, used to see an aligned buffer
-    //  where its working twin in the other wave saw an unaligned one: two layouts in one tile, channels of the
-    //  group's two-substream segments transposed.  Found by tools/soak_reuse.py.)
+    // (judged by the SEGMENT a lane names, not by whether the lane has work)
     bool dir_ok = true;
     if (ILV && !GENERAL && !PARSE && segi < n_seg) {
         const uint64_t ob = a.out_off[sr.stream], os = a.out_stride[sr.stream];
@@ -1007,12 +960,9 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     uint32_t matrix_len = 0, bypass_mask = 0, outch_pack = 0;
     uint32_t oshift_pack = 0, qss_pack = 0;
     uint32_t qss_A = 0, mmc_A = 0;    // quant step sizes / max_matrix_channel the rematrix works with
-    uint32_t par_seen = 0, par_pub = 0;   // WS_BAL: version of the published parameters (taken / written)
-    uint32_t par_phase = 0;               // ... and the phase + 1 the last one was written in
-    uint32_t it = 0;                      // two-wave layout: loop turn (wave-uniform); phase = it / OUT_ROWS
     uint32_t gate_turn = 0;               // loop turn for the header gate (wave-uniform)
     constexpr bool HDR_GATE = !PAIRED && !GENERAL;
-    const uint32_t gl_r = adopt ? gl + 1u : gl;     // workspace lane of the matrices 2..5 it works with
+    const uint32_t gl_r = gl;                       // workspace lane of the matrices 2..5 (sequential pass)
     uint32_t nslots = 0;
     bool have_restart = false;
     uint32_t iir_any = 0;             // bit k: slot k has IIR order > 0
@@ -1178,8 +1128,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         // parse becomes the row loop (sub.fuzz_fast_features: 9 x below the headline in round 2).  So headers are
         // parsed in company: the phase runs when every active lane waits for it (lanes in lockstep: at once), when
         // HDR_GATE_LANES of them do, or on every HDR_GATE_TURNS-th turn -- a lane waits some turns, rowless, and
-        // the wave pays the parser that much less often.  (Not in the two-wave layout -- its waves exchange rows by
-        // turn count -- nor in the sequential pass, whose lane pairs end access units together.)
+        // the wave pays the parser that much less often.  (Not in the sequential pass, whose lane pairs end access
+        // units together.)
         bool hdr_now = active && (rows_left == 0 || (DUO && P0.rows_left == 0));
         if (HDR_GATE && __builtin_expect(__any(hdr_now), 0)) {
             const uint64_t m_need = __ballot(hdr_now), m_act = __ballot(active);
@@ -1361,30 +1311,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 uint32_t err = ST_PARAMS;
                 bool matrix_class_change = false;
                 bool hdr_restart = false;
-                bool too_wide = false;
                 uint32_t chg_mask = 0;                     // chain parse pass: slots whose filter parameters this block sets
                 bool seq_needed = false;                   // ... and what only the sequential pass decodes
-                // two-wave layout, the lane that rematrixes with the OTHER substream's parameters: its own
-                // header sets the same variables (the parse below needs them: matrix count, bypass flags); they
-                // are put back when it is through
-                uint32_t keep_m[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, keep_n[2] = {0, 0};
-                uint32_t keep_ns = 0, keep_seed = 0, keep_ml = 0, keep_oc = 0, keep_os = 0;
-                if (adopt) {
-#pragma unroll
-                    for (int m = 0; m < 2; m++) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            keep_m[m][j] = mreg[m][j];
-                        keep_n[m] = mnoise[m];
-                    }
-                    keep_ns = noise_shift;
-                    keep_seed = seed;
-                    keep_ml = matrix_len;
-                    keep_oc = outch_pack;
-                    keep_os = oshift_pack;
-                    // (its own matrix count outlives the block; it rides in the upper half of par_seen)
-                    matrix_len = par_seen >> 16;
-                }
                 if (rd.read(1)) {
                     // (every lane tops its ring up here, together, and the fields below are cut from resident dwords without a
                     //  test or a loop per field: the generic read() ends in "while the window has run out, step it", which over 64
@@ -1428,11 +1356,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                 }
                             rd.read_resident(8);                            // checksum: ignored
                             nslots = max_ch - min_ch + 1;
-                            // more channels in one substream than this instance keeps in registers (the two-wave
-                            // kernel: WS_SLOTS): the header is parsed to its end -- whether the segment needs the
-                            // history before it is decided there -- and the segment goes to the chain passes
-                            if (NS < 6 && nslots > (uint32_t)NS)
-                                too_wide = true;
                             have_restart = true;
                         }
                         if (blocks_in_frame)
@@ -1797,52 +1720,11 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     status |= ST_SEQ;
                     active = false;
                 }
-                if (!adopt && mat_mine) {
+                if (mat_mine) {
                     qss_A = qss_pack;
                     mmc_A = max_mat_ch;
                 }
-                uint32_t cold_ml = matrix_len;        // (this substream's own matrix count)
-                if (adopt) {
-                    par_seen = (par_seen & 0xFFFFu) | (matrix_len << 16);
-#pragma unroll
-                    for (int m = 0; m < 2; m++) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            mreg[m][j] = keep_m[m][j];
-                        mnoise[m] = keep_n[m];
-                    }
-                    noise_shift = keep_ns;
-                    seed = keep_seed;
-                    matrix_len = keep_ml;
-                    outch_pack = keep_oc;
-                    oshift_pack = keep_os;
-                }
-                if (lends) {
-                    // ---- the parameters the other wave rematrixes with, from this row on; the seed only when a
-                    //      restart header set it (the other lane steps its own copy from there)
-                    if (par_phase == (it >> 2) + 1u) {
-                        status |= ST_COLD;          // (cannot happen: blocks have 8 rows or more; s_par's note)
-                        ok = false;
-                        err = 0;
-                    }
-                    par_phase = (it >> 2) + 1u;
-                    par_pub = (par_pub + 1u) & 0xFFFFu;
-                    uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][par_pub & 1u][0][WS_BAL ? lane & (SPL - 1) : 0];
-                    constexpr int PS = WS_BAL ? SPL : 1;
-                    P[0] = hdr_restart ? 1u : 0u;
-                    P[1 * PS] = seed;
-                    P[2 * PS] = noise_shift | (matrix_len << 8) | (max_mat_ch << 16);
-                    P[3 * PS] = outch_pack;
-                    P[4 * PS] = qss_pack;
-                    P[5 * PS] = oshift_pack;
-#pragma unroll
-                    for (int m = 0; m < 2; m++) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            P[(6 + m * 4 + j) * PS] = mreg[m][j];
-                        P[(14 + m) * PS] = mnoise[m];
-                    }
-                }
+                const uint32_t cold_ml = matrix_len;        // (this substream's own matrix count)
                 if (matrix_class_change)
                     status |= ST_MIDFRAME;
                 if (!ok) {
@@ -1850,7 +1732,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     active = false;
                 } else if (PARSE && !active) {
                     // (ST_SEQ above)
-                } else if (!GENERAL && !PARSE && (iir_any != 0 || cold_ml > 2 || too_wide)) {
+                } else if (!GENERAL && !PARSE && (iir_any != 0 || cold_ml > 2)) {
                     // IIR taps (their coefficients and history live in a memory workspace) or more than the
                     // two register-resident matrices: the chain passes decode such a segment -- the fused row
                     // loop keeps neither in its registers
@@ -1903,8 +1785,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         }
         if (hdr_now)
             DVDA_HSTAMP(4);
-        if (!WSPEC && !__any(active))
-            break;                     // (two-wave layout: the block leaves together, at the exchange)
+        if (!__any(active))
+            break;
         DVDA_STAMP(0);
 
         // ====================================================== row phase
@@ -1948,7 +1830,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                           "=v"(p2.x), "=v"(p2.y), "=v"(p2.z), "=v"(p2.w), "=v"(p3.x), "=v"(p3.y), "=v"(p3.z), "=v"(p3.w));
         bool flush = false;               // this row completes a staged group of OUT_ROWS frames
         const uint32_t frames_before = frames_done;      // (sequential pass: did this turn close an access unit?)
-        uint32_t flush_tile = 0;          // ... in this tile (wave-uniform)
         uint64_t flush_row = 0;
         if constexpr (DUO) {
             if (pfx)
@@ -1968,15 +1849,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         DVDA_STAMP(1);
 
         uint32_t bypass_bits = 0;
-        int32_t val[WSPEC ? 1 : NS];
-        // two-wave layout: this lane's row in the tile pair -- row r lives in tile (r / OUT_ROWS) & 1, for the
-        // wave that writes it and, OUT_ROWS turns later, for the wave that picks it up (wave-uniform: every
-        // active lane of a wave is at the same row)
-        const uint32_t xslot = rows_done & (OUT_ROWS - 1);
-        int32_t *const xtile = &s_out[WSPEC ? ws_grp * 2u + ((rows_done / OUT_ROWS) & 1u) : 0][0][0][WSPEC ? lane : 0];
-        const uint32_t xstride = (ILV && ilv_direct) ? 64u : (uint32_t)OUT_ROWS * 64u;       // channel to channel
-        int32_t *const xrow = xtile + ((ILV && ilv_direct) ? xslot * (6u * 64u) : xslot * 64u);
-        int32_t *const xw_mine = xrow + min_ch * xstride;
+        int32_t val[NS];
         // ONE version of the slot loop for every wave (round 5).  A slot's body -- symbol, filter, history shift -- runs under
         // the execution mask of the lanes that carry the slot (the compiler's s_and_saveexec around an `if`), so nothing in
         // it selects lane by lane; a slot no lane carries is skipped.  (Rounds 1-4 ran every slot for every lane and
@@ -2043,8 +1916,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                         }
                     }
                 }
-                if constexpr (!WSPEC)
-                    val[k] = 0;
+                val[k] = 0;
                 if (k >= 2 && !__any(in))
                     continue;
                 if (in) {
@@ -2135,11 +2007,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                                  (int32_t)((uint32_t)value - (uint32_t)ssum));
                 }
                 }
-                if constexpr (WSPEC) {
-                    xw_mine[k * xstride] = value;     // straight into the tile
-                } else {
-                    val[k] = value;
-                }
+                val[k] = value;
                 }       // (the lanes that carry the slot)
             }
             rd.pos = cpos;
@@ -2150,7 +2018,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             DVDA_STAMP(2);
         };
         auto row_tail = [&](int32_t (&ch)[MAXCH]) {
-            if (owner && (!adopt || active)) {
+            if (owner) {
                 if (GENERAL) {
                     // ---- general pass: park the filtered frame; it is rematrixed at the end of
                     //      the access unit with the parameters its last block leaves
@@ -2184,15 +2052,13 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     //      the frame phase is the same in every lane
                     const uint32_t ph = rows_done & (OUT_ROWS - 1);
                     int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] =
-                        s_out[GENERAL ? 0 : (WSPEC ? ws_grp * 2u + ((rows_done / OUT_ROWS) & 1u) : wv)];
-                    if constexpr (WSPEC)
-                        flush_tile = ws_grp * 2u + ((rows_done / OUT_ROWS) & 1u);
+                        s_out[GENERAL ? 0 : wv];
                     if (ILV && ilv_direct) {
                         int32_t *Td = &T[0][0][GENERAL ? 0 : lane] + ph * (6 * 64);
 #pragma unroll
                         for (int c = 0; c < 6; c++)
                             Td[c * 64] = ch[c];
-                    } else if constexpr (!(PARSE && PAIRED)) {       // (chain parse pass in lane pairs: already there)
+                    } else {
 #pragma unroll
                         for (int c = 0; c < TP; c++)
                             T[c][ph][GENERAL ? 0 : lane] = ch[c];
@@ -2381,75 +2247,12 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         };
         // ---- the frame's channels 0..7 come together for the rematrix
         int32_t ch[MAXCH];
-        // (two-wave layout: the lane that rematrixes starts OUT_ROWS turns late, for good)
-        const bool in_row = active && (!HDR_GATE || (rows_left != 0 && (!DUO || P0.rows_left != 0))) && (!adopt || it >= (uint32_t)OUT_ROWS);
-        if constexpr (WSPEC) {
-            if (in_row)
-                row_head_any();
-            if (lends) {
-                // ---- this turn's row of the other lane's tile: there or not, what it is rematrixed with
-                s_tag[WSPEC ? ws_grp : 0][(it / OUT_ROWS) & 1u][it & (OUT_ROWS - 1)][WSPEC ? lane : 0] =
-                    in_row ? (0x80000000u | (par_pub << 8) | (bypass_bits & 0xFFu)) : 0u;
-            }
-            if (in_row) {
-                if (adopt) {
-                    // ---- the other lane's row: is it there at all, its bypassed LSBs, its parameters
-                    const uint32_t tagw = s_tag[WSPEC ? ws_grp : 0][(rows_done / OUT_ROWS) & 1u][xslot][WSPEC ? lane : 0];
-                    bypass_bits = tagw & 0xFFu;
-                    const uint32_t ver = (tagw >> 8) & 0xFFFFu;
-                    if (!(tagw >> 31)) {
-                        active = false;                  // it stopped (its status says why): no more output
-                        atomicAdd(&s_nchained[wv], 1u);      // (gone with it: one lane less that keeps the wave)
-                    } else if (__builtin_expect(ver != (par_seen & 0xFFFFu), 0)) {
-                        const uint32_t *P = &s_par[WS_BAL ? ws_grp : 0][ver & 1u][0][WS_BAL ? lane & (SPL - 1) : 0];
-                        constexpr int PS = WS_BAL ? SPL : 1;
-                        if (P[0])
-                            seed = P[1 * PS];
-                        par_seen = (par_seen & ~0xFFFFu) | ver;
-                        const uint32_t w2 = P[2 * PS];
-                        noise_shift = w2 & 0xFFu;
-                        matrix_len = (w2 >> 8) & 0xFFu;
-                        mmc_A = w2 >> 16;
-                        outch_pack = P[3 * PS];
-                        qss_A = P[4 * PS];
-                        oshift_pack = P[5 * PS];
-#pragma unroll
-                        for (int m = 0; m < 2; m++) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                mreg[m][j] = P[(6 + m * 4 + j) * PS];
-                            mnoise[m] = P[(14 + m) * PS];
-                        }
-                    }
-                }
-                if (owner) {
-#pragma unroll
-                    for (int c = 0; c < MAXCH; c++)
-                        ch[c] = c < 6 ? xrow[(c < 6 ? c : 0) * xstride] : 0;
-                }
-                row_tail(ch);
-            }
-        } else if (in_row) {
+        const bool in_row = active && (!HDR_GATE || (rows_left != 0 && (!DUO || P0.rows_left != 0)));
+        if (in_row) {
             row_head_any();
-            if (PAIRED && PARSE) {
-                // substreams of one segment sit in adjacent lanes; the residuals go straight into the tile column of
-                // the lane that flushes it (the last substream's: the odd lane of a two-substream segment)
-                const int col = (lane & ~1) + (S == 2u ? 1 : 0);
-                int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
-                const uint32_t ph = rows_done & (OUT_ROWS - 1);
-#pragma unroll
-                for (int k = 0; k < NS; k++)
-                    if ((uint32_t)k < nslots && min_ch + k < (uint32_t)TP)
-                        T[(min_ch + k) < (uint32_t)TP ? min_ch + k : 0][ph][GENERAL ? 0 : col] = val[k];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int c = 0; c < MAXCH; c++)
-                    ch[c] = 0;
-            } else if (PAIRED) {
-                // substreams of one segment sit in adjacent lanes; exchange through LDS
-                const int slot0 = PAIRED ? (lane & ~1) : 0;
+            if (PAIRED) {
+                // (sequential pass) substreams of one segment sit in adjacent lanes; exchange through LDS
+                const int slot0 = lane & ~1;
                 int32_t(*X)[XCH ? 64 : 1] = s_xch[XCH ? wv : 0];
 #pragma unroll
                 for (int k = 0; k < NS; k++)
@@ -2487,7 +2290,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
 
         // ---- the prefetched chunk lands in the ring
 #if defined(DVDA_EXP_STAMP)
-        if (!WSPEC) {       // (diagnostic: the wait for the chunk as a share of its own)
+        {                   // (diagnostic: the wait for the chunk as a share of its own)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DVDA_STAMP(6);
         }
@@ -2526,9 +2329,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         //      q mod 6 of lane q / 6's run, q = 64 i + l in the i-th of six instructions: an instruction covers ten
         //      or eleven runs whole.
         bool coop_out = false;
-        // (not in the two-wave kernel: there the wave that flushes is the one that sets the pace, and the flush's extra
-        //  instructions cost it 7 %)
-        if constexpr (ILV && !GENERAL && !PARSE && !WSPEC) {
+        if constexpr (ILV && !GENERAL && !PARSE) {
             if (!WAVO && ilv_direct && a.wav_bits == 0u && a.coop_min_seg && n_seg >= a.coop_min_seg)
                 coop_out = __ballot(flush) == ~0ull;
         }
@@ -2538,7 +2339,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             const uint64_t doff = out_base + flush_row * 6u;
             const bool off32 = !__any((doff >> 32) != 0);
             const uint32_t d_lo = (uint32_t)doff, d_hi = (uint32_t)(doff >> 32);
-            const int32_t *const T0 = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][0];
+            const int32_t *const T0 = &s_out[GENERAL ? 0 : wv][0][0][0];
             // lane l stores piece l mod 6 of the run of lane 10 i + l / 6 in the i-th of seven instructions (lanes 60..63
             // rest): ten whole runs side by side per instruction, and the lane's part of the addresses -- l / 6, l mod 6 --
             // is the same in every one of them
@@ -2562,10 +2363,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
         }
         if (!GENERAL && !PARSE && ILV && flush && !coop_out) {
             // ---- frame-major: the OUT_ROWS frames are OUT_ROWS * channels consecutive values
-            const int32_t *Tl = &s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)][0][0][GENERAL ? 0 : lane];
+            const int32_t *Tl = &s_out[GENERAL ? 0 : wv][0][0][GENERAL ? 0 : lane];
             int32_t *dst = a.pcm + out_base + flush_row * nch_out;
             // (the one-lane int32 frame-major instance has handed the payload to its WAVO twin; every other instance
-            //  -- two-wave, sequential -- still writes it itself)
+            //  -- two-substream lane, sequential -- still writes it itself)
             constexpr bool WAV_ELSEWHERE = !PAIRED && !WAVO && !DUO;
             if (WAVO || (!WAV_ELSEWHERE && __builtin_expect(a.wav_bits != 0, 0))) {
                 // ---- the WAV payload itself (SURVEY 8(f-3) fused into the decode): the OUT_ROWS frames are
@@ -2648,18 +2449,16 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
-        // (chain parse pass: do all lanes -- or, in lane pairs, all odd / all even lanes -- complete a line this turn?  The usual
-        //  case: lanes advance row by row together.  Then the lines' channel pieces leave in line order, below)
-        uint32_t coop_flush = 0;
-        if constexpr (PARSE && !GENERAL) {
-            const uint64_t fm = __ballot(flush);
-            coop_flush = fm == ~0ull ? 1u : (PAIRED && fm == 0xAAAAAAAAAAAAAAAAull) ? 2u : (PAIRED && fm == 0x5555555555555555ull) ? 3u : 0u;
-        }
+        // (chain parse pass: do all lanes complete a line this turn?  The usual case: lanes advance row by row together.
+        //  Then the lines' channel pieces leave in line order, below)
+        bool coop_flush = false;
+        if constexpr (PARSE && !GENERAL)
+            coop_flush = __ballot(flush) == ~0ull;
         if (PARSE && flush) {
             // ---- chain parse pass: four PCM frames of all eight planes are ONE 128-byte line of the segment's
             //      workspace ([row / 4][plane][row % 4], res_index()): the lane writes it whole, the filter pass's
             //      lanes of a chain read it together, the rematrix pass reads it once
-            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
             int32_t *dst = a.res + out_base + (flush_row >> 2) * 32u;
             if (!DVDA_RANGE_OK(out_base + (flush_row >> 2) * 32u, 32, a.caps.res, BT_RES))
                 dst = a.res;
@@ -2683,12 +2482,10 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                     dsrc = a.res;
                 const uint32_t d_lo = (uint32_t)(uintptr_t)dsrc, d_hi = (uint32_t)((uintptr_t)dsrc >> 32);
                 const int32_t *const T0 = &s_out[wv][0][0][0];
-                const uint32_t n_it = coop_flush == 1u ? 6u : 3u;
-                for (uint32_t it6 = 0; it6 < n_it; it6++) {
+                for (uint32_t it6 = 0; it6 < 6u; it6++) {
                     const uint32_t q = it6 * 64u + (uint32_t)lane;
-                    const uint32_t o6 = (q * 43691u) >> 18;              // q / 6 for q < 384
-                    const uint32_t pc = q - o6 * 6u;
-                    const uint32_t o = coop_flush == 1u ? o6 : 2u * o6 + (coop_flush == 2u ? 1u : 0u);
+                    const uint32_t o = (q * 43691u) >> 18;               // q / 6 for q < 384
+                    const uint32_t pc = q - o * 6u;
                     const uint32_t b_lo = (uint32_t)__shfl((int)d_lo, (int)o, 64), b_hi = (uint32_t)__shfl((int)d_hi, (int)o, 64);
                     int32_t *const od = reinterpret_cast<int32_t *>(((uint64_t)b_hi << 32) | b_lo) + pc * 4u;
                     const int32_t *const Tp = T0 + pc * (OUT_ROWS * 64) + o;
@@ -2700,7 +2497,7 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
             }
         }
         if (!GENERAL && !PARSE && !ILV && flush) {
-            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[WSPEC ? flush_tile : (GENERAL ? 0 : wv)];
+            int32_t(*T)[OUT_ROWS][GENERAL ? 1 : 64] = s_out[GENERAL ? 0 : wv];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 if ((uint32_t)c < nch_out) {
@@ -2723,23 +2520,6 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
                 }
             }
         }
-        if constexpr (WSPEC) {
-            // ---- end of a phase: the rows written in it are there for the wave behind, the tile flushed in it
-            //      is free for the wave in front; the block leaves together when no wave has a lane left
-            if ((it & (OUT_ROWS - 1)) == OUT_ROWS - 1) {
-                const uint32_t ph = (it / OUT_ROWS) & 1u;
-                const uint32_t wave_alive = __any(active) ? 1u : 0u;
-                if (lane == 0)
-                    s_alive[ph][wv] = wave_alive;
-                // LDS only: the chunk in flight and the PCM stores are not waited for
-                DVDA_STAMP(4);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                DVDA_STAMP(6);      // waiting at the phase barrier
-                if (!__any(lane < WAVES && s_alive[ph][lane < WAVES ? lane : 0] != 0))
-                    break;
-            }
-            it++;
-        }
         DVDA_STAMP(4);
     }
 
@@ -2747,8 +2527,8 @@ __global__ __launch_bounds__((PAIRED && !GENERAL && !PARSE) ? WS_THREADS : DEC_T
     DVDA_STAMP(4);
     if (lane == 0 && a.dbg)
         for (int i = 0; i < 8; i++)
-            atomicAdd(&a.dbg[i + (WSPEC ? 8 * (int)ws_last : 0)], stamp_acc[i]);      // two-wave layout: per role
-    if (!WSPEC && lane == 0 && a.dbg)
+            atomicAdd(&a.dbg[i], stamp_acc[i]);
+    if (lane == 0 && a.dbg)
         for (int i = 0; i < 5; i++)
             atomicAdd(&a.dbg[8 + i], hstamp_acc[i]);
 #endif

@@ -58,9 +58,6 @@ static hipError_t ws_malloc(void **p, size_t bytes)
 
 struct dvda_mlp_hip_ctx {
     int device;
-    bool duo_parse;            // (DVDA_DUO=1: the fast pass only, =2: the parse pass only -- diagnostic)
-    bool duo;                  // two-substream streams: one lane reads both substreams (k_decode<.., DUO>); false (DVDA_DUO=0,
-                               // diagnostic): the round 1-5 layouts -- a wave per substream in the fast pass, lane pairs in the parse pass
     uint32_t coop_min_seg;     // DecodeArgs::coop_min_seg: 1.75 waves per SIMD of this device (measured: slower at 1.5, 4.5 % faster at 2) (DVDA_COOP_MIN_SEG overrides: diagnostic)
     uint32_t max_streams, max_segments;
     // index workspace
@@ -256,9 +253,6 @@ extern "C" int dvda_mlp_hip_create(dvda_mlp_hip_ctx **out, int device, uint32_t 
         c->coop_min_seg = (uint32_t)cus * 4u * 64u * 7u / 4u;
         if (const char *e = getenv("DVDA_COOP_MIN_SEG"))
             c->coop_min_seg = (uint32_t)strtoul(e, nullptr, 10);
-        const int duo_env = getenv("DVDA_DUO") ? atoi(getenv("DVDA_DUO")) : 3;
-        c->duo = (duo_env & 1) != 0;
-        c->duo_parse = (duo_env & 2) != 0;
     }
     c->max_streams = max_streams;
     c->max_segments = max_segments;
@@ -828,9 +822,9 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
                            c->d_seg_status, c->d_seg_rows, c->d_yield, c->d_seg_meta, c->max_segments);
     }
     c->decoded = true;
-    // which kernels: one lane per segment for the streams with one substream, the two-wave layout for those
-    // with two -- both unless the caller forced one; a kernel whose class is absent from the batch (the
-    // index knows) exits at once
+    // which kernels: one lane per segment either way -- the one-substream kernel and the one whose lane reads both
+    // substreams of its segment (DUO) -- both unless the caller forced the first; a kernel whose class is absent from
+    // the batch (the index knows) exits at once
     // (64: always the wave-cooperative kernel; 0: the device picks it for small batches -- coop_takes() -- and the
     //  lane kernels for everything else; 1 / 2 force a lane kernel)
     // (3: the lane kernels, picked per batch as under 0, but never the cooperative kernel)
@@ -838,13 +832,12 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     const bool coop_only = c->lanes_per_seg == 64 || (c->lanes_per_seg == 0 && c->small_input);
     const bool lanes_only = c->lanes_per_seg == 3;
     const uint32_t force = (coop_only || lanes_only) ? 0u : c->lanes_per_seg;
-    // (DUO: the two-substream kernel decodes two-substream streams only, so "2" runs both lane kernels, each on its class)
-    const bool run1 = (force != 2 || c->duo) && !coop_only, run2 = force != 1 && !coop_only;
+    // (1: the one-substream lane kernel for every stream -- a two-substream stream is then an envelope error; 2 and 3: both
+    //  lane kernels, each on its class of streams -- the two-substream kernel decodes two-substream streams only)
+    const bool run1 = !coop_only, run2 = force != 1 && !coop_only;
     a.coop = coop_only ? 64u : lanes_only ? 3u : force;
     const uint64_t ms = c->max_segments;
     const unsigned blocks1 = (unsigned)((ms + DEC_THREADS - 1) / DEC_THREADS);            // one lane per segment
-    const unsigned blocks2 = (unsigned)((2 * ms + DEC_THREADS - 1) / DEC_THREADS);        // lane pairs
-    const unsigned ws_blocks = (unsigned)((2 * ms + WS_THREADS - 1) / WS_THREADS);        // fast pass, two waves
 
     const uint32_t slot = (uint32_t)(c->ev_count % EV_RING);
     HIP_TRY(hipEventRecord(c->ev[2 * slot], st));
@@ -862,18 +855,13 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         else
             hipLaunchKernelGGL((k_decode<6, false, false>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
     }
-    if (run2 && c->duo) {
+    if (run2) {
+        // two-substream streams: one lane reads both substreams of its segment (k_decode<.., DUO>)
         a.only_S = 2u;
         if (a.interleaved)
             hipLaunchKernelGGL((k_decode<6, false, false, true, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
         else
             hipLaunchKernelGGL((k_decode<6, false, false, false, false, true>), dim3(blocks1), dim3(DEC_THREADS), 0, st, a);
-    } else if (run2) {
-        a.only_S = force ? 0u : 2u;
-        if (a.interleaved)
-            hipLaunchKernelGGL((k_decode<WS_SLOTS, true, false, true>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
-        else
-            hipLaunchKernelGGL((k_decode<WS_SLOTS, true, false>), dim3(ws_blocks), dim3(WS_THREADS), 0, st, a);
     }
     HIP_TRY(hipEventRecord(c->ev[2 * slot + 1], st));
     c->ev_count++;
@@ -956,18 +944,14 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
         if (coop_parse) {
             hipLaunchKernelGGL(k_coop<true>, dim3(segs), dim3(COOP_THREADS), 0, st, a);
         } else {
-            if (force != 2 || c->duo_parse) {
+            {
                 a.only_S = (force == 1) ? 0u : 1u;
                 hipLaunchKernelGGL((k_decode<6, false, false, false, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
                                    dim3(DEC_THREADS), 0, st, a);
             }
-            if (force != 1 && c->duo_parse) {
+            if (force != 1) {
                 a.only_S = 2u;
                 hipLaunchKernelGGL((k_decode<6, false, false, false, true, true>), dim3((segs + DEC_THREADS - 1) / DEC_THREADS),
-                                   dim3(DEC_THREADS), 0, st, a);
-            } else if (force != 1) {
-                a.only_S = force ? 0u : 2u;
-                hipLaunchKernelGGL((k_decode<6, true, false, false, true>), dim3((2 * segs + DEC_THREADS - 1) / DEC_THREADS),
                                    dim3(DEC_THREADS), 0, st, a);
             }
         }
@@ -1033,7 +1017,6 @@ static int decode_body(dvda_mlp_hip_ctx *c, int32_t *d_pcm, const uint64_t *d_ou
     if (!blocking || c->h_summary->chain_segs || n_seq || c->h_summary->waiting)
         hipLaunchKernelGGL(k_finalize, fgrid, dim3(256), 0, st, c->d_seg, c->d_seg_fbase, c->d_seg_status, c->d_seg_rows,
                            c->d_streams, c->n_streams, c->d_summary, c->d_seq_list, 0u, 1u);
-    (void)blocks2;
     HIP_TRY(hipEventRecord(c->ev_end[slot], st));
     HIP_TRY(hipGetLastError());
     return DVDA_HIP_OK;
