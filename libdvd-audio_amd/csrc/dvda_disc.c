@@ -783,6 +783,7 @@ struct win_slot {
     uint8_t *host;              /* pinned: int32 frames [frame][channel], or the packed WAV payload */
     size_t cap;
     uint64_t frames;
+    uint64_t stride;            /* != 0: int32 PLANAR [channel][stride] (raw-PCM windows: the order the un-swizzle writes) */
 };
 
 struct mlp_windows {
@@ -794,6 +795,14 @@ struct mlp_windows {
     int wav_request, wav_decided;   /* the opener asked for the payload; decided (from the first window's major sync:
                                        only a 16- or 24-bit stream is decoded straight into it) */
     int started, finished, failed;
+    /* a raw-PCM track read in windows (round 6): sectors decode independently of each other (src/pcm.c:149: whole chunks
+       per packet), so a window is a run of sectors and nothing crosses a cut but the count of frames delivered so far */
+    int is_pcm;
+    unsigned pcm_bits, pcm_channels;
+    uint64_t pcm_want;          /* the track's length in PCM frames (its PTS length); whole packets until it is covered */
+    uint64_t pcm_done;
+    uint8_t *pack_tmp;          /* host: a planar window packed for dvda_hip_reader_wav_next() on an int32 reader */
+    size_t pack_cap;
     uint8_t *carry;             /* host: bytes from the last cut on */
     size_t carry_len, carry_cap;
     int32_t fir[2 * 48];
@@ -954,6 +963,7 @@ static void windows_free(struct mlp_windows *w)
         c->slot[i].frames = 0;
     }
     free(w->whole);
+    free(w->pack_tmp);
     aob_close_all(&w->aobs);
     pthread_mutex_destroy(&w->mu);
     pthread_cond_destroy(&w->cv);
@@ -1011,6 +1021,7 @@ static int win_index(struct mlp_windows *w, uint64_t len, uint32_t *n_seg)
 static int win_produce(struct mlp_windows *w, struct win_slot *out)
 {
     out->frames = 0;
+    out->stride = 0;
     unsigned extra = 8;
     for (;;) {
         const int has_track = w->next <= w->last;
@@ -1217,6 +1228,129 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
     }
 }
 
+/* One window of a raw-PCM track into `out` (reference: src/dvd-audio.c:1017-1083 decode_pcm_audio packet by packet,
+ * src/pcm.c:99-193): the next run of sectors -> device -> k_pcm_scan / k_pcm_unswizzle_t -> the pinned slot, planar int32
+ * or the packed payload.  Whole packets are delivered until the track's PTS length is covered (open_pcm's rule); a
+ * track that spills over its sector range reads on.  1 = ok (out->frames may be 0), 0 = failure. */
+static int win_produce_pcm(struct mlp_windows *w, struct win_slot *out)
+{
+    out->frames = 0;
+    out->stride = 0;
+    const unsigned bits = w->pcm_bits, ch = w->pcm_channels;
+    unsigned want = w->window;
+    if (w->next >= w->aobs.total) {
+        w->p_final = 1;
+        return w->started;
+    }
+    if (w->next + want > w->aobs.total || w->next + want < w->next)
+        want = w->aobs.total - w->next;
+    if (want > w->cap_sec) {
+        if (w->h_sec) {
+            (void)hipHostFree(w->h_sec);
+            w->host_now -= w->cap_sec * SECTOR;
+        }
+        (void)hipFree(w->d_sec);
+        (void)hipFree(w->d_work);
+        free(w->h_base);
+        w->h_sec = w->d_sec = NULL;
+        w->d_work = w->h_base = NULL;
+        w->cap_sec = 0;
+        const size_t cap = (size_t)want * SECTOR;
+        if (hipHostMalloc((void **)&w->h_sec, cap, hipHostMallocDefault) != hipSuccess)
+            return 0;
+        win_host_add(w, cap);
+        if (!dev_alloc((void **)&w->d_sec, cap) ||
+            !dev_alloc((void **)&w->d_work, dvda_pcm_hip_workspace_words(want) * sizeof(uint32_t)) ||
+            (w->h_base = malloc(((size_t)want + 1) * sizeof(uint32_t))) == NULL)
+            return 0;
+        w->cap_sec = want;
+    }
+    const unsigned got = aob_read(&w->aobs, w->next, want, w->h_sec);
+    if (!got) {
+        w->p_final = 1;
+        return w->started;                       /* the files end: what was delivered stands */
+    }
+    /* a sector holds at most 2013 payload bytes: upper bound of the PCM frames */
+    uint64_t stride = (uint64_t)got * (2013 / (ch * (bits / 8) * 2)) * 2;
+    stride = (stride + 3) & ~(uint64_t)3;
+    uint64_t total = 0;
+    uint32_t bad = 0;
+    if (!win_grow_dev((void **)&w->d_pcm, &w->cap_pcm, stride * ch * sizeof(int32_t)) ||
+        hipMemcpy(w->d_sec, w->h_sec, (size_t)got * SECTOR, hipMemcpyHostToDevice) != hipSuccess ||
+        dvda_pcm_hip_decode_sectors(w->d_sec, got, bits, ch, w->d_pcm, stride, w->d_work, NULL) != DVDA_HIP_OK ||
+        dvda_pcm_hip_result(w->d_work, got, &total, &bad, NULL) != DVDA_HIP_OK ||
+        hipMemcpy(w->h_base, w->d_work + got, ((size_t)got + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return 0;
+    (void)bad;                                   /* (open_pcm: foreign sectors contribute nothing) */
+    uint64_t deliver = total;
+    int final = 0;
+    if (w->pcm_want == 0) {
+        deliver = w->h_base[1] < total ? w->h_base[1] : total;      /* the opening packet is decoded regardless */
+        final = 1;
+    } else {
+        for (unsigned s = 0; s < got; s++) {
+            if (w->pcm_done + w->h_base[s + 1] >= w->pcm_want) {
+                deliver = w->h_base[s + 1];
+                final = 1;
+                break;
+            }
+        }
+    }
+    w->next += got;
+    w->started = 1;
+    if (!final && (got < want || w->next >= w->aobs.total))
+        final = 1;                               /* the files end inside the track */
+    if (deliver) {
+        if (w->wav_bits) {
+            const size_t bytes = (size_t)deliver * ch * (bits / 8);
+            if (!win_grow_dev((void **)&w->d_stream, &w->cap_stream, bytes + 64) ||
+                dvda_mlp_hip_pack_wav(w->d_pcm, stride, ch, deliver, bits, w->d_stream, NULL) != DVDA_HIP_OK)
+                return 0;
+            if (bytes > out->cap) {
+                if (out->host) {
+                    (void)hipHostFree(out->host);
+                    w->host_now -= out->cap;
+                }
+                out->host = NULL;
+                out->cap = bytes + bytes / 4 + 4096;
+                if (hipHostMalloc((void **)&out->host, out->cap, hipHostMallocDefault) != hipSuccess) {
+                    out->cap = 0;
+                    return 0;
+                }
+                win_host_add(w, out->cap);
+            }
+            if (hipMemcpy(out->host, w->d_stream, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+                return 0;
+        } else {
+            const size_t bytes = (size_t)deliver * ch * sizeof(int32_t);
+            if (bytes > out->cap) {
+                if (out->host) {
+                    (void)hipHostFree(out->host);
+                    w->host_now -= out->cap;
+                }
+                out->host = NULL;
+                out->cap = bytes + bytes / 4 + 4096;
+                if (hipHostMalloc((void **)&out->host, out->cap, hipHostMallocDefault) != hipSuccess) {
+                    out->cap = 0;
+                    return 0;
+                }
+                win_host_add(w, out->cap);
+            }
+            /* the window's frames of every channel, the planes packed to `deliver` frames each */
+            if (hipMemcpy2D(out->host, (size_t)deliver * sizeof(int32_t), w->d_pcm, (size_t)stride * sizeof(int32_t),
+                            (size_t)deliver * sizeof(int32_t), ch, hipMemcpyDeviceToHost) != hipSuccess)
+                return 0;
+            out->stride = deliver;
+        }
+        out->frames = deliver;
+    }
+    w->pcm_done += deliver;
+    w->p_frames += deliver;
+    w->p_final = final;
+    win_dev_sample(w);
+    return 1;
+}
+
 /* publishes what the last win_produce() left (the caller holds w->mu, or no consumer exists yet) */
 static void win_commit(struct mlp_windows *w)
 {
@@ -1247,7 +1381,7 @@ static void *win_thread(void *arg)
         }
         struct win_slot *out = &w->slot[w->head];
         pthread_mutex_unlock(&w->mu);
-        const int ok = win_produce(w, out);
+        const int ok = w->is_pcm ? win_produce_pcm(w, out) : win_produce(w, out);
         pthread_mutex_lock(&w->mu);
         win_commit(w);                          /* status, frames and "finished" together with the window itself */
         if (!ok)
@@ -1479,6 +1613,105 @@ done:
     return r;
 }
 
+/* A raw-PCM track of more sectors than a window: read, un-swizzled and handed out window by window (round 6; the
+ * reference streams a track of any length packet by packet, src/dvd-audio.c:752-795, 1017-1083).  The first window in
+ * the opener's thread, the rest by the producer thread into the two pinned slots: what the reader holds is bounded by
+ * the window, not by the track. */
+static DVDA_Track_Reader *open_pcm_windowed(const DVDA_Track *k, const uint8_t *params)
+{
+    struct mlp_windows *w = calloc(1, sizeof(*w));
+    DVDA_Track_Reader *r = calloc(1, sizeof(*r));
+    size_t tot = 0;
+    if (!w || !r) {
+        free(w);
+        free(r);
+        return NULL;
+    }
+    pthread_mutex_init(&w->mu, NULL);
+    pthread_cond_init(&w->cv, NULL);
+    r->win = w;
+    r->codec = DVDA_PCM;
+    r->bps_code[0] = params[3] >> 4;
+    r->bps_code[1] = params[3] & 15;
+    r->rate_code[0] = params[4] >> 4;
+    r->rate_code[1] = params[4] & 15;
+    r->assignment = params[6];
+    r->channels = channels_of(r->assignment);
+    r->interleaved = 1;
+    const unsigned bits = bits_of(r->bps_code[0]), rate = rate_of(r->rate_code[0]);
+    w->device = g_device;
+    w->is_pcm = 1;
+    w->first = w->next = k->s.first;
+    w->last = k->s.last >= k->s.first ? k->s.last : k->s.first;
+    w->window = window_sectors();
+    if (!r->channels || (bits != 16 && bits != 24) || !rate)
+        goto fail;
+    w->pcm_bits = bits;
+    w->pcm_channels = r->channels;
+    w->pcm_want = (uint64_t)lround((double)k->s.pts_length * (double)rate / DVDA_HIP_PTS_PER_SECOND);
+    w->wav_request = g_wav_output ? 1 : 0;
+    w->wav_bits = w->wav_request ? (int)bits : 0;
+    w->wav_decided = 1;
+    {
+        /* the buffers the thread's last windowed reader left serve this one too (same device) */
+        struct win_cache *c = &t_win_cache;
+        if (c->valid && c->device != w->device)
+            win_cache_free(c);
+        if (c->valid) {
+            w->ctx = c->ctx;
+            w->ctx_segs = c->ctx_segs;
+            w->h_sec = c->h_sec;
+            w->d_sec = c->d_sec;
+            w->d_mlp = c->d_mlp;
+            w->d_stream = c->d_stream;
+            w->carry = c->carry;
+            w->d_work = c->d_work;
+            w->h_base = c->h_base;
+            w->d_meta = c->d_meta;
+            w->d_pcm = c->d_pcm;
+            w->d_fir = c->d_fir;
+            w->cap_sec = c->cap_sec;
+            w->cap_stream = c->cap_stream;
+            w->cap_pcm = c->cap_pcm;
+            w->carry_cap = c->carry_cap;
+            for (int i = 0; i < WIN_SLOTS; i++)
+                w->slot[i] = c->slot[i];
+            w->host_now = w->host_peak = c->host_bytes;
+            w->dev_base = c->dev_bytes;
+            w->dev_peak = c->dev_bytes;
+            memset(c, 0, sizeof(*c));
+        }
+    }
+    (void)hipMemGetInfo(&w->dev_free0, &tot);
+    aob_open_all(&w->aobs, k->dir, k->titleset);
+    if (w->aobs.n == 0)
+        goto fail;
+    {
+        struct win_slot *out = &w->slot[0];
+        for (;;) {
+            const int ok = win_produce_pcm(w, out);
+            win_commit(w);                      /* (no consumer yet: no lock needed) */
+            if (!ok)
+                goto fail;
+            if (out->frames || w->finished)
+                break;
+        }
+        if (out->frames) {
+            w->head = 1 % WIN_SLOTS;
+            w->count = 1;
+        }
+    }
+    if (!w->finished) {
+        if (pthread_create(&w->th, NULL, win_thread, w) != 0)
+            goto fail;
+        w->th_started = 1;
+    }
+    return r;
+fail:
+    reader_free(r);
+    return NULL;
+}
+
 /* ------------------------------------------------------------------ track reader */
 DVDA_Track_Reader *dvda_hip_open_track_reader_on(const DVDA_Track *k, int device, int wav_output)
 {
@@ -1525,7 +1758,8 @@ DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *k)
             const unsigned in_track = k->s.last >= k->s.first ? k->s.last - k->s.first + 1 : 1;
             r = in_track > window_sectors() ? open_mlp_windowed(k) : open_mlp(&aobs, k);
         } else if (codec == CODEC_PCM && body_len >= 9 && pad2 >= 9) {
-            r = open_pcm(&aobs, k, body);
+            const unsigned in_track = k->s.last >= k->s.first ? k->s.last - k->s.first + 1 : 1;
+            r = in_track > window_sectors() ? open_pcm_windowed(k, body) : open_pcm(&aobs, k, body);
         }
         break;
     }
@@ -1608,6 +1842,15 @@ unsigned dvda_read(DVDA_Track_Reader *r, unsigned pcm_frames, int buffer[])
                 break;
             const uint64_t left = s->frames - w->served_in_slot;
             const unsigned n = left < pcm_frames - done ? (unsigned)left : pcm_frames - done;
+            if (s->stride) {
+                /* a raw-PCM window: planes of `stride` frames, interleaved here (src/dvd-audio.c:781-792) */
+                for (unsigned c = 0; c < r->channels; c++) {
+                    const int32_t *src = (const int32_t *)s->host + (size_t)c * s->stride + w->served_in_slot;
+                    int *dst = buffer + (size_t)done * r->channels + c;
+                    for (unsigned i = 0; i < n; i++)
+                        dst[(size_t)i * r->channels] = src[i];
+                }
+            } else
             memcpy(buffer + (size_t)done * r->channels,
                    (const int32_t *)s->host + (size_t)w->served_in_slot * r->channels, (size_t)n * r->channels * sizeof(int32_t));
             w->served_in_slot += n;
@@ -1663,6 +1906,31 @@ unsigned long long dvda_hip_reader_wav_next(DVDA_Track_Reader *r, const unsigned
     if (!s)
         return 0;
     const size_t nb = bits / 8;
+    if (!w->wav_bits && s->stride) {
+        /* a planar int32 window (raw PCM read without the payload option): packed into a buffer of its own */
+        const size_t bytes = (size_t)s->frames * r->channels * nb;
+        if (bytes > w->pack_cap) {
+            free(w->pack_tmp);
+            w->pack_cap = bytes + bytes / 4;
+            w->pack_tmp = malloc(w->pack_cap);
+            if (!w->pack_tmp) {
+                w->pack_cap = 0;
+                return 0;
+            }
+        }
+        const uint32_t sign = 1u << (bits - 1);
+        for (uint64_t i = 0; i < s->frames; i++)
+            for (unsigned c = 0; c < r->channels; c++) {
+                const int32_t v = ((const int32_t *)s->host)[(size_t)c * s->stride + i];
+                const uint32_t u = ((uint32_t)v & (sign - 1)) | (v < 0 ? sign : 0u);
+                for (size_t b = 0; b < nb; b++)
+                    w->pack_tmp[(i * r->channels + c) * nb + b] = (uint8_t)(u >> (8 * b));
+            }
+        w->served_in_slot = s->frames;
+        r->served += s->frames;
+        *payload = w->pack_tmp;
+        return (unsigned long long)bytes;
+    }
     if (!w->wav_bits) {
         /* int32 frames -> payload, in place (the packed form is shorter) */
         const int32_t *src = (const int32_t *)s->host;

@@ -206,6 +206,59 @@ def test_long_tracks_are_read_in_windows_of_bounded_memory(pkg, oracle, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bps_code,assignment", [(2, 12), (0, 1)])
+def test_long_raw_pcm_tracks_are_read_in_windows_of_bounded_memory(pkg, oracle, bps_code, assignment):
+    """A raw-PCM track of more sectors than a window is read, un-swizzled and handed out window by window (round 6;
+    csrc/dvda_disc.c open_pcm_windowed; reference: src/dvd-audio.c:752-795, 1017-1083 streams a track packet by packet,
+    src/pcm.c:99-193): sectors decode independently, so nothing crosses a cut but the count of frames delivered.
+    dvda_read() gives the samples that went in, the payload pieces their write_signed packing, the track after it
+    starts where this one's PTS length is covered, and what the reader holds does not grow with the track."""
+    disc = pkg.disc
+    ch = disc.CHANNELS[assignment]
+    bits = disc.BPS[bps_code]
+    peaks = {}
+    old = os.environ.get("DVDA_WINDOW_SECTORS")
+    os.environ["DVDA_WINDOW_SECTORS"] = "64"
+    try:
+        for n_sec in (400, 1200):
+            rng = np.random.RandomState(100 + n_sec)
+            per = (2048 - 14 - 6 - 7 - 9) // (2 * ch * (bits // 8)) * 2          # PCM frames a sector holds
+            frames = per * n_sec
+            pcm = rng.randint(-(1 << (bits - 1)), 1 << (bits - 1), size=(frames, ch))
+            secs = disc.pcm_track_sectors(pcm, bps_code, 1, assignment)
+            assert len(secs) == n_sec > 4 * 64
+            with tempfile.TemporaryDirectory() as tmp:
+                # a long track (windows) and a short one behind it (one batch): together the whole run of sectors
+                # (the cut at a multiple of eight sectors: the track's length is then a whole number of PTS ticks -- a
+                #  length that is not is rounded, and a track whose rounded length lies past its last sector takes the
+                #  next one's first packet as well, here as in the reference)
+                cut = n_sec - 24
+                ats = disc.write_disc_titles(tmp, [disc.split_tracks(secs, [cut], [cut * per, frames - cut * per], 1)])
+                a = pkg.discdec.read_track(ats, 1, 1, 1, chunk=3001)
+                z = pkg.discdec.read_track(ats, 1, 1, 2)
+                assert a["codec"] == "PCM" and a["bits"] == bits and a["channels"] == ch
+                assert a["windowed"] and not a["failed"] and not z["windowed"]
+                assert a["frames"] == len(a["pcm"]) == cut * per
+                assert np.array_equal(np.concatenate([a["pcm"], z["pcm"]]), pcm)
+                for fused in (False, True):
+                    w = pkg.discdec.read_track(ats, 1, 1, 1, wav=True, fused=fused, pieces=True)
+                    assert w["windowed"] and len(w["piece_sizes"]) >= 4 and not w["failed"]
+                    assert w["payload"] == oracle.wav_pack(a["pcm"].T, bits)
+                whole = pkg.discdec.read_track(ats, 1, 1, 1, wav=True, fused=True)
+                assert whole["payload"] == oracle.wav_pack(a["pcm"].T, bits)
+                peaks[n_sec] = (a["host_peak"], a["device_peak"], len(a["pcm"]) * ch * 4)
+        (h1, d1, p1), (h2, d2, p2) = peaks[400], peaks[1200]
+        assert p2 > 2.5 * p1
+        assert h2 <= 1.35 * h1 + (1 << 20) and d2 <= 1.35 * d1 + (8 << 20)
+        assert h2 < p2 / 2
+    finally:
+        if old is None:
+            del os.environ["DVDA_WINDOW_SECTORS"]
+        else:
+            os.environ["DVDA_WINDOW_SECTORS"] = old
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("damage", ["flipped_byte", "file_cut_short"])
 def test_windowed_reader_stops_at_a_damaged_window_and_says_so(pkg, oracle, damage):

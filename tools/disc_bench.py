@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--no-tier-b", action="store_true")
     ap.add_argument("--devices", default="", help="passed to dvda2wav_hip: comma-separated device entries, one worker "
                                                    "thread each (e.g. 0,0,0: three workers on one GPU)")
+    ap.add_argument("--pcm-sectors", type=int, default=0,
+                    help="instead of MLP tracks: ONE raw-PCM track (6 ch / 96 kHz / 24 bit) of this many sectors, read in "
+                         "windows of bounded memory when longer than one (1 050 000 sectors = 2.15 GB of AOB)")
     ap.add_argument("--chained", action="store_true",
                     help="tracks as an encoder writes them: no raw lead-in at the restart points, the FIR history runs "
                          "through each track (the chain passes decode them)")
@@ -47,6 +50,18 @@ def main():
         cfg = syn.make_cfg(assignment=12, rate_code=1, n_substreams=1, n_aus=a.aus, profile=1 if a.chained else 0,
                            features=syn.SF["CHAINED"] if a.chained else 0)
         tracks, samples = [], 0
+        if a.pcm_sectors:
+            import numpy as np
+            per = (2048 - 14 - 6 - 7 - 9) // 36 * 2
+            rng = np.random.RandomState(5)
+            # (a block of random sectors, repeated: the extractors do not care, and 10^6 sectors are not built one by one)
+            blk = 4096
+            secs = disc.pcm_track_sectors(rng.randint(-(1 << 23), 1 << 23, size=(per * blk, 6)), 2, 1, 12)
+            secs = (secs * ((a.pcm_sectors + blk - 1) // blk))[:a.pcm_sectors]
+            tracks.append({"sectors": secs, "pcm_frames": per * a.pcm_sectors, "rate_code": 1})
+            samples = per * a.pcm_sectors * 6
+            a.tracks = 0
+            a.no_tier_b = True
         for t in range(a.tracks):
             b, f = syn.stream(cfg, 100 + t)
             tracks.append({"sectors": disc.mlp_track_sectors(b), "pcm_frames": f, "rate_code": 1})
