@@ -4,14 +4,18 @@
  * The 27 entry points below have the names, argument meaning, 1-based numbering, NULL-on-failure
  * and ownership rules of the reference's public header (reference include/dvd-audio.h:59-201),
  * so a program written against that header -- utils/dvda2wav.c for one -- links against this
- * library unchanged.  What differs is the inside: opening a track reader reads the track's AOB
- * sectors once, uploads them, and runs ONE batch on the GPU
+ * library unchanged.  What differs is the inside: a track's AOB sectors are read, uploaded and decoded
+ * on the GPU in batches
  *
  *     sector walk + payload gather   (reference src/packet.c:61-188, src/dvd-audio.c:1151-1248)
  *     major-sync search, end-of-track rule            (src/dvd-audio.c:1167-1194, 1238-1421)
  *     MLP decode (tier A of dvda_mlp_hip.h)  /  PCM un-swizzle      (src/mlp.c, src/pcm.c:99-193)
  *
- * and dvda_read() then hands out slices of the decoded track.  There is no CPU decode path: a
+ * -- a track of at most DVDA_WINDOW_SECTORS sectors (default 8 192 = 16 MiB) as ONE batch when its reader is
+ * opened; a longer one, MLP or raw PCM, window by window: a producer thread reads, demultiplexes and decodes
+ * window k + 1 into one of two pinned buffers while dvda_read() / dvda_hip_reader_wav_next() hand out window k,
+ * so what a reader holds is bounded by the window, not by the track (the reference streams a track packet by
+ * packet, src/dvd-audio.c:752-795).  There is no CPU decode path: a
  * track reader cannot be opened without a HIP device.  CPPM-protected discs are not handled
  * (`device` is accepted and ignored; reference src/aob.c:109-127).
  */
@@ -59,7 +63,8 @@ unsigned dvda_track_pts_length(const DVDA_Track *track);
 unsigned dvda_track_first_sector(const DVDA_Track *track);
 unsigned dvda_track_last_sector(const DVDA_Track *track);
 
-/* ---- track reader (src/dvd-audio.c:586-794): the whole track is decoded when it is opened */
+/* ---- track reader (src/dvd-audio.c:586-794): a short track is decoded when its reader is opened, a long one in
+ *      windows while it is read (see the top of this file; dvda_hip_reader_windowed()) */
 DVDA_Track_Reader *dvda_open_track_reader(const DVDA_Track *track);
 void dvda_close_track_reader(DVDA_Track_Reader *reader);
 dvda_codec_t dvda_codec(const DVDA_Track_Reader *reader);
