@@ -34,6 +34,12 @@ import time
 
 import numpy as np
 
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
+# one run in submission order.  sub.host_to_host uses five streams that must not wait for each other (copy in, copy
+# out, three decodes): eight queues, set before the runtime starts.  Nothing else in this file has more than three
+# streams busy at once.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -855,19 +861,34 @@ def mixed_corpus(pkg, torch, dev, local_rank, args, steps, warmup):
 
 
 def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, steps, wav24=False):
-    """Pinned host bytes -> H2D -> index + decode -> D2H -> pinned host PCM, in sub-batches on three HIP
-    streams so that the copies of neighbouring sub-batches overlap the decode ('compressed
-    bytes resident in pinned host memory -> PCM resident in host memory').  Never `value`."""
+    """Pinned host bytes -> H2D -> index + decode -> D2H -> pinned host PCM ('compressed bytes resident in
+    pinned host memory -> PCM resident in host memory').  Never `value`.
+
+    Round 6: the two directions of the link on streams of their own -- every H2D copy on one stream, every D2H copy on
+    another -- and the index + decode of the sub-batches rotating over THREE compute streams (non-blocking decode
+    call: one host thread enqueues the whole pass; GPU_MAX_HW_QUEUES=8, see the top of this file), tied together
+    by events:  H2D(i) waits for the decode that last read its input buffer;  decode(i) waits for H2D(i) and for the
+    D2H that last read its PCM buffer;  D2H(i) waits for decode(i).  A sub-batch of 64 titles takes the lane kernel
+    one segment's time (~1.6 ms, a lone wave per SIMD) however few segments it holds, its copy back 0.9-1.2 ms: three
+    decodes in flight keep the link busy (two: 20.7 ms per pass, three: 18.3, four: 23.2 on one box whose link gave 17.0); the first two sub-batches are small (16 and 48 titles: the cooperative kernel's
+    size) so that the first copy back starts after 0.6 ms instead of 2.2.
+    (Rounds 3-5: 8 sub-batches on 3 streams, copy-in / decode / copy-out one after the other on each stream, a host
+    thread per stream: the two directions mostly took turns.)
+    `pcie_ceiling_GBs`: the same copies with nothing decoded and no event between them -- what this box's link gives with
+    both directions busy."""
     hip = pkg.hipdec
     n = len(sizes)
-    parts = 8 if n >= 64 else 1
-    per = n // parts
+    if n >= 256:
+        cuts = [0, 16, 64] + list(range(128, n, 64)) + [n]
+    else:
+        cuts = [0, n]
+    parts = len(cuts) - 1
     nch = 6
     layout = hip.PCM_WAV24 if wav24 else (hip.PCM_INTERLEAVED if args.layout == "interleaved" else hip.PCM_PLANAR)
     out_bytes = 3 if wav24 else 4
     slots = []
     for p in range(parts):
-        lo, hi = p * per, (p + 1) * per if p < parts - 1 else n
+        lo, hi = cuts[p], cuts[p + 1]
         b0 = int(offs[lo])
         b1 = int(offs[hi]) if hi < n else int(len(flat) - 64)
         h_in = torch.from_numpy(flat[b0:b1 + 64].copy()).pin_memory()
@@ -876,18 +897,18 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         oo = np.zeros(hi - lo, np.int64)
         oo[1:] = np.cumsum(words[:-1])
         tot = int(words.sum())
-        slots.append(dict(h_in=h_in, nbytes=b1 - b0, off=(offs[lo:hi].astype(np.int64) - b0), len=sizes[lo:hi].astype(np.int64),
+        slots.append(dict(lo=lo, h_in=h_in, nbytes=b1 - b0, off=(offs[lo:hi].astype(np.int64) - b0), len=sizes[lo:hi].astype(np.int64),
                           rows=rows, oo=oo, tot=tot, h_out=torch.empty(tot, dtype=torch.int32).pin_memory()))
-    NB = 3
+    NB = min(int(os.environ.get("DVDA_BENCH_H2H_BUFS", "6")), parts)
     bufs = []
     maxb = max(s["nbytes"] for s in slots) + 64
     maxt = max(s["tot"] for s in slots)
     maxn = max(len(s["len"]) for s in slots)
     nseg = maxn * ((args.aus + 7) // 8)
+    n_cs = int(os.environ.get("DVDA_BENCH_H2H_STREAMS", "3"))
     for _ in range(NB):
         bufs.append(dict(d_in=torch.zeros(maxb, dtype=torch.uint8, device=dev),
                          d_pcm=torch.empty(maxt, dtype=torch.int32, device=dev),
-                         st=torch.cuda.Stream(dev),
                          ctx=hip.Context(local_rank, maxn, nseg, lanes_per_segment=0, layout=layout)))
     for s in slots:     # the small per-stream tables live on the device (they are part of the request, not payload)
         s["d_off"] = torch.from_numpy(s["off"]).to(dev)
@@ -895,54 +916,108 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         s["d_oo"] = torch.from_numpy(s["oo"]).to(dev)
         s["d_rows"] = torch.from_numpy(s["rows"]).to(dev)
     torch.cuda.synchronize(dev)
+    # The pass's five streams and its events, made HERE with the runtime's own calls, one after the other: the runtime
+    # deals hardware queues to streams in the order they are made, and the streams of torch's pool were made long ago,
+    # between the streams of every context the sub-records before this one opened and closed -- two of the five then
+    # shared a queue and the decodes took turns (26 ms per pass behind the other sub-records, 18 ms in a run of its own).
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    vp, u32, sz = ctypes.c_void_p, ctypes.c_uint, ctypes.c_size_t
+    rt.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(vp), u32]
+    rt.hipStreamDestroy.argtypes = [vp]
+    rt.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(vp), u32]
+    rt.hipEventDestroy.argtypes = [vp]
+    rt.hipEventRecord.argtypes = [vp, vp]
+    rt.hipStreamWaitEvent.argtypes = [vp, vp, u32]
+    rt.hipMemcpyAsync.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    rt.hipDeviceSynchronize.argtypes = []
 
-    # one host thread per stream: dvda_mlp_hip_decode waits for its fast pass (the summary read-back), and a
-    # single thread would stop enqueueing the neighbouring sub-batches' copies while it waits
-    import threading
+    def chk(rc):
+        if rc != 0:
+            raise SystemExit("host_to_host: HIP runtime call failed (%d)" % rc)
 
-    def lane(t):
-        bf = bufs[t]
-        torch.cuda.set_device(dev)
-        with torch.cuda.stream(bf["st"]):
-            st = bf["st"].cuda_stream
-            for i in range(t, len(slots), NB):
-                s = slots[i]
-                bf["d_in"][:s["nbytes"] + 64].copy_(s["h_in"], non_blocking=True)
-                bf["ctx"].index(bf["d_in"].data_ptr(), s["nbytes"], s["d_off"].data_ptr(), s["d_len"].data_ptr(),
-                                len(s["len"]), st)
-                bf["ctx"].decode(bf["d_pcm"].data_ptr(), s["d_oo"].data_ptr(), s["d_rows"].data_ptr(), st)
-                s["h_out"].copy_(bf["d_pcm"][:s["tot"]], non_blocking=True)
-            bf["st"].synchronize()
+    def mk_stream():
+        h = vp()
+        chk(rt.hipStreamCreateWithFlags(ctypes.byref(h), 1))        # hipStreamNonBlocking
+        return h
+
+    def mk_event():
+        h = vp()
+        chk(rt.hipEventCreateWithFlags(ctypes.byref(h), 2))         # hipEventDisableTiming
+        return h
+
+    s_in, s_out = mk_stream(), mk_stream()
+    s_c = [mk_stream() for _ in range(n_cs)]
+    for bf in bufs:
+        bf["ev_in"], bf["ev_c"], bf["ev_out"] = mk_event(), mk_event(), mk_event()
+    H2D, D2H = 1, 2
 
     def one_pass():
-        ths = [threading.Thread(target=lane, args=(t,)) for t in range(NB)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
+        for i, s in enumerate(slots):
+            bf = bufs[i % NB]
+            cs = s_c[i % len(s_c)]
+            first = i < NB
+            if not first:
+                chk(rt.hipStreamWaitEvent(s_in, bf["ev_c"], 0))     # the decode that read this input buffer is through
+            chk(rt.hipMemcpyAsync(bf["d_in"].data_ptr(), s["h_in"].data_ptr(), s["nbytes"] + 64, H2D, s_in))
+            chk(rt.hipEventRecord(bf["ev_in"], s_in))
+            chk(rt.hipStreamWaitEvent(cs, bf["ev_in"], 0))
+            if not first:
+                chk(rt.hipStreamWaitEvent(cs, bf["ev_out"], 0))     # the copy that read this PCM buffer is through
+            bf["ctx"].index(bf["d_in"].data_ptr(), s["nbytes"], s["d_off"].data_ptr(), s["d_len"].data_ptr(),
+                            len(s["len"]), cs.value)
+            bf["ctx"].decode_async(bf["d_pcm"].data_ptr(), s["d_oo"].data_ptr(), s["d_rows"].data_ptr(), cs.value)
+            chk(rt.hipEventRecord(bf["ev_c"], cs))
+            chk(rt.hipStreamWaitEvent(s_out, bf["ev_c"], 0))
+            chk(rt.hipMemcpyAsync(s["h_out"].data_ptr(), bf["d_pcm"].data_ptr(), s["tot"] * 4, D2H, s_out))
+            chk(rt.hipEventRecord(bf["ev_out"], s_out))
+        t_enq = time.perf_counter()
+        chk(rt.hipDeviceSynchronize())
+        return t_enq
 
-    one_pass()
-    torch.cuda.synchronize(dev)
+    def copies_only():
+        for i, s in enumerate(slots):
+            bf = bufs[i % NB]
+            chk(rt.hipMemcpyAsync(bf["d_in"].data_ptr(), s["h_in"].data_ptr(), s["nbytes"] + 64, H2D, s_in))
+            chk(rt.hipMemcpyAsync(s["h_out"].data_ptr(), bf["d_pcm"].data_ptr(), s["tot"] * 4, D2H, s_out))
+        chk(rt.hipDeviceSynchronize())
+
+    # ---- what the link gives with both directions busy: the same copies, nothing decoded, nothing waited for
+    copies_only()
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_pass()
-    torch.cuda.synchronize(dev)
+        copies_only()
+    dt_copy = time.perf_counter() - t0
+    # ---- the path itself
+    one_pass()
+    one_pass()
+    t0 = time.perf_counter()
+    enq = 0.0
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        enq += one_pass() - t1
     dt = time.perf_counter() - t0
     samples = sum(int((s["rows"] * nch).sum()) for s in slots)
     d2h = sum(s["tot"] for s in slots) * 4
     nbytes = sum(s["nbytes"] for s in slots)
-    for bf in bufs:
-        infos = bf["ctx"].stream_info(stream=bf["st"].cuda_stream)
+    for i, bf in enumerate(bufs):
+        infos = bf["ctx"].stream_info(stream=s_c[0].value)
         if any(inf.status for inf in infos):
             raise SystemExit("host_to_host: decode reported errors")
         bf["ctx"].close()
-    # the host copy of the first and last sub-batch against the oracle, one title each
+    chk(rt.hipDeviceSynchronize())
+    for bf in bufs:
+        for k in ("ev_in", "ev_c", "ev_out"):
+            rt.hipEventDestroy(bf[k])
+    for h in [s_in, s_out] + s_c:
+        rt.hipStreamDestroy(h)
+    # the host copy of the first, a middle and the last sub-batch against the oracle, one title each
     from tests import oracle_lib
     ora = oracle_lib.Oracle()
     ok = True
-    for p, k in ((0, 0), (parts - 1, len(slots[parts - 1]["len"]) - 1)):
+    for p, k in ((0, 0), (parts // 2, 1), (parts - 1, len(slots[parts - 1]["len"]) - 1)):
         s = slots[p]
-        i = p * per + k
+        i = s["lo"] + k
         want, r, st = ora.decode(flat[int(offs[i]):int(offs[i] + sizes[i])], nch, int(frames[i]))
         if wav24:
             nb = int(s["rows"][k]) * nch * 3
@@ -956,9 +1031,14 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         raise SystemExit("host_to_host: PCM in host memory differs from the oracle")
     return {"value": round(samples * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_pass": round(dt / steps * 1e3, 3),
             "titles": n, "sub_batches": parts, "h2d_bytes": nbytes, "d2h_bytes": d2h,
-            "pcie_GBs": round((nbytes + d2h) * steps / dt / 1e9, 2), "bit_exact_sample": ok,
-            "note": "pinned host -> H2D -> index+decode -> D2H -> pinned host, %d sub-batches on %d streams%s" % (
-                parts, NB, "; the decode writes the packed 24-bit WAV payload: 3 B per sample go back" if wav24 else "")}
+            "pcie_GBs": round((nbytes + d2h) * steps / dt / 1e9, 2),
+            "pcie_ceiling_GBs": round((nbytes + d2h) * steps / dt_copy / 1e9, 2),
+            "copy_only_ms_per_pass": round(dt_copy / steps * 1e3, 3), "host_enqueue_ms_per_pass": round(enq / steps * 1e3, 3),
+            "bit_exact_sample": ok,
+            "note": "pinned host -> H2D -> index+decode -> D2H -> pinned host, %d sub-batches (16, 48, then 64 titles); H2D and "
+                    "D2H on streams of their own, three compute streams, event edges; pcie_ceiling_GBs = the same copies with "
+                    "nothing decoded and nothing waited for%s" % (
+                parts, "; the decode writes the packed 24-bit WAV payload: 3 B per sample go back" if wav24 else "")}
 
 
 # ----------------------------------------------------------------------------- plumbing-only ranks (CPU tests)
@@ -1247,16 +1327,20 @@ def main():
         out["host"] = {"gen_seconds": round(t_gen, 2), "cpus": os.cpu_count()}
         if world == 1 and not args.no_sub and args.workload == "c3" and args.substreams == 1 and assignment == 12:
             sub_steps = max(5, min(args.steps, 20))
-            out["sub"] = sub_records(pkg, torch, dev, local_rank, args, b, sub_steps, 2)
+            # (the host-path records first: behind the other sub-records -- dozens of contexts and streams opened and
+            #  closed -- the same passes ran 26 ms where they take 18-21 in a run of their own, copies-only unchanged)
             t_h = time.perf_counter()
             only = set(x for x in args.only_sub.split(",") if x)
+            h2h = {}
             if not only or "host_to_host" in only:
-                out["sub"]["host_to_host"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
-                                                          max(3, sub_steps // 4))
+                h2h["host_to_host"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
+                                                   max(3, sub_steps // 4))
             if not only or "host_to_host_wav24" in only:
-                out["sub"]["host_to_host_wav24"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
-                                                                max(3, sub_steps // 4), wav24=True)
+                h2h["host_to_host_wav24"] = host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames,
+                                                         max(3, sub_steps // 4), wav24=True)
             sys.stderr.write("bench: host_to_host records %.1f s\n" % (time.perf_counter() - t_h))
+            out["sub"] = sub_records(pkg, torch, dev, local_rank, args, b, sub_steps, 2)
+            out["sub"].update(h2h)
             if not only or "streaming_tier" in only:
                 from tests import oracle_lib as _ol
                 out["sub"]["streaming_tier"] = streaming_tier(pkg, _ol.Oracle())
