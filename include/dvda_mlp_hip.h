@@ -215,7 +215,7 @@ int dvda_mlp_hip_decode_time(dvda_mlp_hip_ctx *ctx, double *avg_ms, uint32_t *ca
  * src/dvd-audio.c:597-657, and two decoders share nothing -- so a host with a list of streams gives every GPU its
  * own sub-list: greedy longest-processing-time on the compressed size (dvda_mlp_hip_shard, the same deterministic
  * partition as libdvd-audio_amd/shard.py), one host thread + decode context + HIP stream per device entry, no
- * exchange between devices, a small summary added up on the host (csrc/mlp_multi.cpp).  The streams and the PCM are
+ * exchange between devices, a small summary added up over RCCL -- or on the host, see `reduction` -- (csrc/mlp_multi.cpp).  The streams and the PCM are
  * HOST buffers here (each device gets its own copies); a device may be named more than once. */
 typedef struct dvda_mlp_hip_multi dvda_mlp_hip_multi;
 typedef struct dvda_mlp_multi_summary {
@@ -231,6 +231,10 @@ typedef struct dvda_mlp_multi_summary {
     double device_ms_max;
     double device_ms_min;
     double imbalance;
+    /* (round 6) who added the summary up: 1 = RCCL (one communicator per device, two all-reduces -- a device list that
+     * names every device once, librccl present), 0 = the host (a device named twice, no librccl, DVDA_MULTI_RCCL=0) */
+    uint32_t reduction;
+    uint32_t reserved;
 } dvda_mlp_multi_summary;
 
 /* part_of[i] = which of `parts` parts stream i (sizes[i] bytes) goes to */

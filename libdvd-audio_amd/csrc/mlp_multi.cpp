@@ -4,11 +4,15 @@
 // at a time through one decoder, src/dvd-audio.c:597-657; nothing is shared between two of them) -- so a host that
 // holds a list of streams gives every GPU its own sub-list and adds up a small summary.  This is the C restatement
 // of libdvd-audio_amd/shard.py (what `bench.py --gpus N` does with one PROCESS per GPU and one RCCL all-reduce):
-// here it is one host THREAD per device entry, each with its own decode context, device buffers and HIP stream,
-// and the summary is reduced on the host.  Plain C ABI on top of the batch tier's own entry points: a device list
-// may name a device more than once (two contexts and two host threads on one GPU -- how the tests run it on a
-// one-GPU box, and a way to overlap one batch's copies with another's decode).
+// here it is one host THREAD per device entry, each with its own decode context, device buffers and HIP stream.
+// The summary -- the path's one reduction -- goes over RCCL when the device list names every device once (round 6:
+// one communicator per device, ncclCommInitAll; two small all-reduces, a sum and a max, issued for all devices by the
+// calling thread inside one group once every part is through; librccl is opened at run time, the library does not
+// link it); a list that names a device twice (two contexts and two host threads on one GPU -- how the tests run it
+// on a one-GPU box, and a way to overlap one batch's copies with another's decode), a box without librccl, or
+// DVDA_MULTI_RCCL=0 reduce on the host, the same sums.  dvda_mlp_multi_summary.reduction says which it was.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -21,13 +25,94 @@
 
 #include "../../include/dvda_mlp_hip.h"
 
+// the four RCCL calls the summary needs (rccl.h: ncclCommInitAll, ncclCommDestroy, ncclAllReduce, ncclGroupStart / End)
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int datatype, int op, void *comm, hipStream_t st) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+};
+constexpr int NCCL_UINT64 = 5, NCCL_SUM = 0, NCCL_MAX = 2;      // ncclDataType_t / ncclRedOp_t
+constexpr int RED_SUMS = 4, RED_MAXS = 3, RED_WORDS = 2 * (RED_SUMS + RED_MAXS);
+
 struct dvda_mlp_hip_multi {
     std::vector<int> devices;
     std::vector<dvda_mlp_hip_ctx *> ctx;
     uint32_t max_streams, max_segments;
     std::vector<double> last_ms;            // per device entry: wall time of the last decode_multi
     std::vector<uint64_t> last_bytes;       // ... and the compressed bytes it was dealt
+    // the summary over RCCL: a communicator, a stream and a few device words per device entry
+    RcclApi rccl;
+    bool use_rccl = false;
+    std::vector<void *> comms;
+    std::vector<hipStream_t> red_stream;
+    std::vector<uint64_t *> d_red;          // [RED_WORDS]: sums to send | maxima to send | sums received | maxima received
 };
+
+static void rccl_close(dvda_mlp_hip_multi *m)
+{
+    for (size_t p = 0; p < m->comms.size(); p++) {
+        (void)hipSetDevice(m->devices[p]);
+        if (m->comms[p] && m->rccl.CommDestroy)
+            (void)m->rccl.CommDestroy(m->comms[p]);
+        if (p < m->red_stream.size() && m->red_stream[p])
+            (void)hipStreamDestroy(m->red_stream[p]);
+        if (p < m->d_red.size())
+            (void)hipFree(m->d_red[p]);
+    }
+    m->comms.clear();
+    m->red_stream.clear();
+    m->d_red.clear();
+    if (m->rccl.lib)
+        dlclose(m->rccl.lib);
+    m->rccl = RcclApi();
+    m->use_rccl = false;
+}
+
+// every device named once, librccl there, the communicators made: the summary goes over RCCL; anything else: the host
+static void rccl_open(dvda_mlp_hip_multi *m)
+{
+    const char *e = getenv("DVDA_MULTI_RCCL");
+    if (e && atoi(e) == 0)
+        return;
+    std::vector<int> d = m->devices;
+    std::sort(d.begin(), d.end());
+    if (std::adjacent_find(d.begin(), d.end()) != d.end())
+        return;                             // a device named twice: two ranks of one communicator cannot share a GPU
+    RcclApi &r = m->rccl;
+    r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib)
+        r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib)
+        return;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+    const size_t n = m->devices.size();
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    bool ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd;
+    if (ok) {
+        m->comms.assign(n, nullptr);
+        ok = r.CommInitAll(m->comms.data(), (int)n, m->devices.data()) == 0;
+    }
+    m->red_stream.assign(n, nullptr);
+    m->d_red.assign(n, nullptr);
+    for (size_t p = 0; ok && p < n; p++)
+        ok = hipSetDevice(m->devices[p]) == hipSuccess &&
+             hipStreamCreateWithFlags(&m->red_stream[p], hipStreamNonBlocking) == hipSuccess &&
+             hipMalloc((void **)&m->d_red[p], RED_WORDS * sizeof(uint64_t)) == hipSuccess;
+    (void)hipSetDevice(keep);
+    if (!ok) {
+        rccl_close(m);
+        return;
+    }
+    m->use_rccl = true;
+}
 
 // shard.shard_titles: greedy longest-processing-time on the compressed size -- streams by size descending (ties:
 // lower index first), each to the part with the least bytes so far (ties: lower part) -- deterministic, so that any
@@ -76,6 +161,7 @@ extern "C" int dvda_mlp_hip_create_multi(dvda_mlp_hip_multi **out, const int *de
     }
     m->last_ms.assign(n_devices, 0.0);
     m->last_bytes.assign(n_devices, 0);
+    rccl_open(m);
     *out = m;
     return DVDA_HIP_OK;
 }
@@ -84,6 +170,7 @@ extern "C" void dvda_mlp_hip_destroy_multi(dvda_mlp_hip_multi *m)
 {
     if (!m)
         return;
+    rccl_close(m);
     for (dvda_mlp_hip_ctx *x : m->ctx)
         dvda_mlp_hip_destroy(x);
     delete m;
@@ -286,33 +373,85 @@ extern "C" int dvda_mlp_hip_decode_multi(dvda_mlp_hip_multi *m, const uint8_t *c
         m->last_bytes[p] = jobs[p].bytes;
     }
     if (summary) {
-        // the path's one reduction (bench.py does the same with one all-reduce over RCCL): sums, and the balance
+        // the path's one reduction (bench.py does the same with one all-reduce over RCCL): sums, and the balance.
+        // Every part's own contribution first: {PCM frames, samples, streams with errors, compressed bytes} to add,
+        // {compressed bytes, wall time in us, ~wall time in us} to take the maximum of (the last one is the minimum's)
         memset(summary, 0, sizeof(*summary));
         summary->devices = parts;
-        uint64_t bmax = 0, bsum = 0;
-        for (uint32_t p = 0; p < parts; p++) {
-            bsum += jobs[p].bytes;
-            bmax = jobs[p].bytes > bmax ? jobs[p].bytes : bmax;
-        }
+        std::vector<uint64_t> loc((size_t)parts * (RED_SUMS + RED_MAXS), 0);
         for (uint32_t i = 0; i < n_streams; i++) {
-            summary->pcm_frames += infos[i].pcm_frames;
-            summary->samples += infos[i].pcm_frames * infos[i].channels;
-            summary->streams_with_errors += (infos[i].status & ~(uint32_t)DVDA_ST_BENIGN) ? 1u : 0u;
+            uint64_t *l = &loc[(size_t)part_of[i] * (RED_SUMS + RED_MAXS)];
+            l[0] += infos[i].pcm_frames;
+            l[1] += infos[i].pcm_frames * infos[i].channels;
+            l[2] += (infos[i].status & ~(uint32_t)DVDA_ST_BENIGN) ? 1u : 0u;
         }
-        summary->compressed_bytes = bsum;
-        summary->compressed_bytes_max_device = bmax;
-        double tmax = 0, tmin = 0;
-        bool any = false;
         for (uint32_t p = 0; p < parts; p++) {
-            if (!jobs[p].bytes)
-                continue;                   // (an entry that got no stream did nothing)
-            tmax = !any || jobs[p].ms > tmax ? jobs[p].ms : tmax;
-            tmin = !any || jobs[p].ms < tmin ? jobs[p].ms : tmin;
-            any = true;
+            uint64_t *l = &loc[(size_t)p * (RED_SUMS + RED_MAXS)];
+            l[3] = jobs[p].bytes;
+            l[RED_SUMS + 0] = jobs[p].bytes;
+            // (an entry that got no stream did nothing: it neither sets the slowest nor the fastest time)
+            const uint64_t us = (uint64_t)(jobs[p].ms * 1e3);
+            l[RED_SUMS + 1] = jobs[p].bytes ? us : 0;
+            l[RED_SUMS + 2] = jobs[p].bytes ? ~us : 0;
         }
-        summary->device_ms_max = tmax;
-        summary->device_ms_min = tmin;
-        summary->imbalance = bsum ? (double)bmax * parts / (double)bsum : 1.0;
+        uint64_t tot[RED_SUMS + RED_MAXS] = {0, 0, 0, 0, 0, 0, 0};
+        bool reduced = false;
+        if (m->use_rccl && rc == DVDA_HIP_OK) {
+            // two small all-reduces over RCCL, issued for every device by this thread inside one group (every part is
+            // through: no rank can be missing); any failure falls back to the host's sums below
+            int keep = 0;
+            (void)hipGetDevice(&keep);
+            bool ok = true;
+            for (uint32_t p = 0; ok && p < parts; p++)
+                ok = hipSetDevice(m->devices[p]) == hipSuccess &&
+                     hipMemcpyAsync(m->d_red[p], &loc[(size_t)p * (RED_SUMS + RED_MAXS)], (RED_SUMS + RED_MAXS) * sizeof(uint64_t),
+                                    hipMemcpyHostToDevice, m->red_stream[p]) == hipSuccess;
+            if (ok) {
+                ok = m->rccl.GroupStart() == 0;
+                for (uint32_t p = 0; ok && p < parts; p++) {
+                    uint64_t *d = m->d_red[p];
+                    ok = hipSetDevice(m->devices[p]) == hipSuccess &&
+                         m->rccl.AllReduce(d, d + RED_SUMS + RED_MAXS, RED_SUMS, NCCL_UINT64, NCCL_SUM, m->comms[p], m->red_stream[p]) == 0 &&
+                         m->rccl.AllReduce(d + RED_SUMS, d + 2 * RED_SUMS + RED_MAXS, RED_MAXS, NCCL_UINT64, NCCL_MAX, m->comms[p],
+                                           m->red_stream[p]) == 0;
+                }
+                ok = (m->rccl.GroupEnd() == 0) && ok;
+            }
+            std::vector<uint64_t> back((size_t)parts * (RED_SUMS + RED_MAXS), 0);
+            for (uint32_t p = 0; ok && p < parts; p++)
+                ok = hipSetDevice(m->devices[p]) == hipSuccess &&
+                     hipMemcpyAsync(&back[(size_t)p * (RED_SUMS + RED_MAXS)], m->d_red[p] + RED_SUMS + RED_MAXS,
+                                    (RED_SUMS + RED_MAXS) * sizeof(uint64_t), hipMemcpyDeviceToHost, m->red_stream[p]) == hipSuccess &&
+                     hipStreamSynchronize(m->red_stream[p]) == hipSuccess;
+            // (every rank holds the same result; they are compared -- a summary is not worth a silent disagreement)
+            for (uint32_t p = 1; ok && p < parts; p++)
+                ok = memcmp(&back[0], &back[(size_t)p * (RED_SUMS + RED_MAXS)], (RED_SUMS + RED_MAXS) * sizeof(uint64_t)) == 0;
+            (void)hipSetDevice(keep);
+            if (ok) {
+                memcpy(tot, back.data(), sizeof(tot));
+                reduced = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (!reduced) {
+            for (uint32_t p = 0; p < parts; p++) {
+                const uint64_t *l = &loc[(size_t)p * (RED_SUMS + RED_MAXS)];
+                for (int k = 0; k < RED_SUMS; k++)
+                    tot[k] += l[k];
+                for (int k = RED_SUMS; k < RED_SUMS + RED_MAXS; k++)
+                    tot[k] = l[k] > tot[k] ? l[k] : tot[k];
+            }
+        }
+        summary->pcm_frames = tot[0];
+        summary->samples = tot[1];
+        summary->streams_with_errors = (uint32_t)tot[2];
+        summary->compressed_bytes = tot[3];
+        summary->compressed_bytes_max_device = tot[RED_SUMS + 0];
+        summary->device_ms_max = (double)tot[RED_SUMS + 1] * 1e-3;
+        summary->device_ms_min = tot[RED_SUMS + 2] ? (double)(~tot[RED_SUMS + 2]) * 1e-3 : 0.0;
+        summary->imbalance = tot[3] ? (double)tot[RED_SUMS + 0] * parts / (double)tot[3] : 1.0;
+        summary->reduction = reduced ? 1u : 0u;
     }
     return rc;
 }

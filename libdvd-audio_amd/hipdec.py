@@ -36,7 +36,7 @@ class MultiSummary(ctypes.Structure):
     _fields_ = [("pcm_frames", ctypes.c_uint64), ("samples", ctypes.c_uint64), ("compressed_bytes", ctypes.c_uint64),
                 ("compressed_bytes_max_device", ctypes.c_uint64), ("streams_with_errors", ctypes.c_uint32),
                 ("devices", ctypes.c_uint32), ("device_ms_max", ctypes.c_double), ("device_ms_min", ctypes.c_double),
-                ("imbalance", ctypes.c_double)]
+                ("imbalance", ctypes.c_double), ("reduction", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class HipError(RuntimeError):

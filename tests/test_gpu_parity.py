@@ -1107,6 +1107,7 @@ def test_title_list_dealt_to_several_devices_from_c(pkg, oracle, layout):
     lay = {"planar": hip.PCM_PLANAR, "interleaved": hip.PCM_INTERLEAVED, "wav24": hip.PCM_WAV24}[layout]
     pcm, infos, summ = hip.decode_streams_multi(streams, [0, 0, 0], layout=lay)
     assert summ.devices == 3 and summ.streams_with_errors == 0
+    assert summ.reduction == 0          # (a device named more than once: the summary is added up on the host)
     assert summ.pcm_frames == sum(frames) and summ.samples == sum(f * c for f, c in zip(frames, nchs))
     assert summ.compressed_bytes == sum(len(b) for b in streams)
     owner = hip.shard_c([len(b) for b in streams], 3)
@@ -1122,3 +1123,39 @@ def test_title_list_dealt_to_several_devices_from_c(pkg, oracle, layout):
             assert pcm[i].tobytes() == oracle.wav_pack(want, 24), "stream %d" % i
         else:
             assert np.array_equal(pcm[i], want), "stream %d" % i
+
+
+def test_multi_summary_goes_over_rccl_when_every_device_is_named_once(pkg, oracle):
+    """The C host's one reduction (north_star: "partitioned with RCCL over xGMI only as an
+    embarrassingly-parallel shard of the title list"): with a device list that names every device once the summary of
+    dvda_mlp_hip_decode_multi is two RCCL all-reduces (csrc/mlp_multi.cpp; librccl opened at run time) -- on a test
+    box that is a communicator of ONE rank, which still goes through ncclCommInitAll / ncclAllReduce --; with
+    DVDA_MULTI_RCCL=0 the host adds up.  Both give the same summary, and the PCM is the oracle's either way."""
+    import os
+    syn, hip = pkg.synth, pkg.hipdec
+    streams, frames = [], []
+    for i in range(6):
+        b, f = syn.stream(syn.make_cfg(assignment=12, rate_code=1, n_substreams=1 + (i & 1), n_aus=24), 900 + i)
+        streams.append(b)
+        frames.append(f)
+    got = {}
+    old = os.environ.get("DVDA_MULTI_RCCL")
+    try:
+        for mode in ("1", "0"):
+            os.environ["DVDA_MULTI_RCCL"] = mode
+            pcm, infos, summ = hip.decode_streams_multi(streams, [0])
+            got[mode] = summ
+            for b, f, p in zip(streams, frames, pcm):
+                want, r, st = oracle.decode(b, 6, f)
+                assert st == 0 and np.array_equal(p, want)
+    finally:
+        if old is None:
+            del os.environ["DVDA_MULTI_RCCL"]
+        else:
+            os.environ["DVDA_MULTI_RCCL"] = old
+    assert got["0"].reduction == 0
+    assert got["1"].reduction == 1, "librccl.so is part of the ROCm image: the summary should have gone over RCCL"
+    for k in ("pcm_frames", "samples", "compressed_bytes", "compressed_bytes_max_device", "streams_with_errors", "devices"):
+        assert getattr(got["0"], k) == getattr(got["1"], k), k
+    assert got["1"].pcm_frames == sum(frames) and got["1"].samples == 6 * sum(frames)
+    assert got["1"].device_ms_max > 0 and abs(got["1"].imbalance - 1.0) < 1e-9

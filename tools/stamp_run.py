@@ -48,10 +48,10 @@ for it in range(2):
     hip.lib().dvda_mlp_hip_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     hip.lib().dvda_mlp_hip_debug_counters(ctx._h, out)
 names = ["header phase", "prefetch issue / sync fill", "parse+filter (row)", "exchange+rematrix+stage", "ring commit+flush",
-         "loop top", "phase barrier (two-wave) / wait for the chunk (one-lane)", "ring top-up test"]
-for role in range(2 if SS == 2 else 1):
+         "loop top", "wait for the chunk", "ring top-up test"]
+for role in range(1):       # (rounds 2-5: two roles for the two-wave kernel; since round 6 one lane reads both substreams)
     v = np.array(list(out)[8 * role:8 * role + 8], dtype=np.float64)
-    print("role", role, "(two-wave layout: 0 = first substream's wave, rematrixes; 1 = last substream's wave)" if SS == 2 else "")
+    print("substreams per title:", SS)
     for nme, x in zip(names, v):
         print("  %-28s %6.2f %%  (%.3g cycles)" % (nme, 100 * x / max(v.sum(), 1), x))
 v = np.array(list(out)[8:16], dtype=np.float64)
