@@ -20,10 +20,12 @@ for f in glob.glob(os.path.join(pmc, "*", "**", "*counter_collection.csv"), recu
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"):
             name = row["Kernel_Name"]
-            m = re.search(r"k_decode<\s*\d+\s*,\s*(\w+)\s*,\s*(\w+)", name)      # <NS, PAIRED, GENERAL[, ILV]>
-            # the one-lane fast-pass kernel (the two-wave kernel of the same launch sequence exits at once on a
+            m = re.search(r"k_decode<\s*\d+\s*,\s*(\w+)\s*,\s*(\w+)", name)      # <NS, PAIRED, GENERAL[, ILV, PARSE, DUO, WAVO]>
+            targs = [t.strip() for t in name[name.index("<") + 1:name.index(">")].split(",")] if m else []
+            duo = len(targs) > 5 and targs[5] == "true"
+            # the one-substream fast-pass kernel (the two-substream kernel of the same launch sequence exits at once on a
             # batch without two-substream streams and would halve the mean)
-            key = "decode_fast" if (m and m.group(1) == "false" and m.group(2) == "false") else \
+            key = "decode_fast" if (m and m.group(1) == "false" and m.group(2) == "false" and not duo) else \
                   "sync_mask" if "k_sync_mask" in name else None
             if key:
                 vals[(key, row["Counter_Name"])].append(float(row["Counter_Value"]))
