@@ -34,12 +34,6 @@ import time
 
 import numpy as np
 
-# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share
-# one run in submission order.  sub.host_to_host uses five streams that must not wait for each other (copy in, copy
-# out, three decodes): eight queues, set before the runtime starts.  Nothing else in this file has more than three
-# streams busy at once.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -465,7 +459,11 @@ def disc_tier(pkg, oracle_mod=None, tracks=8, aus=65536):
                 if not rec["first_track_identical_to_oracle"]:
                     raise SystemExit("sub-record disc_tier: track 1's WAV payload differs from the oracle's")
             rec["note"] = ("wall clock of build/dvda2wav_hip on a synthetic %d-track disc (%d MB of AOB), second run; four worker "
-                           "threads on one GPU, tracks read in windows of 8 192 sectors" % (tracks, rec["aob_bytes"] >> 20))
+                           "threads on one GPU, tracks read in windows of 8 192 sectors.  The tool leaves with _exit once its "
+                           "files are closed (workers parked, the HIP runtime's teardown -- 60-80 ms -- left to the operating "
+                           "system; DVDA_TOOL_FULL_TEARDOWN=1 is the orderly way); the figure moves with the HIP runtime's "
+                           "start, 0.17-0.29 s of it, from box to box.  device_peak_mb_max is process-wide (hipMemGetInfo): "
+                           "with four workers on one GPU it includes the other workers' buffers" % (tracks, rec["aob_bytes"] >> 20))
     except SystemExit:
         raise
     except Exception as e:          # (no room for the files, no tool: the record says so, the bench line stays)
@@ -865,12 +863,13 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
     pinned host memory -> PCM resident in host memory').  Never `value`.
 
     Round 6: the two directions of the link on streams of their own -- every H2D copy on one stream, every D2H copy on
-    another -- and the index + decode of the sub-batches rotating over THREE compute streams (non-blocking decode
-    call: one host thread enqueues the whole pass; GPU_MAX_HW_QUEUES=8, see the top of this file), tied together
+    another -- and the index + decode of the sub-batches alternating between TWO compute streams (non-blocking decode
+    call: one host thread enqueues the whole pass; four streams = the runtime's four hardware queues), tied together
     by events:  H2D(i) waits for the decode that last read its input buffer;  decode(i) waits for H2D(i) and for the
     D2H that last read its PCM buffer;  D2H(i) waits for decode(i).  A sub-batch of 64 titles takes the lane kernel
-    one segment's time (~1.6 ms, a lone wave per SIMD) however few segments it holds, its copy back 0.9-1.2 ms: three
-    decodes in flight keep the link busy (two: 20.7 ms per pass, three: 18.3, four: 23.2 on one box whose link gave 17.0); the first two sub-batches are small (16 and 48 titles: the cooperative kernel's
+    one segment's time (~1.6 ms, a lone wave per SIMD) however few segments it holds, its copy back 0.9-1.2 ms: two
+    decodes in flight (with GPU_MAX_HW_QUEUES=8 and three: 18.3 instead of 20.7 ms per pass on a box whose link gave 17.0
+    -- not the default: see where this is called); the first two sub-batches are small (16 and 48 titles: the cooperative kernel's
     size) so that the first copy back starts after 0.6 ms instead of 2.2.
     (Rounds 3-5: 8 sub-batches on 3 streams, copy-in / decode / copy-out one after the other on each stream, a host
     thread per stream: the two directions mostly took turns.)
@@ -899,13 +898,13 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
         tot = int(words.sum())
         slots.append(dict(lo=lo, h_in=h_in, nbytes=b1 - b0, off=(offs[lo:hi].astype(np.int64) - b0), len=sizes[lo:hi].astype(np.int64),
                           rows=rows, oo=oo, tot=tot, h_out=torch.empty(tot, dtype=torch.int32).pin_memory()))
-    NB = min(int(os.environ.get("DVDA_BENCH_H2H_BUFS", "6")), parts)
+    NB = min(int(os.environ.get("DVDA_BENCH_H2H_BUFS", "4")), parts)
     bufs = []
     maxb = max(s["nbytes"] for s in slots) + 64
     maxt = max(s["tot"] for s in slots)
     maxn = max(len(s["len"]) for s in slots)
     nseg = maxn * ((args.aus + 7) // 8)
-    n_cs = int(os.environ.get("DVDA_BENCH_H2H_STREAMS", "3"))
+    n_cs = int(os.environ.get("DVDA_BENCH_H2H_STREAMS", "2"))
     for _ in range(NB):
         bufs.append(dict(d_in=torch.zeros(maxb, dtype=torch.uint8, device=dev),
                          d_pcm=torch.empty(maxt, dtype=torch.int32, device=dev),
@@ -1036,7 +1035,7 @@ def host_to_host(pkg, torch, dev, local_rank, args, flat, offs, sizes, frames, s
             "copy_only_ms_per_pass": round(dt_copy / steps * 1e3, 3), "host_enqueue_ms_per_pass": round(enq / steps * 1e3, 3),
             "bit_exact_sample": ok,
             "note": "pinned host -> H2D -> index+decode -> D2H -> pinned host, %d sub-batches (16, 48, then 64 titles); H2D and "
-                    "D2H on streams of their own, three compute streams, event edges; pcie_ceiling_GBs = the same copies with "
+                    "D2H on streams of their own, two compute streams, event edges; pcie_ceiling_GBs = the same copies with "
                     "nothing decoded and nothing waited for%s" % (
                 parts, "; the decode writes the packed 24-bit WAV payload: 3 B per sample go back" if wav24 else "")}
 
@@ -1328,7 +1327,11 @@ def main():
         if world == 1 and not args.no_sub and args.workload == "c3" and args.substreams == 1 and assignment == 12:
             sub_steps = max(5, min(args.steps, 20))
             # (the host-path records first: behind the other sub-records -- dozens of contexts and streams opened and
-            #  closed -- the same passes ran 26 ms where they take 18-21 in a run of their own, copies-only unchanged)
+            #  closed -- the same passes ran 26 ms where they take 18-21 in a fresh process, copies-only unchanged.  The
+            #  runtime's GPU_MAX_HW_QUEUES is left at its default of 4: with 8 the pass's five streams get a hardware
+            #  queue each and it runs 13.9 instead of 11.6 Gsamples/s, but the records that overlap two or three kernels
+            #  on purpose pay for it -- mixed_corpus_c5 429 -> 370 --, and in a child process of its own, beside this
+            #  one's idle context, the pass was slower than either: measured, round 6)
             t_h = time.perf_counter()
             only = set(x for x in args.only_sub.split(",") if x)
             h2h = {}

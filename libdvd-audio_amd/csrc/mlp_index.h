@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void k_chase(const uint8_t *__restrict__ bytes
 // false candidate is not a frame start of the real chain: the previous candidate's size-chain walk
 // passes over it and lands on a later candidate.  It is marked dead (no frames, no lanes) instead
 // of being trusted; what cannot be resolved this way stays DVDA_ST_IRREGULAR.
+constexpr uint32_t STEP_CAP = 4096;     // candidates a look-behind of mark_dead_one steps over at most (see there)
 __device__ __forceinline__ void mark_dead_one(uint32_t i, uint32_t n_cand, const uint64_t *__restrict__ stream_off,
                                               const uint64_t *__restrict__ stream_len, SegRec *__restrict__ seg,
                                               uint32_t *__restrict__ seg_frames, const StreamRec *__restrict__ streams)
@@ -484,9 +485,17 @@ __device__ __forceinline__ void mark_dead_one(uint32_t i, uint32_t n_cand, const
     // (the look-behind and the look-ahead are bounded in candidates of the stream's OWN parameters -- a run of foreign
     //  ones, which a walk goes through whole, is stepped over however long it is: round 5, more than MAX_DROP dropped
     //  in a row)
+    // (... and in candidates of any kind by STEP_CAP: on a stream whose later syncs all carry foreign parameters every
+    //  one of them would otherwise walk back over all the foreign ones before it -- n^2 global reads for a hostile
+    //  stream.  A candidate whose question is not settled within the cap is reported DVDA_ST_IRREGULAR, not trusted.)
+    uint32_t steps = 0;
     if (!foreign) {
         uint32_t seen = 0;
         for (uint32_t q = i; q-- > 0 && seen <= MAX_DROP + 1 && seg[q].stream == s;) {
+            if (++steps > STEP_CAP) {
+                seg[i].flags |= 1u << 16;
+                return;
+            }
             if ((seg[q].sync & SYNC_PARAMS) != want)
                 continue;
             seen++;
@@ -499,6 +508,10 @@ __device__ __forceinline__ void mark_dead_one(uint32_t i, uint32_t n_cand, const
     uint32_t seen_b = 0;
     for (uint32_t q = i; q-- > 0 && seen_b <= MAX_DROP + 1 && seg[q].stream == s;) {
         const uint64_t e = seg[q].end;
+        if (++steps > STEP_CAP) {
+            seg[i].flags |= 1u << 16;
+            return;
+        }
         if ((seg[q].sync & SYNC_PARAMS) != want)
             continue;
         seen_b++;

@@ -145,10 +145,12 @@ struct pool {
     atomic_uint next, failed, done;     /* done: workers through with the job list */
     const char *dir;
     int fused_wav;
+    int park;                           /* a worker that is through parks instead of ending (the fast way out) */
 };
 struct worker {
     struct pool *pool;
     int device;
+    int threaded;                       /* runs in a thread of its own (not in main's) */
 };
 
 static void *work(void *arg)
@@ -161,9 +163,14 @@ static void *work(void *arg)
         if (!extract(w->pool->jobs[i].title, w->pool->jobs[i].track, w->pool->dir, w->device, w->pool->fused_wav))
             atomic_fetch_add(&w->pool->failed, 1);
     }
-    /* (what this thread's last windowed reader left for a next one is freed when the thread ends -- 30 ms a worker:
-       main() does not wait for that, it leaves as soon as every worker is through with the list) */
+    /* (what this thread's last windowed reader left for a next one would be freed when the thread ends -- 30 ms a worker.
+       main() does not wait for that: it leaves with _exit as soon as every worker is through with the list, and a worker
+       that has counted itself done PARKS here instead of ending, so that no thread is inside a HIP call -- its buffers'
+       release -- when the process goes.  DVDA_TOOL_FULL_TEARDOWN=1: the orderly way, threads joined, everything freed) */
     atomic_fetch_add(&w->pool->done, 1);
+    if (w->pool->park && w->threaded)
+        for (;;)
+            pause();
     return NULL;
 }
 
@@ -261,16 +268,19 @@ int main(int argc, char *argv[])
         for (unsigned i = 0; i < w; i++)
             devices[n_devices++] = one_device;
     }
-    struct pool pool = {jobs, n_jobs, 0, 0, 0, dir, fused_wav};
+    struct pool pool = {jobs, n_jobs, 0, 0, 0, dir, fused_wav, getenv("DVDA_TOOL_FULL_TEARDOWN") == NULL};
     struct worker workers[64];
     pthread_t th[64];
     int started[64];
     for (int i = 0; i < n_devices; i++) {
         workers[i].pool = &pool;
         workers[i].device = devices[i];
+        workers[i].threaded = n_devices > 1;
         started[i] = n_devices > 1 && pthread_create(&th[i], NULL, work, &workers[i]) == 0;
-        if (!started[i])
+        if (!started[i]) {
+            workers[i].threaded = 0;
             work(&workers[i]);              /* one entry (or no thread to be had): here, in turn */
+        }
     }
     {
         unsigned n_started = 0;
