@@ -970,10 +970,55 @@ static void windows_free(struct mlp_windows *w)
     free(w);
 }
 
+/* Does every substream of the sync unit at `off` of the stream [0, len) in d_stream open with a restart header?  (Reference:
+ * decode_block src/mlp.c:748-753 -- two flags in front of a block, "parameters present" and "restart header present";
+ * the unit's layout: 4 bytes of frame header, the 28-byte major sync with substream_count 128 bits in, src/mlp.c:621-632,
+ * one directory word per substream and one more behind it when its top bit is set, src/mlp.c:463-468, 661-667.)
+ * 1 = yes, 0 = no, -1 = the device read failed.  A window may begin at such a unit: the restart header sets every
+ * parameter the lanes do not carry across a cut, the FIR history is carried (win_produce). */
+static int win_unit_restarts(struct mlp_windows *w, uint64_t off, uint64_t len)
+{
+    uint8_t h[4 + 28 + 8 + 1];
+    const uint64_t have = len - off < sizeof(h) ? len - off : sizeof(h);
+    if (have < 4 + 28 + 2 + 1)
+        return 0;
+    if (hipMemcpy(h, w->d_stream + off, have, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    if (h[4] != 0xF8 || h[5] != 0x72 || h[6] != 0x6F || h[7] != 0xBB)
+        return 0;
+    const unsigned S = h[4 + 16] >> 4;
+    if (S != 1 && S != 2)
+        return 0;
+    uint64_t p = 4 + 28, end0 = 0;
+    for (unsigned s = 0; s < S; s++) {
+        if (p + 2 > have)
+            return 0;
+        const unsigned e = ((unsigned)h[p] << 8) | h[p + 1];
+        if (s == 0)
+            end0 = (uint64_t)(e & 0xFFFu) * 2;
+        p += (e & 0x8000u) ? 4 : 2;
+    }
+    if (p >= have || (h[p] & 0xC0) != 0xC0)
+        return 0;
+    if (S == 2) {
+        uint8_t b = 0;
+        if (off + p + end0 >= len)
+            return 0;
+        if (hipMemcpy(&b, w->d_stream + off + p + end0, 1, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        if ((b & 0xC0) != 0xC0)
+            return 0;
+    }
+    return 1;
+}
+
 /* the last segment of the index (a live one: a sync pattern inside another segment's frames is not a cut) -> its number
- * and byte offset; 0 when the stream has no segment start behind its first byte, -1 when the device call failed (that is
- * not "no cut": taken as one, the carried bytes would grow window after window) */
-static int win_last_cut(struct mlp_windows *w, uint32_t n_seg, uint32_t *seg_out, uint64_t *off_out)
+ * and byte offset; 0 when the stream has no segment start behind its first byte, -1 when a device call failed (that is
+ * not "no cut": taken as one, the carried bytes would grow window after window).  restart_len != 0: the last one a
+ * window can BEGIN at -- a major sync does not oblige the substreams to restart (the reference reads its parameters and
+ * decodes on, src/mlp.c:449-460), and a lane that starts there would have no parameters; such a unit stays inside its
+ * window, where the sequential pass reaches it with the state of the units before it.  restart_len = the stream's length. */
+static int win_last_cut(struct mlp_windows *w, uint32_t n_seg, uint64_t restart_len, uint32_t *seg_out, uint64_t *off_out)
 {
     for (uint32_t s = n_seg; s-- > 0;) {
         dvda_mlp_segment_info si;
@@ -981,6 +1026,13 @@ static int win_last_cut(struct mlp_windows *w, uint32_t n_seg, uint32_t *seg_out
             return -1;
         if (si.status & DVDA_ST_FALSE_SYNC)
             continue;
+        if (restart_len && si.offset != 0) {
+            const int r = win_unit_restarts(w, si.offset, restart_len);
+            if (r < 0)
+                return -1;
+            if (!r)
+                continue;
+        }
         *seg_out = s;
         *off_out = si.offset;
         return si.offset != 0;
@@ -1117,7 +1169,7 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         if (!win_index(w, len, &n_seg))
             return 0;
         if (!final) {
-            const int have_cut = win_last_cut(w, n_seg, &cut_seg, &cut);
+            const int have_cut = win_last_cut(w, n_seg, len, &cut_seg, &cut);
             if (have_cut < 0)
                 return 0;
             if (!have_cut) {
@@ -1197,7 +1249,7 @@ static int win_produce(struct mlp_windows *w, struct win_slot *out)
         if (!final) {
             uint32_t last_seg = 0;
             uint64_t dummy = 0;
-            if (win_last_cut(w, n_seg, &last_seg, &dummy) < 0)
+            if (win_last_cut(w, n_seg, 0, &last_seg, &dummy) < 0)
                 return 0;
             if (dvda_mlp_hip_segment_fir(w->ctx, last_seg, w->fir, NULL) != DVDA_HIP_OK)
                 return 0;

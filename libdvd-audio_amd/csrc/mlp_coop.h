@@ -479,7 +479,10 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                         }
                         if (!have_restart && ok) {
                             ok = false;
-                            e1 = ST_ENVELOPE;                          // parameters before any restart header
+                            // parameters before any restart header: a segment behind a major sync that restarts nothing
+                            // (src/mlp.c:449-460) is decoded by the sequential pass, with the state of the segments
+                            // before it; a stream's first segment has none (as k_decode)
+                            e1 = (!RESUME && segi != stream_first) ? ST_SEQ : ST_ENVELOPE;
                         }
                         if (ok) {
                             // ---- decoding parameters (src/mlp.c:866-990); flags bit (7-i) = flags[i]
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     }
                     if (!have_restart && ok) {
                         ok = false;
-                        e1 = ST_ENVELOPE;
+                        e1 = (!RESUME && segi != stream_first) ? ST_SEQ : ST_ENVELOPE;
                     }
                     if (!ok) {
                         err = e1;

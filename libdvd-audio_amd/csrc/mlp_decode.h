@@ -961,6 +961,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     uint32_t oshift_pack = 0, qss_pack = 0;
     uint32_t qss_A = 0, mmc_A = 0;    // quant step sizes / max_matrix_channel the rematrix works with
     uint32_t gate_turn = 0;               // loop turn for the header gate (wave-uniform)
+    // A segment whose first block carries no restart header: a major sync does not oblige the substreams to restart -- the
+    // reference compares the sync's parameters and decodes on with the state it has (src/mlp.c:449-460, 748-753).  A lane
+    // that starts at such a segment has no parameters: the stream goes to the sequential pass, which reaches the segment
+    // with the state of the ones before it.  At a stream's FIRST segment (and so in the sequential pass, which starts
+    // there) nothing came before: outside the reference's defined behaviour.
+    // (read back from memory: this is rare, and the kernel has no register to keep the stream's first segment in)
+    auto no_restart_yet = [&]() -> uint32_t {
+        if (GENERAL)
+            return ST_ENVELOPE;
+        const uint32_t first = a.streams[a.seg[segi].stream].first_seg;
+        return segi != first ? ST_SEQ : ST_ENVELOPE;
+    };
     constexpr bool HDR_GATE = !PAIRED && !GENERAL;
     const uint32_t gl_r = gl;                       // workspace lane of the matrices 2..5 (sequential pass)
     uint32_t nslots = 0;
@@ -1364,7 +1376,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                     DVDA_HSTAMP(1);
                     if (!have_restart && ok) {
                         ok = false;
-                        err = ST_ENVELOPE;                         // parameters before any restart header
+                        err = no_restart_yet();                    // parameters before any restart header
                     }
                     if (ok) {
                         // ---- decoding parameters (src/mlp.c:866-990); flags bit (7-i) = flags[i]
@@ -1700,7 +1712,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 DVDA_HSTAMP(3);
                 if (!have_restart && ok) {
                     ok = false;
-                    err = ST_ENVELOPE;
+                    err = no_restart_yet();
                 }
                 hdr_parsed = true;
                 if (PARSE && iir_any)

@@ -9,7 +9,7 @@ from . import _build
 SF = dict(IIR=1 << 0, QSS=1 << 1, OUTSHIFT=1 << 2, HUFFOFF=1 << 3, VARBLOCK=1 << 4, VARROWS=1 << 5,
           MIDMATRIX=1 << 6, CHAINED=1 << 7, EXTRAWORD=1 << 8, MIDRESTART=1 << 9, FLAGS=1 << 10,
           MIXBOOKS=1 << 11, NOCHECK=1 << 12, PARAMBLOCKS=1 << 13, MATRIXRAND=1 << 14,
-          TERMINATOR=1 << 15, FIRRAND=1 << 16, NOISE=1 << 17, CHECKQUIRK=1 << 18, DISC=1 << 19)
+          TERMINATOR=1 << 15, FIRRAND=1 << 16, NOISE=1 << 17, CHECKQUIRK=1 << 18, DISC=1 << 19, SYNCONLY=1 << 20)
 SF_ALL = (1 << 18) - 1
 # features the fused kernel decodes without its reporting paths (standard timing,
 # raw lead-in per segment, matrix-class parameters constant inside a frame)

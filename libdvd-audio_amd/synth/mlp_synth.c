@@ -842,6 +842,8 @@ size_t mlp_synth_stream(const mlp_synth_cfg *cfg, uint64_t seed, uint8_t *out, s
 
     for (au = 0; au < cfg->n_aus; au++) {
         const int restart_au = (au % cfg->restart_interval) == 0;
+        /* (MLP_SF_SYNCONLY: a major sync in front of an access unit whose substreams go on without a restart header) */
+        const int sync_au = restart_au || ((f & MLP_SF_SYNCONLY) && rnd_chance(&g.rng, 30));
         const int last_au = au + 1 == cfg->n_aus;
         unsigned rows = g.rows_per_au;
         unsigned blk[2][8];
@@ -868,7 +870,7 @@ size_t mlp_synth_stream(const mlp_synth_cfg *cfg, uint64_t seed, uint8_t *out, s
             if (f & MLP_SF_EXTRAWORD)
                 extraword[s] = rnd_chance(&g.rng, 30);
         }
-        total = 4 + (restart_au ? 28 : 0) + 2 * S + 2 * (extraword[0] + extraword[1]) + sslen[0] + sslen[1];
+        total = 4 + (sync_au ? 28 : 0) + 2 * S + 2 * (extraword[0] + extraword[1]) + sslen[0] + sslen[1];
         if (total > 8190 || (total & 1))
             goto fail;
         if (pos + total > cap)
@@ -879,7 +881,7 @@ size_t mlp_synth_stream(const mlp_synth_cfg *cfg, uint64_t seed, uint8_t *out, s
         bw_put(&hw, 4, rnd(&g.rng) & 0xF);
         bw_put(&hw, 12, (uint32_t)(total / 2));
         bw_put(&hw, 16, (au * g.rows_per_au) & 0xFFFF);
-        if (restart_au) {
+        if (sync_au) {
             bw_put(&hw, 24, 0xF8726F);
             bw_put(&hw, 8, 0xBB);
             bw_put(&hw, 4, cfg->bps_code);

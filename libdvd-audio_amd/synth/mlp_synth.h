@@ -42,6 +42,8 @@ extern "C" {
                                          reference goes by substream 0's flag for both (src/mlp.c:545)               */
 #define MLP_SF_DISC        (1u << 19) /* what an encoder writes: EVERY block carries parameters, most channels are
                                          sent and most of those re-send their FIR taps; fixed block positions       */
+#define MLP_SF_SYNCONLY    (1u << 20) /* a major sync in front of some access units that carry NO restart header:
+                                         the reference re-reads the sync's parameters and decodes on (src/mlp.c:449-460) */
 
 typedef struct mlp_synth_cfg {
     uint32_t profile;          /* 0 = BASELINE.md recipe, 1 = fuzz (uses .features) */

@@ -95,6 +95,26 @@ def test_disc_profile_streams(pkg, oracle, S, lanes):
     _check(pkg, oracle, cases, lanes=lanes)
 
 
+@pytest.mark.parametrize("lanes", [0, 2, 64])
+@pytest.mark.parametrize("S", [1, 2])
+def test_major_syncs_without_restart_headers(pkg, oracle, S, lanes):
+    """A major sync does not oblige the substreams to restart: the reference checks the sync's parameters against the
+    first one's and decodes on with the state it has (src/mlp.c:449-460; decode_block src/mlp.c:748-753 reads a restart
+    header only where the block's flag says so).  Generator feature SYNCONLY puts such syncs in front of three access
+    units in ten; a segment that starts at one has no parameters of its own, the stream goes to the pass that carries
+    them.  Same PCM as the oracle (which the compiled reference agrees with on these streams: tests/test_oracle.py)."""
+    syn = pkg.synth
+    SF = syn.SF
+    cases = []
+    for seed in range(6):
+        feats = SF["SYNCONLY"] | [0, syn.SF_FAST, SF["CHAINED"] | SF["FIRRAND"], syn.SF_ALL, SF["DISC"] | SF["MIXBOOKS"],
+                                  SF["IIR"] | SF["MIDRESTART"]][seed]
+        cfg = syn.make_cfg(assignment=12 if seed % 3 else 0x14, rate_code=[1, 0, 2, 9, 1, 8][seed], n_substreams=S,
+                           n_aus=40, profile=1, features=feats, restart_interval=[8, 4, 16, 8, 5, 3][seed])
+        cases.append((cfg, 900 + seed))
+    _check(pkg, oracle, cases, lanes=lanes)
+
+
 def test_golden_vectors_on_gpu(pkg):
     """Every committed golden vector (PCM produced by the real reference) through the HIP path."""
     import glob

@@ -112,6 +112,30 @@ def test_oracle_vs_compiled_reference(oracle, pkg):
     assert n == 90
 
 
+@pytest.mark.skipif(not oracle_lib.Reference.available(), reason="compiled reference not present")
+def test_oracle_vs_reference_on_major_syncs_without_restart_headers(oracle, pkg):
+    """reference src/mlp.c:449-460, 748-753: a major sync in front of an access unit whose blocks carry no restart
+    header (generator feature SYNCONLY) -- the parameters are compared, the decode goes on with the state it has."""
+    syn = pkg.synth
+    ref = oracle_lib.Reference()
+    n = 0
+    for asg, S in ((12, 1), (12, 2), (1, 1), (0x14, 2)):
+        for feat in (0, syn.SF_ALL, syn.SF_FAST, syn.SF["CHAINED"] | syn.SF["FIRRAND"]):
+            for seed in range(2):
+                cfg = syn.make_cfg(assignment=asg, rate_code=1, n_substreams=S, n_aus=32, profile=1,
+                                   features=feat | syn.SF["SYNCONLY"], restart_interval=[8, 3][seed])
+                data, frames = syn.stream(cfg, 2000 + n)
+                v = data[:len(data) - len(data) % 2].reshape(-1, 2)
+                syncs = int(np.count_nonzero((v[:-1, 0] == 0xF8) & (v[:-1, 1] == 0x72) & (v[1:, 0] == 0x6F) & (v[1:, 1] == 0xBB)))
+                assert syncs > (32 + [8, 3][seed] - 1) // [8, 3][seed]          # more syncs than restart points
+                want, r = ref.decode(data, asg, 1, cfg.bps_code, frames)
+                got, r2, st = oracle.decode(data, syn.channels(asg), frames, chunk=[0, 777][seed])
+                assert st == 0 and r == r2 == frames
+                assert np.array_equal(got, want)
+                n += 1
+    assert n == 32
+
+
 def test_oracle_flags_corruption(oracle, pkg):
     """Where the reference would assert()/abort, the oracle records an error bit."""
     syn = pkg.synth
