@@ -158,6 +158,7 @@ struct CoopResult {
     uint32_t frames_out;        // access units that yielded PCM
     uint32_t rows_written;      // PCM frames written
     uint32_t sync_seen;         // 1 + index of the last access unit of this call that carries the stream's own major sync
+                                // AND restarts every substream (a unit a decode can start from)
     int32_t fir[2][48];         // the FIR histories in front of that unit ([substream][slot * 8 + tap]: what
                                 // dvda_mlp_hip_segment_fir hands out for the segment before it)
 };
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         const uint64_t frame_end = cur + fsize;
         uint32_t err = too_big ? ST_SEQ : 0u;       // the sequential pass decodes such a stream, in order
         bool dropped = false;
+        bool own_sync = false;                      // streaming tier: the unit carries the stream's own major sync
         // ---- major sync: the segment's first unit has one (validated by the index).  Any other unit that carries a
         //      valid one was walked through by the index because its stream parameters differ: the reference drops
         //      it, restart header and all (src/mlp.c:449-460)
@@ -385,14 +387,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                     const uint32_t pks = (b8 >> 4) | ((b8 & 0xFu) << 4) | ((b9 >> 4) << 8) | ((b9 & 0xFu) << 12) | ((b11 & 0x1Fu) << 16);
                     if (((pks ^ stream_sync) & SYNC_PARAMS) == 0) {
                         rd.seek(save + 28u * 8u);
-                        // the histories in front of this unit: what a caller that has to decode it again starts from
-                        if (lane < 6u) {
-#pragma unroll
-                            for (int j = 0; j < 8; j++)
-                                cres->fir[sub][lane * 8u + j] = lane < nslots ? h[j] : 0;
-                        }
-                        if (is_last && lane == 0)
-                            cres->sync_seen = f + 1u;
+                        own_sync = true;
                     } else {
                         dropped = true;
                     }
@@ -411,15 +406,17 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
         uint32_t frame_rows = 0;
         if (!dropped && !too_big) {
             // ---- substream info "1u 1u 1u 1p 12u" (+16p) (src/mlp.c:463-468, 660-667)
-            uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0;
+            uint32_t end_prev = 0, my_start = 0, my_end = 0, check0 = 0, end0 = 0;
             bool bad = false;
             for (uint32_t s = 0; s < S; s++) {
                 const uint32_t info = rd.read(16);
                 const uint32_t end = (info & 0xFFFu) * 2u;
                 if (info & 0x8000u)
                     rd.read(16);
-                if (s == 0)
+                if (s == 0) {
                     check0 = (info >> 13) & 1u;
+                    end0 = end;
+                }
                 if (end < end_prev)
                     bad = true;
                 if (s == sub) {
@@ -434,6 +431,28 @@ __global__ __launch_bounds__(COOP_THREADS) void k_coop(DecodeArgs a)
                 err = ST_EOF;
             } else {
                 const uint32_t ss_end_bit = data0_bit + 8u * (check0 ? my_end - 2u : my_end);
+                if (RESUME && own_sync) {
+                    // A unit a caller may have to decode again FROM (mlp_stream.c keeps the bytes from the last one on, and
+                    // the histories in front of it): one whose substreams all open with a restart header -- a major sync
+                    // does not oblige them to (src/mlp.c:449-460, 748-753: the block's two flags), and a decode that
+                    // starts at one that restarts nothing has no parameters.  The host judges the unit by the same bits
+                    // (unit_restarts): the two have to name the same unit.
+                    rd.seek(data0_bit);
+                    bool restarts = rd.read(2) == 3u;
+                    if (two) {
+                        rd.seek(data0_bit + 8u * end0);
+                        restarts = rd.read(2) == 3u && restarts;
+                    }
+                    if (restarts) {
+                        if (lane < 6u) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                cres->fir[sub][lane * 8u + j] = lane < nslots ? h[j] : 0;
+                        }
+                        if (is_last && lane == 0)
+                            cres->sync_seen = f + 1u;
+                    }
+                }
                 rd.seek(data0_bit + 8u * my_start);
                 COOP_STAMP(0);
                 uint32_t blocks_in_frame = 0;

@@ -78,6 +78,34 @@ static int sync_at(const uint8_t *q, size_t pos, size_t size)
            q[pos + 7] == 0xBB && ((q[pos + 20] >> 4) == 1 || (q[pos + 20] >> 4) == 2);
 }
 
+/* Does every substream of the sync unit q[pos, pos + size) open with a restart header?  A major sync does not oblige the
+ * substreams to restart: the reference compares its parameters and decodes on with the state it has (src/mlp.c:449-460;
+ * decode_block src/mlp.c:748-753 reads a restart header where the block's two flags say so).  Only a unit that restarts
+ * everything is one a decode can START from -- the queue is cut at those, and k_coop<false, true> (mlp_coop.h) reports
+ * the FIR histories in front of exactly those, judged by the same bits.  S: the stream's latched substream count, which
+ * is what the directory is read with (src/mlp.c:463-468, 661-667). */
+static int unit_restarts(const uint8_t *q, size_t pos, size_t size, unsigned S)
+{
+    size_t p = 4 + 28, end0 = 0;
+    unsigned s;
+    if (S != 1 && S != 2)
+        return 0;
+    for (s = 0; s < S; s++) {
+        unsigned e;
+        if (p + 2 > size)
+            return 0;
+        e = ((unsigned)q[pos + p] << 8) | q[pos + p + 1];
+        if (s == 0)
+            end0 = (size_t)(e & 0xFFFu) * 2;
+        p += (e & 0x8000u) ? 4 : 2;
+    }
+    if (p >= size || (q[pos + p] & 0xC0) != 0xC0)
+        return 0;
+    if (S == 2 && (p + end0 >= size || (q[pos + p + end0] & 0xC0) != 0xC0))
+        return 0;
+    return 1;
+}
+
 dvda_hip_mlpdecoder *dvda_hip_open_mlpdecoder(unsigned g0_bps, unsigned g1_bps, unsigned g0_rate,
                                               unsigned g1_rate, unsigned channel_assignment, int device)
 {
@@ -142,7 +170,7 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
                                            const int32_t **planar, unsigned *channels)
 {
     size_t pos, complete_end = 0, last_sync = 0;
-    uint32_t n_sync = 0;
+    uint32_t n_sync = 0, n_sync_all = 0;     /* major syncs of the stream's own parameters: that restart every substream / all */
     dvda_mlp_stream_info info;
     uint64_t meta[4];
     uint64_t rows_cap, R, fresh;
@@ -196,8 +224,12 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
                 complete_end = pos;
                 continue;
             }
-            n_sync++;
-            last_sync = pos;
+            n_sync_all++;
+            /* (the queue is cut, and a fall-back decode starts, only at a unit that restarts every substream) */
+            if (unit_restarts(d->q, pos, size, d->sync_params[3])) {
+                n_sync++;
+                last_sync = pos;
+            }
         } else if (pos == 0) {
             d->status |= DVDA_ST_NO_SYNC;           /* substream count unknown: undefined in the reference */
             return 0;
@@ -344,10 +376,10 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
         return 0;
     if (!d->ctx && dvda_mlp_hip_create(&d->ctx, d->device, 1, d->ctx_segments) != DVDA_HIP_OK)
         return 0;
-    if (n_sync + 1 > d->ctx_segments) {
+    if (n_sync_all + 1 > d->ctx_segments) {
         dvda_mlp_hip_destroy(d->ctx);
         d->ctx = NULL;
-        d->ctx_segments = 2 * (n_sync + 1);
+        d->ctx_segments = 2 * (n_sync_all + 1);
         if (dvda_mlp_hip_create(&d->ctx, d->device, 1, d->ctx_segments) != DVDA_HIP_OK)
             return 0;
     }
@@ -441,34 +473,32 @@ unsigned dvda_hip_mlpdecoder_decode_packet(dvda_hip_mlpdecoder *d, const uint8_t
     /* ---- keep what the next call needs: bytes from the last major sync on, the FIR history in
      *      front of that segment, and how many of its frames have been handed out */
     if (n_sync >= 2) {
-        /* device segment indices also count sync patterns found inside payload bytes
-           (DVDA_ST_FALSE_SYNC): the last two LIVE segments are the ones wanted */
-        dvda_mlp_segment_info si, sp;
-        uint32_t n_dev = 0, last_i, prev_i;
+        /* device segment indices also count sync patterns found inside payload bytes (DVDA_ST_FALSE_SYNC) and the
+           syncs that restart nothing: wanted are the LIVE segments from the queue's new first unit on (their PCM frames
+           have been handed out) and the live one in front of them (its FIR history at its end) */
+        dvda_mlp_segment_info si;
+        uint32_t n_dev = 0, prev_i;
+        uint64_t rows_after = 0;
+        int found = 0;
         if (dvda_mlp_hip_segment_count(d->ctx, &n_dev, NULL) || n_dev < 2)
             return 0;
-        last_i = n_dev - 1;
-        for (;;) {
-            if (dvda_mlp_hip_segment_info(d->ctx, last_i, &si, NULL))
+        for (prev_i = n_dev; prev_i-- > 0;) {
+            if (dvda_mlp_hip_segment_info(d->ctx, prev_i, &si, NULL))
                 return 0;
-            if (!(si.status & DVDA_ST_FALSE_SYNC) || last_i == 0)
+            if (si.status & DVDA_ST_FALSE_SYNC)
+                continue;
+            if (si.offset < last_sync) {
+                found = 1;
                 break;
-            last_i--;
+            }
+            rows_after += si.pcm_frames;
         }
-        if (last_i == 0)
+        if (!found)
             return 0;
-        prev_i = last_i - 1;
-        for (;;) {
-            if (dvda_mlp_hip_segment_info(d->ctx, prev_i, &sp, NULL))
-                return 0;
-            if (!(sp.status & DVDA_ST_FALSE_SYNC) || prev_i == 0)
-                break;
-            prev_i--;
-        }
         if (dvda_mlp_hip_segment_fir(d->ctx, prev_i, d->fir, NULL))
             return 0;
         d->have_fir = 1;
-        d->rows_before = si.pcm_frames;
+        d->rows_before = rows_after;
         memmove(d->q, d->q + last_sync, d->qlen - last_sync);
         d->qlen -= last_sync;
         d->decoded_end = complete_end - last_sync;

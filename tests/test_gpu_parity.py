@@ -243,7 +243,10 @@ def test_streaming_tier_state_on_the_device_and_its_fall_back(pkg, oracle, S):
     SF = syn.SF
     fast = SF["CHAINED"] | SF["FIRRAND"] | SF["IIR"] | SF["PARAMBLOCKS"] | SF["MATRIXRAND"] | SF["MIDMATRIX"] | \
         SF["QSS"] | SF["OUTSHIFT"] | SF["VARBLOCK"] | SF["MIXBOOKS"] | SF["MIDRESTART"]
-    for feats, want_path in ((fast, 0), (fast | SF["VARROWS"], 1)):
+    # (SYNCONLY: major syncs in front of units that restart nothing, src/mlp.c:449-460 -- the state on the device decodes
+    #  through them; the queue is cut, and the fall-back starts, only at a sync whose substreams all restart)
+    for feats, want_path in ((fast, 0), (fast | SF["VARROWS"], 1), (fast | SF["SYNCONLY"], 0),
+                             (fast | SF["SYNCONLY"] | SF["VARROWS"], 1)):
         for seed in range(4):
             cfg = syn.make_cfg(assignment=12 if S == 2 or seed % 2 == 0 else 1, rate_code=seed % 3, n_substreams=S, n_aus=36,
                                profile=1, features=feats, restart_interval=[4, 3, 8, 5][seed])

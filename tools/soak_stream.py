@@ -30,6 +30,8 @@ for i in range(n):
     S = 1 + (i & 1)
     asg = int(rng.choice(two)) if S == 2 else int(rng.randint(0, 21))
     feats = int(rng.randint(0, 1 << 18)) if i % 3 else syn.SF_ALL
+    if i % 7 == 3:
+        feats |= syn.SF["SYNCONLY"]          # major syncs that restart nothing (src/mlp.c:449-460)
     cfg = syn.make_cfg(assignment=asg, rate_code=int(rng.randint(0, 3)), n_substreams=S,
                        n_aus=int(rng.randint(6, 48)), profile=1, features=feats,
                        restart_interval=int(rng.randint(1, 9)))
