@@ -516,11 +516,27 @@ struct BitReaderT {
     //  per read_signed" in round 4's stamps.  Filled together the lanes stay together: three or four.)
     __device__ __forceinline__ void ensure(uint32_t n)
     {
+#if defined(DVDA_EXP_STAMP)
+        const unsigned long long t0_ = clock64();       // (diagnostic: the wave's time inside synchronous fills)
+        bool any_ = false;
+#endif
         while (__builtin_expect(__any(ahead() < (int32_t)n), 0)) {
             if (room())
                 fill_sync();
+#if defined(DVDA_EXP_STAMP)
+            any_ = true;
+#endif
         }
+#if defined(DVDA_EXP_STAMP)
+        if (any_) {
+            fill_cyc += clock64() - t0_;
+            fill_n++;
+        }
+#endif
     }
+#if defined(DVDA_EXP_STAMP)
+    unsigned long long fill_cyc = 0, fill_n = 0;
+#endif
     // repositions the reader
     __device__ __forceinline__ void seek_byte(uint64_t byte_pos)
     {
@@ -1128,6 +1144,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = clock64();
     unsigned long long hstamp_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long hfills = 0, hcount = 0;
     unsigned long long hstamp_t = 0;
 #endif
     for (;;) {
@@ -1153,6 +1170,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         if (__builtin_expect(hdr_now, 0)) {
 #if defined(DVDA_EXP_STAMP)
             hstamp_t = clock64();
+            rd.fill_cyc = rd.fill_n = 0;
+            if constexpr (DUO)
+                rx.fill_cyc = rx.fill_n = 0;
 #endif
             // (a loop only because of dropped frames: a frame that carries a major sync with other stream
             //  parameters yields nothing and the next one is looked at, src/mlp.c:449-460)
@@ -1795,8 +1815,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
                 }
             }
         }
-        if (hdr_now)
+        if (hdr_now) {
             DVDA_HSTAMP(4);
+#if defined(DVDA_EXP_STAMP)
+            hstamp_acc[5] += rd.fill_cyc + (DUO ? rx.fill_cyc : 0ull);     // inside the header phase: synchronous fills ...
+            hfills += rd.fill_n + (DUO ? rx.fill_n : 0ull);                 // ... and how many
+            hcount++;
+#endif
+        }
         if (!__any(active))
             break;
         DVDA_STAMP(0);
@@ -2541,8 +2567,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void k_decode(DecodeArgs a)
         for (int i = 0; i < 8; i++)
             atomicAdd(&a.dbg[i], stamp_acc[i]);
     if (lane == 0 && a.dbg)
-        for (int i = 0; i < 5; i++)
+        for (int i = 0; i < 6; i++)
             atomicAdd(&a.dbg[8 + i], hstamp_acc[i]);
+    if (lane == 0 && a.dbg) {
+        atomicAdd(&a.dbg[14], hfills);
+        atomicAdd(&a.dbg[15], hcount);
+    }
 #endif
     if (!GENERAL && !PARSE && a.fir_ws && segi < n_seg && sub < S && frames_done == sr.nframes && sr.nframes) {
         // FIR history at the segment's end, for a following segment that depends on it
