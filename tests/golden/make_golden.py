@@ -46,6 +46,10 @@ FIXTURES = [
     ("fuzz_2ch_176k_16bit", 1, 10, 1, 12, 1, syn.SF_FAST, 24, 4, dict(bps_code=0)),
     ("check_flags_disagree_2ss", 12, 1, 2, 24, 1, SF["CHECKQUIRK"] | SF["NOCHECK"] | SF["FIRRAND"] | SF["PARAMBLOCKS"], 25, 4),
     ("disc_profile_2ss", 12, 1, 2, 24, 1, SF["DISC"] | SF["CHAINED"] | SF["FIRRAND"] | SF["MIXBOOKS"], 26, 8),
+    # round 6: major syncs in front of access units that carry NO restart header (src/mlp.c:449-460: the sync's
+    # parameters are compared and the decode goes on with the state it has; decode_block src/mlp.c:748-753)
+    ("sync_only_6ch", 12, 1, 1, 32, 1, SF["SYNCONLY"] | SF["FIRRAND"] | SF["PARAMBLOCKS"] | SF["IIR"], 27, 8),
+    ("sync_only_chained_2ss", 12, 1, 2, 32, 1, SF["SYNCONLY"] | SF["CHAINED"] | SF["FIRRAND"] | SF["MIXBOOKS"], 28, 5),
 ]
 
 
