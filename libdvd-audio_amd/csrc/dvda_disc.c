@@ -756,7 +756,8 @@ done:
  * therefore read and decoded window by window:
  *
  *   window = the next WINDOW_SECTORS sectors of the track -> GPU demux -> [bytes kept from the window before | new bytes]
- *   cut    = the LAST major sync of that stream at which a segment starts (the index says where: restart segments
+ *   cut    = the LAST major sync of that stream at which a segment starts AND every substream restarts
+ *            (win_unit_restarts: a window cannot begin at a sync that restarts nothing) (the index says where: restart segments
  *            are the units of parallel decode): everything in front of it is whole segments and is decoded
  *            now; what follows is kept for the next window.  The first window starts at the first major-sync
  *            pattern, the last one ends as open_mlp()'s whole track does (src/dvd-audio.c:1167-1194).

@@ -5,7 +5,8 @@
  * decoder state from packet to packet inside MLPDecoder; here the state that can cross a call
  * is reduced to what the format really needs by cutting only at major syncs:
  *
- *   - the queue keeps every byte from the last major-sync access unit onward, so each call
+ *   - the queue keeps every byte from the last major-sync access unit onward (round 6: the last one whose substreams
+ *     all open with a restart header -- unit_restarts(); a sync need not restart anything, src/mlp.c:449-460), so each call
  *     re-decodes at most one restart segment it has seen before (parameters, noise seed, IIR
  *     history are all re-established by that segment's restart header, src/mlp.c:867-990);
  *   - the FIR history -- the one thing the reference never resets (src/mlp.c:297-304, 1302) --
