@@ -524,7 +524,8 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     syn, hip = pkg.synth, pkg.hipdec
     out = {}
 
-    def in_flight(depth, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign, k_steps, name, replicas=1):
+    def in_flight(depth, flat, offs, sizes, frames, nchs, nseg, layout, chained, benign, k_steps, name, replicas=1,
+                  what=None):
         """the same small batch with `depth` decode contexts in flight (own HIP stream and PCM buffer each, the
         non-blocking decode call): a batch the cooperative kernel decodes leaves most of the device idle, a feeder
         with more than one such batch to decode overlaps them.  Every slot's PCM must be the same."""
@@ -538,8 +539,8 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
             raise SystemExit("sub-record %s: the pipelined decode differs (slots equal %s, oracle %s)" % (name, same, okp))
         r = {"contexts_in_flight": depth, "value": round(bp.samples * k_steps / dtp / 1e6, 1), "unit": "Msamples/s",
              "ms_per_step": round(dtp / k_steps * 1e3, 4), "steps": k_steps, "slots_bit_identical": same,
-             "what": "%d decode contexts in flight on their own HIP streams, non-blocking decode call; a step is still "
-                     "one index + one decode of the whole batch" % depth}
+             "what": what or ("%d decode contexts in flight on their own HIP streams, non-blocking decode call; a step is "
+                              "still one index + one decode of the whole batch" % depth)}
         bp.close()
         del bp
         torch.cuda.empty_cache()
@@ -595,6 +596,17 @@ def sub_records(pkg, torch, dev, local_rank, args, main_batch, steps, warmup):
     nseg = args.streams * args.replicas * ((args.aus + cfg.restart_interval - 1) // cfg.restart_interval)
     run("planar_layout", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, "planar", 0,
         note="same titles as the headline, PCM written planar [channel][frame] (reference decode_packet order)")
+    # ---- the headline batch with TWO steps in flight (what a feeder with a second batch to decode does; `--pipeline 2` makes
+    #      the main record run this way): the host's part of a step and most of the next batch's index hide behind this
+    #      batch's decode.  Not the main record: k_decode shares the device with the other step's index kernels and its own
+    #      time -- what the roofline figure is quoted on -- rises with it
+    if not only or "two_steps_in_flight" in only:
+        out["two_steps_in_flight"] = in_flight(
+            2, flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.layout, False, 0, max(steps, 30),
+            "two_steps_in_flight", replicas=args.replicas,
+            what="the headline batch, two decode contexts in flight (own HIP stream and PCM buffer each, non-blocking decode "
+                 "call, the second step's decode ordered behind the first's by an event): a step is still one index + one "
+                 "decode of the whole batch; whole-job throughput of a feeder that always has the next batch ready")
     # ---- the output stage fused into the decode: interleaved packed 24-bit WAV payload, 3 B per sample out
     run("wav24_output", flat, offs, sizes, frames, np.full(len(sizes), 6), nseg, args.replicas, "wav24", 0,
         note="same titles, d_pcm receives the little-endian 24-bit WAV payload dvda2wav writes (write_signed): "
